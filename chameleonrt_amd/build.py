@@ -1,0 +1,44 @@
+"""Build the HIP core (libcrt_hip_core.so) for gfx950, in-tree.
+
+    python -m chameleonrt_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU
+box with the working tree. Parity builds use -ffp-contract=off and no fast-math so that
++ - * / sqrt are bit-reproducible against the CPU oracle (DESIGN.md "Numerics").
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcrt_hip_core.so")
+SOURCES = ["kernels.hip", "crt_core.cpp", "bvh_builder.cpp"]
+HEADERS = ["crt_types.h", "pt_device.h", "traverse.h", "wavefront.h", "kernels.h", "bvh_builder.h",
+           os.path.join("..", "..", "include", "crt_hip.h"), os.path.join("..", "..", "include", "crt_kat.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

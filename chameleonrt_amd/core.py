@@ -1,0 +1,104 @@
+"""ctypes binding of the C-ABI in include/crt_hip.h (libcrt_hip_core.so).
+
+This is plumbing only: every call goes straight to the HIP core. There is no Python or CPU
+implementation of the render path behind it -- if the shared library is missing or no GPU is
+present, the functions raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import SceneDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrt_hip_core.so")
+
+FLAG_COUNTERS = 1
+FLAG_TIMING = 2
+
+# every symbol include/crt_hip.h declares
+EXPORTS = [
+    "crt_hip_abi_version", "crt_hip_device_count", "crt_hip_create", "crt_hip_destroy",
+    "crt_hip_last_error", "crt_hip_name", "crt_hip_set_stream", "crt_hip_set_partition",
+    "crt_hip_initialize", "crt_hip_set_scene", "crt_hip_render", "crt_hip_framebuffer",
+    "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_frame_id", "crt_hip_tile_buffer",
+    "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
+    "crt_hip_bvh_copy",
+]
+
+
+class RenderStats(C.Structure):
+    """crt_render_stats (RenderStats of util/render_backend.h:7-10 + roofline inputs)."""
+    _fields_ = [("render_time_ms", C.c_float), ("rays_per_second", C.c_float), ("rays", C.c_uint64),
+                ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("closest_ms", C.c_float),
+                ("shadow_ms", C.c_float), ("shade_ms", C.c_float), ("closest_nodes", C.c_uint64),
+                ("closest_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class CoreError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libcrt_hip_core.so; raises if it has not been built (python -m chameleonrt_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CoreError(f"{LIB_PATH} not found: build it with `python -m chameleonrt_amd.build` "
+                        "(there is no CPU fallback for the render path)")
+    L = C.CDLL(LIB_PATH)
+    fp, u32p, i32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p
+    L.crt_hip_abi_version.restype = C.c_int
+    L.crt_hip_device_count.restype = C.c_int
+    L.crt_hip_create.restype = vp
+    L.crt_hip_create.argtypes = [C.c_int, C.c_uint32]
+    L.crt_hip_destroy.argtypes = [vp]
+    L.crt_hip_destroy.restype = None
+    L.crt_hip_last_error.restype = C.c_char_p
+    L.crt_hip_last_error.argtypes = [vp]
+    L.crt_hip_name.restype = C.c_char_p
+    L.crt_hip_name.argtypes = [vp]
+    L.crt_hip_set_stream.argtypes = [vp, vp]
+    L.crt_hip_set_partition.argtypes = [vp, C.c_int, C.c_int]
+    L.crt_hip_initialize.argtypes = [vp, C.c_int, C.c_int]
+    L.crt_hip_set_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.crt_hip_render.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.POINTER(RenderStats)]
+    L.crt_hip_framebuffer.restype = u32p
+    L.crt_hip_framebuffer.argtypes = [vp]
+    L.crt_hip_read_accum.argtypes = [vp, fp]
+    L.crt_hip_read_ray_counts.argtypes = [vp, u32p]
+    L.crt_hip_frame_id.restype = C.c_uint32
+    L.crt_hip_frame_id.argtypes = [vp]
+    L.crt_hip_tile_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.crt_hip_assemble_tiles.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.crt_hip_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, fp, fp, fp, i32p, i32p, i32p,
+                                     C.POINTER(RenderStats)]
+    L.crt_hip_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
+    L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p]
+    L.crt_hip_bvh_copy.argtypes = [vp, vp, vp]
+    for fn in ("crt_hip_set_stream", "crt_hip_set_partition", "crt_hip_initialize", "crt_hip_set_scene",
+               "crt_hip_render", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_tile_buffer",
+               "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
+               "crt_hip_bvh_copy"):
+        getattr(L, fn).restype = C.c_int
+    _lib = L
+    return L
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def check(ctx, rc, what):
+    """Error codes -> exceptions, the reference's error convention."""
+    if rc != 0:
+        msg = load().crt_hip_last_error(ctx)
+        raise CoreError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,32 @@
+// bvh_builder.h — host-side binned-SAH BVH2 builder producing the 64-byte node layout the
+// traversal kernels read (crt_types.h). Stands in for Embree's rtcCommitScene
+// (reference backends/embree/embree_utils.cpp:63-76, 121-129); static scenes only, so the build
+// runs once per set_scene on the host cores and the result is uploaded to HBM.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "crt_types.h"
+
+namespace crt {
+
+struct Aabb {
+    float lo[3], hi[3];
+};
+
+struct BuiltBvh {
+    std::vector<BvhNode> nodes;  // nodes[0] is the root; the first n_top nodes are the top levels in BFS order
+    std::vector<uint32_t> order; // item ids in leaf order (leaf `first` indexes this array)
+    uint32_t n_top = 0;
+    Aabb bounds;
+    uint32_t max_depth = 0;
+};
+
+// boxes: one per item. Leaves hold at most max_leaf (<= 8) items.
+// node_base / item_base are added to the inner-node indices / leaf `first` values so several
+// BVHs can be concatenated into one array. If leaf_holds_item_id is set (TLAS), max_leaf must
+// be 1 and a leaf's `first` is the item id itself instead of its position in `order`.
+BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
+                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads);
+
+} // namespace crt

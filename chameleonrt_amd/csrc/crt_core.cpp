@@ -1,0 +1,1145 @@
+// crt_core.cpp — the C-ABI of include/crt_hip.h: context, scene upload, frame loop.
+//
+// Host half of the MI355X backend, mirroring what RenderEmbree does around its kernels
+// (reference backends/embree/render_embree.cpp:19-216): initialize -> framebuffer + accumulation
+// state, set_scene -> geometry/BVH/textures/materials/lights resident in HBM, render -> view
+// parameters, the wavefront launch sequence, timing and REPORT_RAY_STATS accounting.
+// There is no CPU fallback anywhere in this file: no device, no context.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "bvh_builder.h"
+#include "crt_types.h"
+#include "kernels.h"
+#include "wavefront.h"
+
+using namespace crt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError {
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t err__ = (expr);                                                                        \
+        if (err__ != hipSuccess) {                                                                        \
+            throw HipError{std::string(#expr) + ": " + hipGetErrorString(err__)};                          \
+        }                                                                                                 \
+    } while (0)
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n)
+    {
+        release();
+        if (n == 0) {
+            n = 16;
+        }
+        HIP_CHECK(hipMalloc(&ptr, n));
+        bytes = n;
+    }
+    void release()
+    {
+        if (ptr) {
+            (void)hipFree(ptr);
+            ptr = nullptr;
+            bytes = 0;
+        }
+    }
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+};
+
+template <typename T> void upload(DeviceBuffer &buf, const std::vector<T> &v, hipStream_t s)
+{
+    buf.alloc(v.size() * sizeof(T));
+    if (!v.empty()) {
+        HIP_CHECK(hipMemcpyAsync(buf.ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+}
+
+// util/util.cpp:102-108 (std::pow(float, double): evaluated in double)
+inline float srgb_to_linear(float x)
+{
+    if (x <= 0.04045f) {
+        return x / 12.92f;
+    }
+    return (float)std::pow((double)((x + 0.055f) / 1.055f), 2.4);
+}
+
+// 4x4 inverse by cofactor expansion: stands in for glm::inverse (embree_utils.cpp:97).
+bool invert4x4(const float m[16], float out[16])
+{
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
+             m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
+             m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
+             m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
+              m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
+             m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
+             m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
+             m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
+              m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
+             m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
+             m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
+              m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
+              m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
+             m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
+             m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
+              m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
+              m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.f) {
+        return false;
+    }
+    const float r = 1.f / det;
+    for (int i = 0; i < 16; ++i) {
+        out[i] = inv[i] * r;
+    }
+    return true;
+}
+
+bool is_identity(const float m[16])
+{
+    static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    return std::memcmp(m, id, sizeof(id)) == 0;
+}
+
+struct Vec3 {
+    float x, y, z;
+};
+inline Vec3 sub(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 mul(Vec3 a, float s) { return Vec3{a.x * s, a.y * s, a.z * s}; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
+{
+    const float c = 1.f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    return Vec3{v.x * c, v.y * c, v.z * c};
+}
+
+constexpr int MAX_TOP_NODES_HOST = 255; // must match kernels.hip MAX_TOP_NODES
+constexpr uint32_t MAX_TRAVERSAL_DEPTH = 60;
+
+} // namespace
+
+struct crt_hip_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int n_cus = 256;
+    std::string name, err;
+    int rank = 0, world = 1;
+
+    // framebuffer state (RenderEmbree::initialize)
+    int width = 0, height = 0, ntx = 0, nty = 0;
+    std::vector<uint32_t> tile_ids; // tiles this rank renders
+    uint32_t n_local_tiles = 0, n_tiles_padded = 0;
+    DeviceBuffer d_tile_ids, d_accum, d_tile_fb, d_img, d_ray_counts;
+    std::vector<uint32_t> img;
+    uint32_t frame_id = 0;
+
+    // scene (RenderEmbree::set_scene)
+    bool has_scene = false;
+    uint32_t spp = 1;
+    SceneView sv{};
+    DeviceBuffer d_nodes, d_tris, d_instances, d_geoms, d_indices, d_uvs, d_material_ids, d_materials, d_textures,
+        d_texels, d_lights;
+    uint64_t n_nodes = 0, n_tris = 0;
+
+    // wavefront state
+    uint64_t capacity = 0; // paths per pass
+    DeviceBuffer d_queue_mem, d_pc;
+    PathQueue q[2]{};
+    HitBuf hits{};
+    ShadowQueueA sa{};
+    ShadowQueueB sb{};
+    float4 *radiance = nullptr;
+    PassCounters *h_pc = nullptr; // pinned, one per pass
+    uint32_t h_pc_slots = 0;
+    std::vector<hipEvent_t> events;
+
+    ~crt_hip_ctx()
+    {
+        for (hipEvent_t e : events) {
+            (void)hipEventDestroy(e);
+        }
+        if (h_pc) {
+            (void)hipHostFree(h_pc);
+        }
+        if (own_stream) {
+            (void)hipStreamDestroy(own_stream);
+        }
+    }
+    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0}; }
+};
+
+namespace {
+
+int fail(crt_hip_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) {
+        ctx->err = msg;
+    } else {
+        g_create_error = msg;
+    }
+    return code;
+}
+
+template <typename F> int guarded(crt_hip_ctx *ctx, F &&f)
+{
+    if (!ctx) {
+        return fail(nullptr, CRT_HIP_EINVAL, "null context");
+    }
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        return f();
+    } catch (const HipError &e) {
+        return fail(ctx, CRT_HIP_EDEVICE, e.msg);
+    } catch (const std::exception &e) {
+        return fail(ctx, CRT_HIP_EINVAL, e.what());
+    }
+}
+
+uint64_t default_capacity()
+{
+    if (const char *s = std::getenv("CRT_HIP_MAX_PATHS")) {
+        const long long v = std::atoll(s);
+        if (v > 0) {
+            return (uint64_t)v;
+        }
+    }
+    return 32ull << 20; // 32 Mi paths ~ 7.7 GiB of queue state, a sliver of 288 GB
+}
+
+// carve the SoA queues out of one allocation
+void setup_queues(crt_hip_ctx *c)
+{
+    const uint64_t total_slots = (uint64_t)c->n_local_tiles * TILE_PIXELS;
+    uint64_t cap = std::min<uint64_t>(default_capacity(), total_slots * c->spp);
+    const uint64_t slots_per_pass = std::max<uint64_t>(64, (cap / c->spp) / 64 * 64);
+    cap = slots_per_pass * c->spp;
+    c->capacity = cap;
+    const size_t n_fields = 2 * 11 + 5 + 12 + 18 + 4;
+    c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
+    uint32_t *base = c->d_queue_mem.as<uint32_t>();
+    size_t k = 0;
+    auto f32 = [&]() { return reinterpret_cast<float *>(base + (k++) * cap); };
+    auto u32 = [&]() { return base + (k++) * cap; };
+    auto i32 = [&]() { return reinterpret_cast<int32_t *>(base + (k++) * cap); };
+    for (int qi = 0; qi < 2; ++qi) {
+        for (int a = 0; a < 3; ++a) {
+            c->q[qi].o[a] = f32();
+        }
+        for (int a = 0; a < 3; ++a) {
+            c->q[qi].d[a] = f32();
+        }
+        c->q[qi].path = u32();
+        c->q[qi].rng = u32();
+        for (int a = 0; a < 3; ++a) {
+            c->q[qi].tp[a] = f32();
+        }
+    }
+    c->hits.t = f32();
+    c->hits.u = f32();
+    c->hits.v = f32();
+    c->hits.tri = i32();
+    c->hits.inst = i32();
+    for (int a = 0; a < 3; ++a) {
+        c->sa.o[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        c->sa.d[a] = f32();
+    }
+    c->sa.tmax = f32();
+    for (int a = 0; a < 3; ++a) {
+        c->sa.c[a] = f32();
+    }
+    c->sa.path = u32();
+    c->sa.bslot = i32();
+    for (int a = 0; a < 3; ++a) {
+        c->sb.o[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        c->sb.d[a] = f32();
+    }
+    c->sb.tmax = f32();
+    for (int a = 0; a < 3; ++a) {
+        c->sb.ca[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        c->sb.cb[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        c->sb.tp[a] = f32();
+    }
+    c->sb.path = u32();
+    c->sb.vis_a = i32();
+    c->radiance = reinterpret_cast<float4 *>(base + k * cap);
+    c->d_pc.alloc(sizeof(PassCounters));
+    const uint64_t total_paths = total_slots * c->spp;
+    const uint32_t n_pass = (uint32_t)((total_paths + cap - 1) / cap);
+    if (c->h_pc) {
+        (void)hipHostFree(c->h_pc);
+        c->h_pc = nullptr;
+    }
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pc), sizeof(PassCounters) * n_pass));
+    c->h_pc_slots = n_pass;
+}
+
+hipEvent_t get_event(crt_hip_ctx *c, size_t i)
+{
+    while (c->events.size() <= i) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        c->events.push_back(e);
+    }
+    return c->events[i];
+}
+
+void check_scene(const crt_scene_desc *s)
+{
+    if (!s) {
+        throw std::runtime_error("scene is null");
+    }
+    if (s->n_instances == 0 || s->n_meshes == 0 || s->n_geometries == 0) {
+        throw std::runtime_error("scene has no instances/meshes/geometries");
+    }
+    if (s->n_lights == 0) {
+        throw std::runtime_error("scene has no lights (the reference divides by num_lights)");
+    }
+    if (s->n_materials == 0) {
+        throw std::runtime_error("scene has no materials");
+    }
+    for (uint32_t i = 0; i < s->n_instances; ++i) {
+        const uint32_t pm = s->instances[i].parameterized_mesh_id;
+        if (pm >= s->n_parameterized_meshes) {
+            throw std::runtime_error("instance references a missing parameterized mesh");
+        }
+        const crt_parameterized_mesh_desc &p = s->parameterized_meshes[pm];
+        if (p.mesh_id >= s->n_meshes || p.n_material_ids < s->meshes[p.mesh_id].n_geometries) {
+            throw std::runtime_error("parameterized mesh / material id count mismatch");
+        }
+        for (uint32_t k = 0; k < p.n_material_ids; ++k) {
+            if (p.material_ids[k] >= s->n_materials) {
+                throw std::runtime_error("material id out of range");
+            }
+        }
+    }
+    for (uint32_t m = 0; m < s->n_meshes; ++m) {
+        if (s->meshes[m].first_geometry + s->meshes[m].n_geometries > s->n_geometries) {
+            throw std::runtime_error("mesh geometry range out of bounds");
+        }
+    }
+    for (uint32_t g = 0; g < s->n_geometries; ++g) {
+        const crt_geometry_desc &gd = s->geometries[g];
+        for (uint64_t t = 0; t < 3 * gd.n_triangles; ++t) {
+            if (gd.indices[t] >= gd.n_vertices) {
+                throw std::runtime_error("triangle index out of range");
+            }
+        }
+    }
+    for (uint32_t m = 0; m < s->n_materials; ++m) {
+        for (int k = 0; k < 14; ++k) {
+            if (k == 1 || k == 2) {
+                continue; // base_color.g/.b are never handles
+            }
+            uint32_t bits;
+            std::memcpy(&bits, &s->materials[16 * (size_t)m + k], 4);
+            if ((bits & 0x80000000u) && (bits & 0x1fffffffu) >= s->n_textures) {
+                throw std::runtime_error("material references a missing texture");
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int crt_hip_abi_version(void) { return CRT_HIP_ABI_VERSION; }
+
+int crt_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = "no HIP device available (this backend has no CPU fallback)";
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device id out of range";
+        return nullptr;
+    }
+    std::unique_ptr<crt_hip_ctx> c(new crt_hip_ctx);
+    try {
+        c->device = device_id;
+        c->flags = flags;
+        HIP_CHECK(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        c->n_cus = prop.multiProcessorCount;
+        c->name = std::string("HIP wavefront path tracer (") + prop.name + ", " + prop.gcnArchName + ")";
+        HIP_CHECK(hipStreamCreate(&c->own_stream));
+        c->stream = c->own_stream;
+    } catch (const HipError &err) {
+        g_create_error = err.msg;
+        return nullptr;
+    }
+    return c.release();
+}
+
+void crt_hip_destroy(crt_hip_ctx *ctx)
+{
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        delete ctx;
+    }
+}
+
+const char *crt_hip_last_error(const crt_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *crt_hip_name(const crt_hip_ctx *ctx) { return ctx ? ctx->name.c_str() : ""; }
+uint32_t crt_hip_frame_id(const crt_hip_ctx *ctx) { return ctx ? ctx->frame_id : 0; }
+
+int crt_hip_set_stream(crt_hip_ctx *ctx, void *hip_stream)
+{
+    return guarded(ctx, [&]() -> int {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world)
+{
+    return guarded(ctx, [&]() -> int {
+        if (world < 1 || rank < 0 || rank >= world) {
+            return fail(ctx, CRT_HIP_EINVAL, "bad rank/world");
+        }
+        if (ctx->width != 0) {
+            return fail(ctx, CRT_HIP_ESTATE, "set_partition must precede initialize");
+        }
+        ctx->rank = rank;
+        ctx->world = world;
+        return CRT_HIP_OK;
+    });
+}
+
+// RenderEmbree::initialize (render_embree.cpp:38-56)
+int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
+{
+    return guarded(ctx, [&]() -> int {
+        if (fb_width <= 0 || fb_height <= 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "bad framebuffer size");
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->frame_id = 0;
+        ctx->width = fb_width;
+        ctx->height = fb_height;
+        ctx->ntx = fb_width / TILE + (fb_width % TILE != 0 ? 1 : 0);
+        ctx->nty = fb_height / TILE + (fb_height % TILE != 0 ? 1 : 0);
+        const uint32_t ntiles = (uint32_t)(ctx->ntx * ctx->nty);
+        ctx->tile_ids.clear();
+        for (uint32_t t = (uint32_t)ctx->rank; t < ntiles; t += (uint32_t)ctx->world) {
+            ctx->tile_ids.push_back(t);
+        }
+        ctx->n_local_tiles = (uint32_t)ctx->tile_ids.size();
+        ctx->n_tiles_padded = (ntiles + ctx->world - 1) / ctx->world;
+        ctx->img.assign((size_t)fb_width * fb_height, 0u);
+        std::vector<uint32_t> ids = ctx->tile_ids;
+        if (ids.empty()) {
+            ids.push_back(0);
+        }
+        upload(ctx->d_tile_ids, ids, ctx->stream);
+        const size_t slots = (size_t)std::max(1u, ctx->n_local_tiles) * TILE_PIXELS;
+        ctx->d_accum.alloc(slots * sizeof(float4));
+        ctx->d_ray_counts.alloc(slots * sizeof(uint32_t));
+        ctx->d_tile_fb.alloc((size_t)std::max(1u, ctx->n_tiles_padded) * TILE_PIXELS * sizeof(uint32_t));
+        ctx->d_img.alloc((size_t)fb_width * fb_height * sizeof(uint32_t));
+        HIP_CHECK(hipMemsetAsync(ctx->d_accum.ptr, 0, ctx->d_accum.bytes, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(ctx->d_ray_counts.ptr, 0, ctx->d_ray_counts.bytes, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(ctx->d_tile_fb.ptr, 0, ctx->d_tile_fb.bytes, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(ctx->d_img.ptr, 0, ctx->d_img.bytes, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->capacity = 0; // queues are (re)sized lazily: they depend on spp too
+        return CRT_HIP_OK;
+    });
+}
+
+// RenderEmbree::set_scene (render_embree.cpp:58-133, embree_utils.cpp:9-136)
+int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
+{
+    return guarded(ctx, [&]() -> int {
+        check_scene(s);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->frame_id = 0;
+        ctx->has_scene = false;
+        ctx->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
+        ctx->capacity = 0;
+        const int n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+
+        // geometry tables
+        std::vector<GeomRec> geoms(s->n_geometries);
+        std::vector<uint32_t> indices;
+        std::vector<float> uvs;
+        {
+            uint64_t n_idx = 0, n_uv = 0;
+            for (uint32_t g = 0; g < s->n_geometries; ++g) {
+                n_idx += 3 * s->geometries[g].n_triangles;
+                n_uv += s->geometries[g].uvs ? 2 * s->geometries[g].n_vertices : 0;
+            }
+            indices.reserve(n_idx);
+            uvs.reserve(n_uv);
+        }
+        for (uint32_t g = 0; g < s->n_geometries; ++g) {
+            const crt_geometry_desc &gd = s->geometries[g];
+            if (indices.size() / 3 + gd.n_triangles >= (1ull << 32) || uvs.size() / 2 + gd.n_vertices >= (1ull << 31)) {
+                throw std::runtime_error("scene too large for 32-bit geometry tables");
+            }
+            geoms[g].index_base = (uint32_t)(indices.size() / 3);
+            indices.insert(indices.end(), gd.indices, gd.indices + 3 * gd.n_triangles);
+            if (gd.uvs) {
+                geoms[g].uv_base = (int32_t)(uvs.size() / 2);
+                uvs.insert(uvs.end(), gd.uvs, gd.uvs + 2 * gd.n_vertices);
+            } else {
+                geoms[g].uv_base = -1;
+            }
+        }
+
+        // one BLAS per Mesh (embree_utils.cpp:63-76)
+        const bool two_level = s->n_instances > 1;
+        std::vector<BvhNode> nodes;
+        std::vector<TriRec> tris;
+        std::vector<int32_t> blas_root(s->n_meshes);
+        std::vector<Aabb> blas_bounds(s->n_meshes);
+        std::vector<uint32_t> blas_top(s->n_meshes);
+        // node 0.. are reserved for the TLAS when two_level so that the staged top levels are the TLAS's
+        std::vector<BuiltBvh> built(s->n_meshes);
+        for (uint32_t m = 0; m < s->n_meshes; ++m) {
+            const crt_mesh_desc &md = s->meshes[m];
+            std::vector<TriRec> recs;
+            std::vector<Aabb> boxes;
+            for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
+                recs.reserve(recs.size() + gd.n_triangles);
+                boxes.reserve(boxes.size() + gd.n_triangles);
+                for (uint64_t t = 0; t < gd.n_triangles; ++t) {
+                    const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
+                    const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
+                    const float *v2 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 2];
+                    TriRec r;
+                    Aabb b;
+                    for (int a = 0; a < 3; ++a) {
+                        r.v0[a] = v0[a];
+                        r.e1[a] = v0[a] - v1[a];
+                        r.e2[a] = v2[a] - v0[a];
+                        b.lo[a] = std::min(v0[a], std::min(v1[a], v2[a]));
+                        b.hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
+                    }
+                    r.geom = k;
+                    r.prim = (uint32_t)t;
+                    r.pad = 0;
+                    recs.push_back(r);
+                    boxes.push_back(b);
+                }
+            }
+            if (recs.empty()) {
+                throw std::runtime_error("mesh without triangles");
+            }
+            built[m] = build_bvh(boxes.data(), boxes.size(), 4, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
+                                 n_threads);
+            if (built[m].max_depth > MAX_TRAVERSAL_DEPTH - 8) {
+                throw std::runtime_error("BVH too deep for the traversal stack");
+            }
+            // triangles in leaf order
+            const size_t tri_base = tris.size();
+            tris.resize(tri_base + recs.size());
+            for (size_t i = 0; i < recs.size(); ++i) {
+                tris[tri_base + i] = recs[built[m].order[i]];
+            }
+            blas_bounds[m] = built[m].bounds;
+            // re-base the node / leaf references later, once the TLAS size is known
+            blas_root[m] = (int32_t)tri_base; // temporarily: triangle base
+        }
+
+        // instances + TLAS (embree_utils.cpp:90-104, 121-129)
+        std::vector<InstanceRec> insts(s->n_instances);
+        std::vector<uint32_t> material_ids;
+        std::vector<Aabb> inst_boxes(s->n_instances);
+        for (uint32_t i = 0; i < s->n_instances; ++i) {
+            const crt_instance_desc &id = s->instances[i];
+            const crt_parameterized_mesh_desc &pm = s->parameterized_meshes[id.parameterized_mesh_id];
+            InstanceRec r;
+            std::memset(&r, 0, sizeof(r));
+            if (!invert4x4(id.transform, r.w2o)) {
+                throw std::runtime_error("singular instance transform");
+            }
+            r.identity = is_identity(id.transform) ? 1u : 0u;
+            r.geom_base = s->meshes[pm.mesh_id].first_geometry;
+            r.mat_base = (uint32_t)material_ids.size();
+            r.blas_root = (int32_t)pm.mesh_id; // temporarily: mesh id
+            material_ids.insert(material_ids.end(), pm.material_ids, pm.material_ids + pm.n_material_ids);
+            insts[i] = r;
+            const Aabb &mb = blas_bounds[pm.mesh_id];
+            Aabb wb;
+            for (int a = 0; a < 3; ++a) {
+                wb.lo[a] = INFINITY;
+                wb.hi[a] = -INFINITY;
+            }
+            const float *m = id.transform;
+            for (int c = 0; c < 8; ++c) {
+                const float p[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1],
+                                    (c & 4) ? mb.hi[2] : mb.lo[2]};
+                for (int a = 0; a < 3; ++a) {
+                    const float w = r.identity ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
+                    wb.lo[a] = std::min(wb.lo[a], w);
+                    wb.hi[a] = std::max(wb.hi[a], w);
+                }
+            }
+            // pad: the BLAS is walked with a transformed (rounded) ray
+            const float ext = std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
+            for (int a = 0; a < 3; ++a) {
+                wb.lo[a] -= 1e-5f * ext;
+                wb.hi[a] += 1e-5f * ext;
+            }
+            inst_boxes[i] = wb;
+        }
+        uint32_t n_top = 0;
+        int32_t root = 0;
+        if (two_level) {
+            BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, MAX_TOP_NODES_HOST, 1);
+            if (tlas.max_depth + 8 > MAX_TRAVERSAL_DEPTH / 2) {
+                throw std::runtime_error("TLAS too deep for the traversal stack");
+            }
+            nodes = tlas.nodes;
+            n_top = tlas.n_top;
+        }
+        for (uint32_t m = 0; m < s->n_meshes; ++m) {
+            const int32_t node_base = (int32_t)nodes.size();
+            const uint32_t tri_base = (uint32_t)blas_root[m];
+            for (BvhNode nd : built[m].nodes) {
+                auto rebase = [&](int32_t c) -> int32_t {
+                    if (c >= 0) {
+                        return c + node_base;
+                    }
+                    const uint32_t x = ~(uint32_t)c;
+                    return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
+                };
+                nd.c0 = rebase(nd.c0);
+                nd.c1 = rebase(nd.c1);
+                nodes.push_back(nd);
+            }
+            blas_root[m] = node_base;
+            blas_top[m] = built[m].n_top;
+            built[m] = BuiltBvh();
+        }
+        if (tris.size() >= (1u << 28)) {
+            throw std::runtime_error("too many triangles for the 28-bit leaf reference");
+        }
+        for (InstanceRec &r : insts) {
+            r.blas_root = blas_root[r.blas_root];
+        }
+        if (!two_level) {
+            root = insts[0].blas_root;
+            n_top = blas_top[s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id];
+        }
+
+        // textures: sRGB -> linear in 8 bits, on the host, like the reference (render_embree.cpp:90-104)
+        std::vector<TexRec> tex(s->n_textures);
+        std::vector<uint8_t> texels;
+        {
+            size_t total = 0;
+            for (uint32_t t = 0; t < s->n_textures; ++t) {
+                const crt_image_desc &im = s->textures[t];
+                if (im.width <= 0 || im.height <= 0 || im.channels < 1 || im.channels > 4 || !im.data) {
+                    throw std::runtime_error("bad texture");
+                }
+                total = (total + 15) / 16 * 16 + (size_t)im.width * im.height * im.channels;
+            }
+            texels.reserve(total + 16);
+        }
+        uint8_t lut[256];
+        for (int v = 0; v < 256; ++v) {
+            const float x = srgb_to_linear(v / 255.f);
+            lut[v] = (uint8_t)std::min(std::max(x * 255.f, 0.f), 255.f);
+        }
+        for (uint32_t t = 0; t < s->n_textures; ++t) {
+            const crt_image_desc &im = s->textures[t];
+            texels.resize((texels.size() + 15) / 16 * 16);
+            TexRec r;
+            std::memset(&r, 0, sizeof(r));
+            r.width = im.width;
+            r.height = im.height;
+            r.channels = im.channels;
+            r.offset = texels.size();
+            const size_t npx = (size_t)im.width * im.height;
+            texels.insert(texels.end(), im.data, im.data + npx * im.channels);
+            if (im.color_space == CRT_COLORSPACE_SRGB) {
+                uint8_t *p = texels.data() + r.offset;
+                const int convert_channels = std::min(3, im.channels);
+                for (size_t px = 0; px < npx; ++px) {
+                    for (int c = 0; c < convert_channels; ++c) {
+                        p[px * im.channels + c] = lut[p[px * im.channels + c]];
+                    }
+                }
+            }
+            tex[t] = r;
+        }
+        std::vector<float> materials((size_t)s->n_materials * 16);
+        std::memcpy(materials.data(), s->materials, materials.size() * sizeof(float));
+        std::vector<float> lights((size_t)s->n_lights * 20);
+        std::memcpy(lights.data(), s->lights, lights.size() * sizeof(float));
+
+        upload(ctx->d_nodes, nodes, ctx->stream);
+        upload(ctx->d_tris, tris, ctx->stream);
+        upload(ctx->d_instances, insts, ctx->stream);
+        upload(ctx->d_geoms, geoms, ctx->stream);
+        upload(ctx->d_indices, indices, ctx->stream);
+        upload(ctx->d_uvs, uvs, ctx->stream);
+        upload(ctx->d_material_ids, material_ids, ctx->stream);
+        upload(ctx->d_materials, materials, ctx->stream);
+        upload(ctx->d_textures, tex, ctx->stream);
+        upload(ctx->d_texels, texels, ctx->stream);
+        upload(ctx->d_lights, lights, ctx->stream);
+        ctx->n_nodes = nodes.size();
+        ctx->n_tris = tris.size();
+
+        SceneView &sv = ctx->sv;
+        sv.nodes = ctx->d_nodes.as<BvhNode>();
+        sv.tris = ctx->d_tris.as<TriRec>();
+        sv.instances = ctx->d_instances.as<InstanceRec>();
+        sv.geoms = ctx->d_geoms.as<GeomRec>();
+        sv.indices = ctx->d_indices.as<uint32_t>();
+        sv.uvs = ctx->d_uvs.as<float>();
+        sv.material_ids = ctx->d_material_ids.as<uint32_t>();
+        sv.materials = ctx->d_materials.as<float>();
+        sv.textures = ctx->d_textures.as<TexRec>();
+        sv.texels = ctx->d_texels.as<uint8_t>();
+        sv.lights = ctx->d_lights.as<float>();
+        sv.n_lights = s->n_lights;
+        sv.n_instances = s->n_instances;
+        sv.root = root;
+        sv.two_level = two_level ? 1u : 0u;
+        sv.n_top_nodes = n_top;
+        ctx->has_scene = true;
+        return CRT_HIP_OK;
+    });
+}
+
+// RenderEmbree::render (render_embree.cpp:135-216)
+int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], const float up_[3], float fovy,
+                   int camera_changed, int readback, crt_render_stats *stats)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene || ctx->width == 0) {
+            return fail(ctx, CRT_HIP_ESTATE, "render before initialize + set_scene");
+        }
+        if (ctx->capacity == 0) {
+            setup_queues(ctx);
+        }
+        if (camera_changed) {
+            ctx->frame_id = 0;
+        }
+        // render_embree.cpp:149-159; glm::radians(x) = x * 0.0174532925...
+        const Vec3 dir{dir_[0], dir_[1], dir_[2]}, up{up_[0], up_[1], up_[2]};
+        const float plane_y = 2.f * std::tan(0.5f * fovy * 0.01745329251994329576923690768489f);
+        const float plane_x = plane_y * (float)ctx->width / (float)ctx->height;
+        const Vec3 du = mul(normalize(cross(dir, up)), plane_x);
+        const Vec3 ndv = normalize(cross(du, dir));
+        const Vec3 dv = mul(Vec3{-ndv.x, -ndv.y, -ndv.z}, plane_y);
+        const Vec3 tl = sub(sub(dir, mul(du, 0.5f)), mul(dv, 0.5f));
+        ViewParams vp;
+        vp.pos[0] = pos[0];
+        vp.pos[1] = pos[1];
+        vp.pos[2] = pos[2];
+        vp.dir_du[0] = du.x;
+        vp.dir_du[1] = du.y;
+        vp.dir_du[2] = du.z;
+        vp.dir_dv[0] = dv.x;
+        vp.dir_dv[1] = dv.y;
+        vp.dir_dv[2] = dv.z;
+        vp.dir_top_left[0] = tl.x;
+        vp.dir_top_left[1] = tl.y;
+        vp.dir_top_left[2] = tl.z;
+        vp.frame_id = ctx->frame_id;
+        vp.fb_width = (uint32_t)ctx->width;
+        vp.fb_height = (uint32_t)ctx->height;
+        vp.spp = ctx->spp;
+        vp.n_tiles_x = (uint32_t)ctx->ntx;
+
+        const LaunchCfg cfg = ctx->cfg();
+        const bool timing = (ctx->flags & CRT_HIP_FLAG_TIMING) != 0;
+        const uint32_t *d_tiles = ctx->d_tile_ids.as<uint32_t>();
+        const uint64_t total_slots = (uint64_t)ctx->n_local_tiles * TILE_PIXELS;
+        const uint64_t slots_per_pass = ctx->capacity / ctx->spp;
+        size_t ev = 0;
+        struct Span {
+            size_t a, b;
+            int kind;
+        };
+        std::vector<Span> spans;
+        auto mark = [&](int kind) {
+            if (timing) {
+                hipEvent_t e0 = get_event(ctx, ev), e1 = get_event(ctx, ev + 1);
+                (void)e1;
+                HIP_CHECK(hipEventRecord(e0, ctx->stream));
+                spans.push_back(Span{ev, ev + 1, kind});
+                ev += 2;
+            }
+        };
+        auto mark_end = [&]() {
+            if (timing) {
+                HIP_CHECK(hipEventRecord(get_event(ctx, spans.back().b), ctx->stream));
+            }
+        };
+
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        uint32_t pass = 0;
+        for (uint64_t slot0 = 0; slot0 < total_slots; slot0 += slots_per_pass, ++pass) {
+            const uint32_t n_slots = (uint32_t)std::min<uint64_t>(slots_per_pass, total_slots - slot0);
+            const uint32_t n_paths = n_slots * ctx->spp;
+            PassCounters *d_pc = ctx->d_pc.as<PassCounters>();
+            HIP_CHECK(hipMemsetAsync(d_pc, 0, sizeof(PassCounters), ctx->stream));
+            mark(2);
+            launch_raygen(cfg, vp, d_tiles, (uint32_t)slot0, n_paths, ctx->q[0], ctx->radiance, d_pc);
+            mark_end();
+            for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
+                mark(0);
+                launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
+                mark_end();
+                mark(2);
+                launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
+                             ctx->radiance, d_pc, b);
+                mark_end();
+                mark(1);
+                launch_trace_shadow_a(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
+                launch_trace_shadow_b(cfg, ctx->sv, ctx->sb, ctx->radiance, d_pc, b);
+                mark_end();
+            }
+            mark(2);
+            launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
+                              ctx->d_tile_fb.as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
+                              ctx->d_ray_counts.as<uint32_t>());
+            mark_end();
+            HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+        }
+        HIP_CHECK(hipGetLastError());
+        if (readback && ctx->world == 1) {
+            HIP_CHECK(hipMemcpyAsync(ctx->img.data(), ctx->d_img.ptr, ctx->img.size() * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const auto t1 = std::chrono::high_resolution_clock::now();
+
+        crt_render_stats st;
+        std::memset(&st, 0, sizeof(st));
+        for (uint32_t p = 0; p < pass; ++p) {
+            const PassCounters &pc = ctx->h_pc[p];
+            for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
+                st.closest_rays += pc.n_queue[b];
+                st.shadow_rays += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
+            }
+            st.closest_nodes += pc.nodes_closest;
+            st.closest_tris += pc.tris_closest;
+            st.shadow_nodes += pc.nodes_shadow;
+            st.shadow_tris += pc.tris_shadow;
+        }
+        st.rays = st.closest_rays + st.shadow_rays;
+        st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
+        st.rays_per_second = (float)(st.rays / (st.render_time_ms * 1.0e-3));
+        if (timing) {
+            for (const Span &sp : spans) {
+                float ms = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&ms, ctx->events[sp.a], ctx->events[sp.b]));
+                (sp.kind == 0 ? st.closest_ms : (sp.kind == 1 ? st.shadow_ms : st.shade_ms)) += ms;
+            }
+        }
+        if (stats) {
+            *stats = st;
+        }
+        ++ctx->frame_id;
+        return CRT_HIP_OK;
+    });
+}
+
+const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx) { return ctx ? ctx->img.data() : nullptr; }
+
+int crt_hip_read_accum(crt_hip_ctx *ctx, float *rgb)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!rgb || ctx->width == 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "read_accum: bad arguments");
+        }
+        const size_t slots = (size_t)ctx->n_local_tiles * TILE_PIXELS;
+        std::vector<float4> a(slots);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpy(a.data(), ctx->d_accum.ptr, slots * sizeof(float4), hipMemcpyDeviceToHost));
+        std::memset(rgb, 0, sizeof(float) * 3 * (size_t)ctx->width * ctx->height);
+        for (uint32_t lt = 0; lt < ctx->n_local_tiles; ++lt) {
+            const uint32_t tile = ctx->tile_ids[lt];
+            const uint32_t tx = (tile % ctx->ntx) * TILE, ty = (tile / ctx->ntx) * TILE;
+            for (uint32_t m = 0; m < (uint32_t)TILE_PIXELS; ++m) {
+                uint32_t ix = 0, iy = 0;
+                for (int b = 0; b < 6; ++b) {
+                    ix |= ((m >> (2 * b)) & 1u) << b;
+                    iy |= ((m >> (2 * b + 1)) & 1u) << b;
+                }
+                const uint32_t x = tx + ix, y = ty + iy;
+                if (x < (uint32_t)ctx->width && y < (uint32_t)ctx->height) {
+                    const float4 v = a[(size_t)lt * TILE_PIXELS + m];
+                    float *dst = rgb + 3 * ((size_t)y * ctx->width + x);
+                    dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                }
+            }
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_read_ray_counts(crt_hip_ctx *ctx, uint32_t *counts)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!counts || ctx->width == 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "read_ray_counts: bad arguments");
+        }
+        const size_t slots = (size_t)ctx->n_local_tiles * TILE_PIXELS;
+        std::vector<uint32_t> a(slots);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpy(a.data(), ctx->d_ray_counts.ptr, slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::memset(counts, 0, sizeof(uint32_t) * (size_t)ctx->width * ctx->height);
+        for (uint32_t lt = 0; lt < ctx->n_local_tiles; ++lt) {
+            const uint32_t tile = ctx->tile_ids[lt];
+            const uint32_t tx = (tile % ctx->ntx) * TILE, ty = (tile / ctx->ntx) * TILE;
+            for (uint32_t m = 0; m < (uint32_t)TILE_PIXELS; ++m) {
+                uint32_t ix = 0, iy = 0;
+                for (int b = 0; b < 6; ++b) {
+                    ix |= ((m >> (2 * b)) & 1u) << b;
+                    iy |= ((m >> (2 * b + 1)) & 1u) << b;
+                }
+                const uint32_t x = tx + ix, y = ty + iy;
+                if (x < (uint32_t)ctx->width && y < (uint32_t)ctx->height) {
+                    counts[(size_t)y * ctx->width + x] = a[(size_t)lt * TILE_PIXELS + m];
+                }
+            }
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_tile_buffer(crt_hip_ctx *ctx, void **device_ptr, size_t *n_bytes)
+{
+    return guarded(ctx, [&]() -> int {
+        if (ctx->width == 0) {
+            return fail(ctx, CRT_HIP_ESTATE, "tile_buffer before initialize");
+        }
+        if (device_ptr) {
+            *device_ptr = ctx->d_tile_fb.ptr;
+        }
+        if (n_bytes) {
+            *n_bytes = (size_t)ctx->n_tiles_padded * TILE_PIXELS * sizeof(uint32_t);
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered, int world, int readback)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!gathered || world != ctx->world || ctx->width == 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "assemble_tiles: bad arguments");
+        }
+        launch_assemble(ctx->cfg(), static_cast<const uint32_t *>(gathered), ctx->n_tiles_padded * TILE_PIXELS, world,
+                        (uint32_t)ctx->width, (uint32_t)ctx->height, ctx->d_img.as<uint32_t>());
+        HIP_CHECK(hipGetLastError());
+        if (readback) {
+            HIP_CHECK(hipMemcpyAsync(ctx->img.data(), ctx->d_img.ptr, ctx->img.size() * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const float *dir, const float *tmin,
+                       const float *tmax, int closest, float *out_t, float *out_u, float *out_v, int32_t *out_inst,
+                       int32_t *out_geom, int32_t *out_prim, crt_render_stats *stats)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene) {
+            return fail(ctx, CRT_HIP_ESTATE, "trace_rays before set_scene");
+        }
+        if (!org || !dir || !tmin || !tmax || !out_t || n == 0 || n > 0x7fffffffull ||
+            (closest && (!out_u || !out_v || !out_inst || !out_geom || !out_prim))) {
+            return fail(ctx, CRT_HIP_EINVAL, "trace_rays: bad arguments");
+        }
+        DeviceBuffer d_org, d_dir, d_tmin, d_tmax, d_t, d_u, d_v, d_inst, d_geom, d_prim, d_ctr;
+        d_org.alloc(n * 12);
+        d_dir.alloc(n * 12);
+        d_tmin.alloc(n * 4);
+        d_tmax.alloc(n * 4);
+        d_t.alloc(n * 4);
+        d_u.alloc(n * 4);
+        d_v.alloc(n * 4);
+        d_inst.alloc(n * 4);
+        d_geom.alloc(n * 4);
+        d_prim.alloc(n * 4);
+        d_ctr.alloc(16);
+        hipStream_t s = ctx->stream;
+        HIP_CHECK(hipMemcpyAsync(d_org.ptr, org, n * 12, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_dir.ptr, dir, n * 12, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_tmin.ptr, tmin, n * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_tmax.ptr, tmax, n * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 16, s));
+        hipEvent_t e0 = get_event(ctx, 0), e1 = get_event(ctx, 1);
+        HIP_CHECK(hipEventRecord(e0, s));
+        launch_trace_diag(ctx->cfg(), ctx->sv, (uint32_t)n, d_org.as<float>(), d_dir.as<float>(), d_tmin.as<float>(),
+                          d_tmax.as<float>(), closest != 0, d_t.as<float>(), d_u.as<float>(), d_v.as<float>(),
+                          d_inst.as<int32_t>(), d_geom.as<int32_t>(), d_prim.as<int32_t>(),
+                          d_ctr.as<unsigned long long>());
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out_t, d_t.ptr, n * 4, hipMemcpyDeviceToHost, s));
+        if (closest) {
+            HIP_CHECK(hipMemcpyAsync(out_u, d_u.ptr, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(out_v, d_v.ptr, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(out_inst, d_inst.ptr, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(out_geom, d_geom.ptr, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(out_prim, d_prim.ptr, n * 4, hipMemcpyDeviceToHost, s));
+        }
+        unsigned long long ctr[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(ctr, d_ctr.ptr, 16, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (stats) {
+            std::memset(stats, 0, sizeof(*stats));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            stats->rays = n;
+            stats->render_time_ms = ms;
+            stats->rays_per_second = (float)(n / (ms * 1e-3));
+            if (closest) {
+                stats->closest_rays = n;
+                stats->closest_ms = ms;
+                stats->closest_nodes = ctr[0];
+                stats->closest_tris = ctr[1];
+            } else {
+                stats->shadow_rays = n;
+                stats->shadow_ms = ms;
+                stats->shadow_nodes = ctr[0];
+                stats->shadow_tris = ctr[1];
+            }
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_stride, float *out, int out_stride)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!in || !out || n == 0 || n > 0x7fffffffull || in_stride <= 0 || out_stride <= 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "kat: bad arguments");
+        }
+        DeviceBuffer d_in, d_out;
+        d_in.alloc(n * in_stride * 4);
+        d_out.alloc(n * out_stride * 4);
+        hipStream_t s = ctx->stream;
+        HIP_CHECK(hipMemcpyAsync(d_in.ptr, in, n * in_stride * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(d_out.ptr, 0, n * out_stride * 4, s));
+        if (launch_kat(ctx->cfg(), ctx->sv, fn, (uint32_t)n, d_in.as<float>(), in_stride, d_out.as<float>(),
+                       out_stride) != 0) {
+            return fail(ctx, CRT_HIP_EINVAL, "kat: unknown function id");
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, d_out.ptr, n * out_stride * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris, uint64_t *n_instances,
+                     int32_t *two_level)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene) {
+            return fail(ctx, CRT_HIP_ESTATE, "bvh_info before set_scene");
+        }
+        if (n_nodes) {
+            *n_nodes = ctx->n_nodes;
+        }
+        if (n_tris) {
+            *n_tris = ctx->n_tris;
+        }
+        if (n_instances) {
+            *n_instances = ctx->sv.n_instances;
+        }
+        if (two_level) {
+            *two_level = (int32_t)ctx->sv.two_level;
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene) {
+            return fail(ctx, CRT_HIP_ESTATE, "bvh_copy before set_scene");
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (nodes) {
+            HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+        }
+        if (tris) {
+            HIP_CHECK(hipMemcpy(tris, ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+} // extern "C"

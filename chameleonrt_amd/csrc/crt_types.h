@@ -1,0 +1,92 @@
+// crt_types.h — device-resident scene layout shared by the host core and the HIP kernels.
+// (DESIGN.md "Data layout in HBM".) Everything is plain 32-bit words; records are sized and
+// aligned so a lane fetches them with dwordx4 loads.
+#pragma once
+#include <stdint.h>
+
+namespace crt {
+
+// One BVH2 node = 64 B = one quarter of a 256-B HBM burst; 4 x dwordx4 per lane.
+// Holds the boxes of BOTH children, so one fetch decides both.
+// Child reference c: c >= 0 -> inner node index (global, into Scene::nodes)
+//                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
+//                              BLAS: triangles [first, first+count) of Scene::tris
+//                              TLAS: instance `first` (count is 1)
+struct alignas(16) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// One triangle = 48 B; 3 x dwordx4. Embree-style precomputed edges:
+// e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1). geom = Embree geomID (position of the
+// Geometry in its Mesh), prim = Embree primID (triangle index in that Geometry).
+struct alignas(16) TriRec {
+    float v0[3], e1[3], e2[3];
+    uint32_t geom, prim, pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 96 B.
+struct alignas(16) InstanceRec {
+    float w2o[16];      // world_to_object, column-major like glm (m[c*4+r])
+    int32_t blas_root;  // node index of the mesh's BLAS root
+    uint32_t geom_base; // global geometry index of the mesh's geometry 0
+    uint32_t mat_base;  // offset into Scene::material_ids for this instance's geomID 0
+    uint32_t identity;  // 1 if the transform is bit-exactly the identity (ray not transformed)
+    uint32_t pad[4];
+};
+static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
+
+// Per-geometry shading data (ISPCGeometry, backends/embree/embree_utils.h:38-46): only the
+// index buffer and UVs are ever read by the hot path (normals are ignored, quirk Q7).
+struct GeomRec {
+    uint32_t index_base; // first uint3 of this geometry in Scene::indices (in triangles)
+    int32_t uv_base;     // first float2 in Scene::uvs, or -1 if the geometry has no UVs
+};
+
+// ISPCTexture2D (backends/embree/texture2d.ih:6-11); texels live in one byte blob.
+struct alignas(16) TexRec {
+    int32_t width, height, channels, pad;
+    uint64_t offset; // byte offset of texel (0,0) in Scene::texels
+    uint64_t pad1;
+};
+
+// ViewParams (backends/embree/embree_utils.h:137-140) + framebuffer geometry.
+struct ViewParams {
+    float pos[3], dir_du[3], dir_dv[3], dir_top_left[3];
+    uint32_t frame_id;
+    uint32_t fb_width, fb_height;
+    uint32_t spp;
+    uint32_t n_tiles_x;
+};
+
+// Device pointers of the whole scene, passed to kernels by value.
+struct SceneView {
+    const BvhNode *nodes;
+    const TriRec *tris;
+    const InstanceRec *instances;
+    const GeomRec *geoms;
+    const uint32_t *indices;      // 3 per triangle
+    const float *uvs;             // 2 per vertex
+    const uint32_t *material_ids; // per instance per geomID
+    const float *materials;       // 16 floats per material (14 used, MaterialParams order)
+    const TexRec *textures;
+    const uint8_t *texels;
+    const float *lights;          // 20 floats per QuadLight
+    uint32_t n_lights;
+    uint32_t n_instances;
+    int32_t root;                 // TLAS root (two-level) or the single BLAS root
+    uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly
+    uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
+};
+
+constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)
+constexpr int TILE_PIXELS = TILE * TILE;
+constexpr float RAY_EPS = 0.0001f;    // EPSILON, backends/embree/util.ih:8
+constexpr int MAX_PATH_DEPTH = 5;     // backends/embree/util.ih:10
+constexpr float RAY_TFAR = 1e20f;     // set_ray_hit, backends/embree/util.ih:118
+
+} // namespace crt

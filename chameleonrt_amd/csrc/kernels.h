@@ -1,0 +1,46 @@
+// kernels.h — host-callable launchers of the wavefront kernels (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "crt_types.h"
+#include "wavefront.h"
+
+namespace crt {
+
+struct LaunchCfg {
+    hipStream_t stream;
+    int n_cus;      // compute units of the device (grid sizing)
+    bool counters;  // instrumented traversal (CRT_HIP_FLAG_COUNTERS)
+};
+
+// K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.
+void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
+                   uint32_t n_paths, PathQueue q, float4 *radiance, PassCounters *pc);
+// K2: closest-hit traversal of the rays of bounce `bounce` (persistent waves, dynamic fetch).
+void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q, HitBuf hits,
+                          PassCounters *pc, int bounce);
+// K3: hit shading: material unpack, NEE set-up, BSDF sampling, Russian roulette, compaction.
+void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce);
+// K4: any-hit traversal of the NEE shadow rays (A: light samples, B: BSDF samples).
+void launch_trace_shadow_a(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
+                           float4 *radiance, PassCounters *pc, int bounce);
+void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueB sb, float4 *radiance,
+                           PassCounters *pc, int bounce);
+// K5: per-pixel sample sum, running mean over frames, sRGB8, ray statistics.
+void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
+                       uint32_t n_slots, const float4 *radiance, float4 *accum, uint32_t *tile_fb,
+                       uint32_t *img_rowmajor, uint32_t *ray_counts);
+// K8: un-permute `world` gathered compact tile buffers into the row-major image.
+void launch_assemble(const LaunchCfg &cfg, const uint32_t *gathered, uint32_t slab_pixels, int world,
+                     uint32_t fb_width, uint32_t fb_height, uint32_t *img_rowmajor);
+
+// Diagnostics (crt_hip_trace_rays / crt_hip_kat): same traversal code, explicit rays.
+void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, const float *org, const float *dir,
+                       const float *tmin, const float *tmax, bool closest, float *out_t, float *out_u,
+                       float *out_v, int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
+                       unsigned long long *counters /* nodes, tris */);
+int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,
+               float *out, int out_stride);
+
+} // namespace crt

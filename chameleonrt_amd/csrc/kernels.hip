@@ -1,0 +1,770 @@
+// kernels.hip — wavefront path-tracing kernels for MI355X (gfx950, wave64).
+//
+// The reference's per-pixel loop (backends/embree/render_embree.ispc:198-355, one ISPC lane
+// per pixel walking its whole path) is split into one kernel per stage so that a wave always
+// executes ONE stage for 64 different paths:
+//
+//   K1 raygen         pixel-sample -> primary ray                       (ispc:213-232)
+//   K2 trace_closest  BVH2 traversal + triangle test, closest hit       (rtcIntersectV, ispc:245)
+//   K3 shade          hit -> material, NEE set-up, BSDF sample, RR      (ispc:251-335)
+//   K4 trace_shadow   any-hit traversal of NEE rays                     (rtcOccludedV, ispc:144,170)
+//   K5 accumulate     sample sum, running mean, sRGB8                   (ispc:339-353, 358-370)
+//   K8 assemble       multi-GPU tile un-permute                         (new)
+//
+// Rays that survive a bounce are compacted into the next queue with __ballot + mbcnt and one
+// atomic per wave. Traversal kernels are persistent: a fixed grid of waves pulls 64-ray
+// packets from the queue with an atomic cursor, so long rays do not stall a whole block.
+// No MFMA anywhere: the path is divergent pointer chasing bounded by memory, not a contraction.
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/crt_kat.h"
+#include "kernels.h"
+#include "pt_device.h"
+#include "traverse.h"
+
+namespace crt {
+
+constexpr int TRACE_BLOCK = 256;   // 4 waves
+constexpr int MAX_TOP_NODES = 255; // top 8 levels of the BVH staged in LDS (16 KB)
+constexpr int SHADE_BLOCK = 256;
+
+// ---- wave-level helpers (wave64) -------------------------------------------------------------
+CRT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+CRT_DEV uint32_t lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Compacting append: every lane of the wave must call this (wave-uniform control flow). Lanes
+// with pred get consecutive slots; one atomic per wave. Returns the slot (undefined if !pred).
+CRT_DEV uint32_t wave_append(uint32_t *counter, bool pred)
+{
+    const uint64_t mask = __ballot(pred);
+    if (mask == 0) {
+        return 0;
+    }
+    const uint32_t rank = lanes_below(mask);
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) {
+        base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    }
+    base = __shfl(base, leader);
+    return base + rank;
+}
+// A wave grabs the next 64-element packet of a queue of n elements.
+CRT_DEV uint32_t wave_fetch(uint32_t *cursor)
+{
+    uint32_t base = 0;
+    if (lane_id() == 0) {
+        base = atomicAdd(cursor, 64u);
+    }
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// pixel slot -> pixel. Slots are tile-major over this GPU's tiles; inside a 64x64 tile they
+// follow a Morton curve so the 64 lanes of a wave cover a compact pixel block (coherent
+// primary rays) for any spp.
+CRT_DEV uint32_t compact_bits(uint32_t x)
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    return x;
+}
+CRT_DEV bool slot_to_pixel(const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot, uint32_t &x,
+                           uint32_t &y, uint32_t &ix, uint32_t &iy)
+{
+    const uint32_t tile = tile_ids[slot / TILE_PIXELS];
+    const uint32_t m = slot % TILE_PIXELS;
+    ix = compact_bits(m);
+    iy = compact_bits(m >> 1);
+    x = (tile % vp.n_tiles_x) * TILE + ix;
+    y = (tile / vp.n_tiles_x) * TILE + iy;
+    return x < vp.fb_width && y < vp.fb_height;
+}
+
+// ---- K1 raygen: render_embree.ispc:213-232 ------------------------------------------------------
+__global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uint32_t *tile_ids,
+                                                        uint32_t slot0, uint32_t n_paths, PathQueue q,
+                                                        float4 *radiance, PassCounters *pc)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
+        const uint32_t p = base + threadIdx.x;
+        bool valid = p < n_paths;
+        uint32_t x = 0, y = 0, ix, iy, s = 0;
+        if (valid) {
+            s = p % vp.spp;
+            valid = slot_to_pixel(vp, tile_ids, slot0 + p / vp.spp, x, y, ix, iy);
+            radiance[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const uint32_t slot = wave_append(&pc->n_queue[0], valid);
+        if (valid) {
+            // quirk Q1: the Embree backend keys the RNG with frame_id * spp + 1 + s
+            uint32_t rng = rng_seed(x + y * vp.fb_width, vp.frame_id * vp.spp + 1u + s);
+            const float px_x = (x + rng_nextf(rng)) / vp.fb_width;
+            const float px_y = (y + rng_nextf(rng)) / vp.fb_height;
+            const V3 dir = unit(v3(vp.dir_du[0] * px_x + vp.dir_dv[0] * px_y + vp.dir_top_left[0],
+                                   vp.dir_du[1] * px_x + vp.dir_dv[1] * px_y + vp.dir_top_left[1],
+                                   vp.dir_du[2] * px_x + vp.dir_dv[2] * px_y + vp.dir_top_left[2]));
+            q.o[0][slot] = vp.pos[0];
+            q.o[1][slot] = vp.pos[1];
+            q.o[2][slot] = vp.pos[2];
+            q.d[0][slot] = dir.x;
+            q.d[1][slot] = dir.y;
+            q.d[2][slot] = dir.z;
+            q.path[slot] = p;
+            q.rng[slot] = rng;
+            q.tp[0][slot] = 1.f;
+            q.tp[1][slot] = 1.f;
+            q.tp[2][slot] = 1.f;
+        }
+    }
+}
+
+// ---- LDS layout shared by the traversal kernels ----------------------------------------------
+struct TraceLds {
+    BvhNode top[MAX_TOP_NODES + 1];
+    int32_t stack[LDS_STACK][TRACE_BLOCK];
+};
+
+CRT_DEV const BvhNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
+{
+    // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step.
+    const uint32_t n = min(sc.n_top_nodes, (uint32_t)MAX_TOP_NODES);
+    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes + sc.root);
+    float4 *dst = reinterpret_cast<float4 *>(lds.top);
+    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x) {
+        dst[i] = src[i];
+    }
+    __syncthreads();
+    return n > 0 ? lds.top : nullptr;
+}
+
+// ---- K2 trace_closest ----------------------------------------------------------------------------
+template <bool TWO_LEVEL, bool COUNTERS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
+                                                               PassCounters *pc, int bounce)
+{
+    __shared__ TraceLds lds;
+    const BvhNode *top = stage_top_nodes(sc, lds);
+    TraversalStack st;
+    st.lds = &lds.stack[0][threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    const uint32_t n = pc->n_queue[bounce];
+    // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
+    const float tnear = bounce == 0 ? 0.f : RAY_EPS;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        const uint32_t base = wave_fetch(&pc->cur_closest[bounce]);
+        if (base >= n) {
+            break;
+        }
+        const uint32_t i = base + lane_id();
+        if (i < n) {
+            const V3 o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
+            const V3 d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
+            RayHit h;
+            traverse<false, TWO_LEVEL, COUNTERS>(sc, top, o, d, tnear, RAY_TFAR, h, st, n_nodes, n_tris);
+            hits.t[i] = h.t;
+            hits.u[i] = h.u;
+            hits.v[i] = h.v;
+            hits.tri[i] = h.tri;
+            hits.inst[i] = h.inst;
+        }
+    }
+    if (COUNTERS) {
+        atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
+        atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
+    }
+}
+
+// ---- K4 trace_shadow (A: light samples) ----------------------------------------------------------
+template <bool TWO_LEVEL, bool COUNTERS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
+                                                                float4 *radiance, PassCounters *pc, int bounce)
+{
+    __shared__ TraceLds lds;
+    const BvhNode *top = stage_top_nodes(sc, lds);
+    TraversalStack st;
+    st.lds = &lds.stack[0][threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    const uint32_t n = pc->n_shadow_a[bounce];
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        const uint32_t base = wave_fetch(&pc->cur_shadow_a[bounce]);
+        if (base >= n) {
+            break;
+        }
+        const uint32_t i = base + lane_id();
+        if (i < n) {
+            const V3 o = v3(sa.o[0][i], sa.o[1][i], sa.o[2][i]);
+            const V3 d = v3(sa.d[0][i], sa.d[1][i], sa.d[2][i]);
+            RayHit h;
+            traverse<true, TWO_LEVEL, COUNTERS>(sc, top, o, d, RAY_EPS, sa.tmax[i], h, st, n_nodes, n_tris);
+            const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148
+            const int32_t bslot = sa.bslot[i];
+            if (bslot >= 0) {
+                sb.vis_a[bslot] = visible ? 1 : 0;
+            } else if (visible) {
+                // illum = illum + path_throughput * nee, nee = cA (ispc:151, 301)
+                const uint32_t p = sa.path[i];
+                float4 L = radiance[p];
+                L.x = L.x + sa.c[0][i];
+                L.y = L.y + sa.c[1][i];
+                L.z = L.z + sa.c[2][i];
+                radiance[p] = L;
+            }
+        }
+    }
+    if (COUNTERS) {
+        atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
+        atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
+    }
+}
+
+// ---- K4 trace_shadow (B: BSDF samples that hit the light) ---------------------------------------
+template <bool TWO_LEVEL, bool COUNTERS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, ShadowQueueB sb, float4 *radiance,
+                                                                PassCounters *pc, int bounce)
+{
+    __shared__ TraceLds lds;
+    const BvhNode *top = stage_top_nodes(sc, lds);
+    TraversalStack st;
+    st.lds = &lds.stack[0][threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    const uint32_t n = pc->n_shadow_b[bounce];
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        const uint32_t base = wave_fetch(&pc->cur_shadow_b[bounce]);
+        if (base >= n) {
+            break;
+        }
+        const uint32_t i = base + lane_id();
+        if (i < n) {
+            const V3 o = v3(sb.o[0][i], sb.o[1][i], sb.o[2][i]);
+            const V3 d = v3(sb.d[0][i], sb.d[1][i], sb.d[2][i]);
+            RayHit h;
+            traverse<true, TWO_LEVEL, COUNTERS>(sc, top, o, d, RAY_EPS, sb.tmax[i], h, st, n_nodes, n_tris);
+            // sample_direct_light's return value (ispc:117,151,175): illum = 0; [illum = cA;] [illum += cB]
+            V3 nee = v3(0.f);
+            if (sb.vis_a[i]) {
+                nee = v3(sb.ca[0][i], sb.ca[1][i], sb.ca[2][i]);
+            }
+            if (h.tri < 0) {
+                nee = nee + v3(sb.cb[0][i], sb.cb[1][i], sb.cb[2][i]);
+            }
+            const V3 add = v3(sb.tp[0][i], sb.tp[1][i], sb.tp[2][i]) * nee;
+            const uint32_t p = sb.path[i];
+            float4 L = radiance[p];
+            L.x = L.x + add.x;
+            L.y = L.y + add.y;
+            L.z = L.z + add.z;
+            radiance[p] = L;
+        }
+    }
+    if (COUNTERS) {
+        atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
+        atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
+    }
+}
+
+// ---- K3 shade: render_embree.ispc:251-335 + sample_direct_light :105-181 -----------------------
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
+                                                       ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
+                                                       PassCounters *pc, int bounce)
+{
+    const uint32_t n = pc->n_queue[bounce];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        bool is_hit = false, alive = false, has_b = false;
+        V3 hit_p = v3(0.f), light_dir = v3(0.f), w_i_b = v3(0.f), w_i = v3(0.f);
+        V3 c_a = v3(0.f), c_b = v3(0.f), tp = v3(0.f), tp_in = v3(0.f);
+        float light_dist = 0.f, light_dist_b = 0.f;
+        uint32_t path = 0, rng = 0;
+        if (valid) {
+            const V3 o = v3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
+            const V3 d = v3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
+            path = qin.path[i];
+            rng = qin.rng[i];
+            tp_in = v3(qin.tp[0][i], qin.tp[1][i], qin.tp[2][i]);
+            tp = tp_in;
+            const int32_t tri = hits.tri[i];
+            float4 L = radiance[path];
+            L.w += 1.f; // the closest-hit ray (REPORT_RAY_STATS, ispc:246-248)
+            if (tri < 0) {
+                // ispc:258-262
+                const V3 m = tp * miss_color(d);
+                L.x = L.x + m.x;
+                L.y = L.y + m.y;
+                L.z = L.z + m.z;
+            } else {
+                is_hit = true;
+                const float t = hits.t[i], bu = hits.u[i], bv = hits.v[i];
+                const InstanceRec &in = sc.instances[hits.inst[i]];
+                const float4 *tr = reinterpret_cast<const float4 *>(sc.tris + tri);
+                const float4 ta = tr[0], tb = tr[1], tc = tr[2];
+                const uint32_t geom = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+                const V3 w_o = -d;
+                hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
+                // hit.Ng = cross(e2, e1), instance-local, unnormalised
+                V3 normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
+                V2 uv = v2(0.f, 0.f);
+                const GeomRec g = sc.geoms[in.geom_base + geom];
+                if (g.uv_base >= 0) { // ispc:277-285
+                    const uint32_t *ix = sc.indices + 3 * ((size_t)g.index_base + prim);
+                    const float *uvb = sc.uvs + 2 * (size_t)g.uv_base;
+                    const V2 uva = v2(uvb[2 * ix[0]], uvb[2 * ix[0] + 1]);
+                    const V2 uvb_ = v2(uvb[2 * ix[1]], uvb[2 * ix[1] + 1]);
+                    const V2 uvc = v2(uvb[2 * ix[2]], uvb[2 * ix[2] + 1]);
+                    uv = (1.f - bu - bv) * uva + bu * uvb_ + bv * uvc;
+                }
+                { // normal = normalize(transpose(world_to_object) * normal), ispc:288-290
+                    const float *m = in.w2o;
+                    normal = unit(v3(m[0] * normal.x + m[1] * normal.y + m[2] * normal.z,
+                                     m[4] * normal.x + m[5] * normal.y + m[6] * normal.z,
+                                     m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
+                }
+                Surface mat;
+                unpack_material(sc, mat, sc.materials + 16 * (size_t)sc.material_ids[in.mat_base + geom], uv);
+                if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
+                    normal = -normal;
+                }
+                V3 v_x, v_y;
+                ortho_basis(v_x, v_y, normal);
+
+                // -- sample_direct_light, ispc:105-181 --
+                uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
+                light_id = min(light_id, sc.n_lights - 1u);
+                const QuadLight light = load_light(sc.lights + 20 * (size_t)light_id);
+                {
+                    V2 ls;
+                    ls.x = rng_nextf(rng);
+                    ls.y = rng_nextf(rng);
+                    const V3 light_pos = light_sample_position(light, ls);
+                    light_dir = light_pos - hit_p;
+                    light_dist = len3(light_dir);
+                    light_dir = unit(light_dir);
+                    const float l_pdf = light_pdf(light, light_pos, light_dir);
+                    const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
+                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
+                        const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
+                        const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
+                        c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
+                    }
+                }
+                {
+                    float b_pdf;
+                    const V3 bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i_b, b_pdf);
+                    V3 light_pos;
+                    if (!is_black(bsdf) && b_pdf >= RAY_EPS &&
+                        light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
+                        const float l_pdf = light_pdf(light, light_pos, w_i_b);
+                        if (l_pdf >= RAY_EPS) {
+                            const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
+                            c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
+                            has_b = true;
+                        }
+                    }
+                }
+                L.w += has_b ? 2.f : 1.f; // the occlusion rays (ispc:145-147, 171-173)
+
+                // -- continue the path, ispc:313-335 --
+                float pdf;
+                const V3 bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
+                alive = !(pdf == 0.f || is_black(bsdf));
+                if (alive) {
+                    tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
+                    const int next_bounce = bounce + 1;
+                    if (next_bounce >= MAX_PATH_DEPTH) {
+                        alive = false; // `while (bounce < MAX_PATH_DEPTH)`: roulette outcome is unobservable
+                    } else if (next_bounce > 3) {
+                        const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
+                        if (rng_nextf(rng) < qr) {
+                            alive = false;
+                        } else {
+                            tp = tp / (1.f - qr);
+                        }
+                    }
+                }
+            }
+            radiance[path] = L;
+        }
+        // compaction: B slots first (A entries point at them)
+        const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce], has_b);
+        const uint32_t slot_a = wave_append(&pc->n_shadow_a[bounce], is_hit);
+        const uint32_t slot_n = wave_append(&pc->n_queue[bounce + 1], alive);
+        if (has_b) {
+            sb.o[0][slot_b] = hit_p.x;
+            sb.o[1][slot_b] = hit_p.y;
+            sb.o[2][slot_b] = hit_p.z;
+            sb.d[0][slot_b] = w_i_b.x;
+            sb.d[1][slot_b] = w_i_b.y;
+            sb.d[2][slot_b] = w_i_b.z;
+            sb.tmax[slot_b] = light_dist_b;
+            sb.ca[0][slot_b] = c_a.x;
+            sb.ca[1][slot_b] = c_a.y;
+            sb.ca[2][slot_b] = c_a.z;
+            sb.cb[0][slot_b] = c_b.x;
+            sb.cb[1][slot_b] = c_b.y;
+            sb.cb[2][slot_b] = c_b.z;
+            sb.tp[0][slot_b] = tp_in.x;
+            sb.tp[1][slot_b] = tp_in.y;
+            sb.tp[2][slot_b] = tp_in.z;
+            sb.path[slot_b] = path;
+            sb.vis_a[slot_b] = 0;
+        }
+        if (is_hit) {
+            const V3 c = tp_in * c_a;
+            sa.o[0][slot_a] = hit_p.x;
+            sa.o[1][slot_a] = hit_p.y;
+            sa.o[2][slot_a] = hit_p.z;
+            sa.d[0][slot_a] = light_dir.x;
+            sa.d[1][slot_a] = light_dir.y;
+            sa.d[2][slot_a] = light_dir.z;
+            sa.tmax[slot_a] = light_dist;
+            sa.c[0][slot_a] = c.x;
+            sa.c[1][slot_a] = c.y;
+            sa.c[2][slot_a] = c.z;
+            sa.path[slot_a] = path;
+            sa.bslot[slot_a] = has_b ? (int32_t)slot_b : -1;
+        }
+        if (alive) {
+            qout.o[0][slot_n] = hit_p.x;
+            qout.o[1][slot_n] = hit_p.y;
+            qout.o[2][slot_n] = hit_p.z;
+            qout.d[0][slot_n] = w_i.x;
+            qout.d[1][slot_n] = w_i.y;
+            qout.d[2][slot_n] = w_i.z;
+            qout.path[slot_n] = path;
+            qout.rng[slot_n] = rng;
+            qout.tp[0][slot_n] = tp.x;
+            qout.tp[1][slot_n] = tp.y;
+            qout.tp[2][slot_n] = tp.z;
+        }
+    }
+}
+
+// ---- K5 accumulate: render_embree.ispc:339-353 + tile_to_uint8 :358-370 ------------------------
+__global__ __launch_bounds__(SHADE_BLOCK) void k_accumulate(ViewParams vp, const uint32_t *tile_ids,
+                                                            uint32_t slot0, uint32_t n_slots, const float4 *radiance,
+                                                            float4 *accum, uint32_t *tile_fb, uint32_t *img_rowmajor,
+                                                            uint32_t *ray_counts)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) {
+        return;
+    }
+    const uint32_t slot = slot0 + k;
+    uint32_t x, y, ix, iy;
+    if (!slot_to_pixel(vp, tile_ids, slot, x, y, ix, iy)) {
+        return;
+    }
+    V3 illum = v3(0.f);
+    float rays = 0.f;
+    for (uint32_t s = 0; s < vp.spp; ++s) {
+        const float4 L = radiance[(size_t)k * vp.spp + s];
+        illum = illum + v3(L.x, L.y, L.z);
+        rays += L.w;
+    }
+    illum = illum / (float)vp.spp;
+    const float4 a = accum[slot];
+    illum = (illum + (float)vp.frame_id * v3(a.x, a.y, a.z)) / (float)(vp.frame_id + 1u);
+    accum[slot] = make_float4(illum.x, illum.y, illum.z, 0.f);
+    const uint32_t rgba = srgb8(illum.x) | (srgb8(illum.y) << 8) | (srgb8(illum.z) << 16) | 0xff000000u;
+    tile_fb[(size_t)(slot / TILE_PIXELS) * TILE_PIXELS + iy * TILE + ix] = rgba;
+    if (img_rowmajor) {
+        img_rowmajor[(size_t)y * vp.fb_width + x] = rgba;
+    }
+    ray_counts[slot] = (uint32_t)rays;
+}
+
+// ---- K8 assemble: gathered[rank][local_tile][64*64] -> row-major image --------------------------
+__global__ void k_assemble(const uint32_t *gathered, uint32_t slab_pixels, int world, uint32_t fb_width,
+                           uint32_t fb_height, uint32_t *img)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= fb_width || y >= fb_height) {
+        return;
+    }
+    const uint32_t ntx = (fb_width + TILE - 1) / TILE;
+    const uint32_t tile = (y / TILE) * ntx + x / TILE;
+    const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
+    img[(size_t)y * fb_width + x] =
+        gathered[(size_t)rank * slab_pixels + (size_t)local * TILE_PIXELS + (y % TILE) * TILE + (x % TILE)];
+}
+
+// ---- diagnostics: explicit rays through the production traversal -------------------------------
+template <bool ANY_HIT, bool TWO_LEVEL>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32_t n, const float *org,
+                                                            const float *dir, const float *tmin, const float *tmax,
+                                                            float *out_t, float *out_u, float *out_v,
+                                                            int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
+                                                            unsigned long long *counters)
+{
+    __shared__ TraceLds lds;
+    const BvhNode *top = stage_top_nodes(sc, lds);
+    TraversalStack st;
+    st.lds = &lds.stack[0][threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        RayHit h;
+        traverse<ANY_HIT, TWO_LEVEL, true>(sc, top, o, d, tmin[i], tmax[i], h, st, n_nodes, n_tris);
+        if (ANY_HIT) {
+            out_t[i] = h.tri < 0 ? 1.f : 0.f;
+        } else {
+            out_t[i] = h.t;
+            out_u[i] = h.u;
+            out_v[i] = h.v;
+            out_inst[i] = h.tri < 0 ? -1 : h.inst;
+            out_geom[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].geom;
+            out_prim[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].prim;
+        }
+    }
+    atomicAdd(&counters[0], (unsigned long long)n_nodes);
+    atomicAdd(&counters[1], (unsigned long long)n_tris);
+}
+
+// ---- KATs of the device shading functions (record layouts: include/crt_kat.h) ------------------
+__global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_stride, float *out, int out_stride)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const float *a = in + (size_t)i * in_stride;
+    float *o = out + (size_t)i * out_stride;
+    auto st3 = [](float *p, V3 v) {
+        p[0] = v.x;
+        p[1] = v.y;
+        p[2] = v.z;
+    };
+    auto load_surface = [](const float *p) {
+        Surface m;
+        m.base_color = v3(p[0], p[1], p[2]);
+        m.metallic = p[3];
+        m.specular = p[4];
+        m.roughness = p[5];
+        m.specular_tint = p[6];
+        m.anisotropy = p[7];
+        m.sheen = p[8];
+        m.sheen_tint = p[9];
+        m.clearcoat = p[10];
+        m.clearcoat_gloss = p[11];
+        m.ior = p[12];
+        m.specular_transmission = p[13];
+        return m;
+    };
+    switch (fn) {
+    case CRT_KAT_DISNEY_EVAL: {
+        const Surface m = load_surface(a);
+        const V3 nn = ld3(a + 14), w_o = ld3(a + 17), w_i = ld3(a + 20), v_x = ld3(a + 23), v_y = ld3(a + 26);
+        st3(o, disney_eval(m, nn, w_o, w_i, v_x, v_y));
+        o[3] = disney_pdf(m, nn, w_o, w_i, v_x, v_y);
+        break;
+    }
+    case CRT_KAT_DISNEY_SAMPLE: {
+        const Surface m = load_surface(a);
+        const V3 nn = ld3(a + 14), w_o = ld3(a + 17), v_x = ld3(a + 20), v_y = ld3(a + 23);
+        uint32_t rng = __float_as_uint(a[26]);
+        V3 w_i = v3(0.f);
+        float pdf = 0.f;
+        const V3 f = disney_sample(m, nn, w_o, v_x, v_y, rng, w_i, pdf);
+        st3(o, f);
+        st3(o + 3, w_i);
+        o[6] = pdf;
+        o[7] = __uint_as_float(rng);
+        break;
+    }
+    case CRT_KAT_LIGHT: {
+        const QuadLight l = load_light(a);
+        const V3 orig = ld3(a + 20), dir = ld3(a + 23);
+        const V3 p = light_sample_position(l, v2(a[26], a[27]));
+        st3(o, p);
+        o[3] = light_pdf(l, p, dir);
+        float t = 0.f;
+        V3 lp = v3(0.f);
+        const bool hit = light_intersect(l, orig, dir, t, lp);
+        o[4] = hit ? 1.f : 0.f;
+        o[5] = hit ? t : 0.f;
+        st3(o + 6, hit ? lp : v3(0.f));
+        break;
+    }
+    case CRT_KAT_TEXTURE: {
+        const TexRec &t = sc.textures[__float_as_uint(a[0])];
+        const V4 c = sample_rgba(sc, t, v2(a[1], a[2]));
+        o[0] = c.x;
+        o[1] = c.y;
+        o[2] = c.z;
+        o[3] = c.w;
+        const int ch = (int)__float_as_uint(a[3]);
+        o[4] = ch < t.channels ? sample_channel(sc, t, v2(a[1], a[2]), ch) : 0.f;
+        break;
+    }
+    case CRT_KAT_MISS:
+        st3(o, miss_color(ld3(a)));
+        break;
+    case CRT_KAT_ORTHO_BASIS: {
+        V3 v_x, v_y;
+        ortho_basis(v_x, v_y, ld3(a));
+        st3(o, v_x);
+        st3(o + 3, v_y);
+        break;
+    }
+    case CRT_KAT_SRGB8:
+        o[0] = (float)srgb8(a[0]);
+        break;
+    case CRT_KAT_RNG: {
+        uint32_t rng = rng_seed(__float_as_uint(a[0]), __float_as_uint(a[1]));
+        o[0] = __uint_as_float(rng);
+        for (int k = 0; k < 8; ++k) {
+            uint32_t copy = rng;
+            const float f = rng_nextf(copy);
+            const uint32_t r = rng_next(rng);
+            o[1 + 2 * k] = __uint_as_float(r);
+            o[2 + 2 * k] = f;
+        }
+        break;
+    }
+    case CRT_KAT_UNPACK_MATERIAL: {
+        Surface m;
+        unpack_material(sc, m, sc.materials + 16 * (size_t)__float_as_uint(a[0]), v2(a[1], a[2]));
+        st3(o, m.base_color);
+        o[3] = m.metallic;
+        o[4] = m.specular;
+        o[5] = m.roughness;
+        o[6] = m.specular_tint;
+        o[7] = m.anisotropy;
+        o[8] = m.sheen;
+        o[9] = m.sheen_tint;
+        o[10] = m.clearcoat;
+        o[11] = m.clearcoat_gloss;
+        o[12] = m.ior;
+        o[13] = m.specular_transmission;
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
+static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)
+{
+    const uint32_t want = (n + block - 1) / block;
+    const uint32_t cap = (uint32_t)cfg.n_cus * 8u;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
+                   uint32_t n_paths, PathQueue q, float4 *radiance, PassCounters *pc)
+{
+    k_raygen<<<capped_grid(cfg, n_paths, SHADE_BLOCK), SHADE_BLOCK, 0, cfg.stream>>>(vp, tile_ids, slot0, n_paths, q,
+                                                                                      radiance, pc);
+}
+
+template <typename... Args> static void launch4(bool two_level, bool counters, void (*k00)(Args...),
+                                                void (*k01)(Args...), void (*k10)(Args...), void (*k11)(Args...),
+                                                int grid, hipStream_t stream, Args... args)
+{
+    auto k = two_level ? (counters ? k11 : k10) : (counters ? k01 : k00);
+    k<<<grid, TRACE_BLOCK, 0, stream>>>(args...);
+}
+
+void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q, HitBuf hits, PassCounters *pc,
+                          int bounce)
+{
+    launch4(sc.two_level != 0, cfg.counters, k_trace_closest<false, false>, k_trace_closest<false, true>,
+            k_trace_closest<true, false>, k_trace_closest<true, true>, persistent_grid(cfg, 4), cfg.stream, sc, q,
+            hits, pc, bounce);
+}
+
+void launch_trace_shadow_a(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
+                           float4 *radiance, PassCounters *pc, int bounce)
+{
+    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_a<false, false>, k_trace_shadow_a<false, true>,
+            k_trace_shadow_a<true, false>, k_trace_shadow_a<true, true>, persistent_grid(cfg, 4), cfg.stream, sc, sa,
+            sb, radiance, pc, bounce);
+}
+
+void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueB sb, float4 *radiance,
+                           PassCounters *pc, int bounce)
+{
+    // B rays are rare (BSDF sample must hit the light quad): a quarter-size grid is plenty
+    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_b<false, false>, k_trace_shadow_b<false, true>,
+            k_trace_shadow_b<true, false>, k_trace_shadow_b<true, true>, persistent_grid(cfg, 1), cfg.stream, sc, sb,
+            radiance, pc, bounce);
+}
+
+void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce)
+{
+    k_shade<<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc,
+                                                                     bounce);
+}
+
+void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
+                       uint32_t n_slots, const float4 *radiance, float4 *accum, uint32_t *tile_fb,
+                       uint32_t *img_rowmajor, uint32_t *ray_counts)
+{
+    const int grid = (int)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
+    k_accumulate<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(vp, tile_ids, slot0, n_slots, radiance, accum, tile_fb,
+                                                       img_rowmajor, ray_counts);
+}
+
+void launch_assemble(const LaunchCfg &cfg, const uint32_t *gathered, uint32_t slab_pixels, int world,
+                     uint32_t fb_width, uint32_t fb_height, uint32_t *img_rowmajor)
+{
+    const dim3 block(64, 4);
+    const dim3 grid((fb_width + 63) / 64, (fb_height + 3) / 4);
+    k_assemble<<<grid, block, 0, cfg.stream>>>(gathered, slab_pixels, world, fb_width, fb_height, img_rowmajor);
+}
+
+void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, const float *org, const float *dir,
+                       const float *tmin, const float *tmax, bool closest, float *out_t, float *out_u, float *out_v,
+                       int32_t *out_inst, int32_t *out_geom, int32_t *out_prim, unsigned long long *counters)
+{
+    const int grid = capped_grid(cfg, n, TRACE_BLOCK);
+    if (closest) {
+        if (sc.two_level) {
+            k_trace_diag<false, true><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
+                                                                            out_v, out_inst, out_geom, out_prim,
+                                                                            counters);
+        } else {
+            k_trace_diag<false, false><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
+                                                                             out_v, out_inst, out_geom, out_prim,
+                                                                             counters);
+        }
+    } else {
+        if (sc.two_level) {
+            k_trace_diag<true, true><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
+                                                                           out_v, out_inst, out_geom, out_prim,
+                                                                           counters);
+        } else {
+            k_trace_diag<true, false><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
+                                                                            out_v, out_inst, out_geom, out_prim,
+                                                                            counters);
+        }
+    }
+}
+
+int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,
+               float *out, int out_stride)
+{
+    if (fn < CRT_KAT_DISNEY_EVAL || fn > CRT_KAT_UNPACK_MATERIAL) {
+        return -1;
+    }
+    k_kat<<<(n + 63) / 64, 64, 0, cfg.stream>>>(sc, fn, n, in, in_stride, out, out_stride);
+    return 0;
+}
+
+} // namespace crt

@@ -1,0 +1,72 @@
+// wavefront.h — SoA ray/hit queues and per-pass counters of the wavefront path tracer.
+//
+// One "pass" renders all samples of a contiguous range of this GPU's pixel slots. Its state
+// lives in HBM as struct-of-arrays so that lane i of a wave touches element i of each field
+// array (coalesced 256-B wave accesses):
+//
+//   PathQueue (x2, ping-pong)  closest-hit rays of one bounce: origin, direction, path id,
+//                              RNG state, throughput                       11 dwords / ray
+//   HitBuf                     t, u, v, triangle record index, instance     5 dwords / ray
+//   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray
+//   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare) 18 dwords / ray
+//   radiance                   float4 per path: rgb = radiance so far, w = rays traced
+//
+// Queue sizes are produced on the device (wave ballot + one atomic per wave) and never read
+// by the host between bounces: every kernel takes its element count from PassCounters.
+#pragma once
+#include "crt_types.h"
+
+namespace crt {
+
+struct PathQueue {
+    float *o[3];
+    float *d[3];
+    uint32_t *path; // path index inside the pass (= (pixel slot - first slot) * spp + s)
+    uint32_t *rng;  // LCG state (lcg_rng.ih)
+    float *tp[3];   // path_throughput (render_embree.ispc:241)
+};
+
+struct HitBuf {
+    float *t, *u, *v;
+    int32_t *tri; // index into SceneView::tris, -1 on a miss
+    int32_t *inst;
+};
+
+// First NEE shadow ray of a hit (render_embree.ispc:131-153). c = throughput * contribution,
+// added to the path's radiance if the ray is unoccluded and the hit has no B ray. If the hit
+// also spawned a B ray, the visibility is handed to that entry instead (bslot).
+struct ShadowQueueA {
+    float *o[3];
+    float *d[3];
+    float *tmax;
+    float *c[3];
+    uint32_t *path;
+    int32_t *bslot; // index into ShadowQueueB or -1
+};
+
+// Second NEE shadow ray (render_embree.ispc:156-179): keeps both contributions and the
+// throughput unmultiplied so that illum += tp * (cA*visA + cB*visB) is evaluated in the
+// reference's order.
+struct ShadowQueueB {
+    float *o[3];
+    float *d[3];
+    float *tmax;
+    float *ca[3];
+    float *cb[3];
+    float *tp[3];
+    uint32_t *path;
+    int32_t *vis_a; // written by the A kernel
+};
+
+struct PassCounters {
+    uint32_t n_queue[MAX_PATH_DEPTH + 1]; // closest-hit rays entering bounce b
+    uint32_t n_shadow_a[MAX_PATH_DEPTH];
+    uint32_t n_shadow_b[MAX_PATH_DEPTH];
+    uint32_t cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
+    uint32_t cur_shadow_a[MAX_PATH_DEPTH];
+    uint32_t cur_shadow_b[MAX_PATH_DEPTH];
+    uint32_t pad;
+    unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow; // CRT_HIP_FLAG_COUNTERS
+};
+
+} // namespace crt

@@ -1,0 +1,127 @@
+"""RenderHIP -- host-side mirror of the reference's ``RenderBackend`` for the HIP core.
+
+Same names, argument meaning and error behaviour as the reference interface
+(util/render_backend.h:12-32; the Embree implementation backends/embree/render_embree.h:11-44):
+
+    r = RenderHIP()              # make_renderer(display)
+    r.initialize(w, h)           # RenderBackend::initialize
+    r.set_scene(scene)           # RenderBackend::set_scene (copies what it needs)
+    stats = r.render(pos, dir, up, fovy, camera_changed, readback_framebuffer)
+    r.img                        # W*H RGBA8, row 0 = top (RenderBackend::img)
+
+Errors are exceptions (the reference throws std::runtime_error). Everything is executed by
+libcrt_hip_core.so on the GPU; this class holds no rendering logic.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import core
+from .scene import PackedScene, Scene
+
+
+class RenderHIP:
+    def __init__(self, device: int = 0, flags: int = 0, rank: int = 0, world: int = 1, stream=None):
+        self._lib = core.load()
+        self._ctx = self._lib.crt_hip_create(device, flags)
+        if not self._ctx:
+            raise core.CoreError("crt_hip_create failed: " + self._lib.crt_hip_last_error(None).decode())
+        self.samples_per_pixel = 1
+        self.width = self.height = 0
+        self.rank, self.world = rank, world
+        if world > 1:
+            core.check(self._ctx, self._lib.crt_hip_set_partition(self._ctx, rank, world), "set_partition")
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.crt_hip_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def name(self) -> str:
+        return self._lib.crt_hip_name(self._ctx).decode()
+
+    def set_stream(self, stream_handle: int):
+        core.check(self._ctx, self._lib.crt_hip_set_stream(self._ctx, C.c_void_p(stream_handle)), "set_stream")
+
+    def initialize(self, fb_width: int, fb_height: int):
+        core.check(self._ctx, self._lib.crt_hip_initialize(self._ctx, fb_width, fb_height), "initialize")
+        self.width, self.height = fb_width, fb_height
+
+    def set_scene(self, scene: Scene):
+        packed = PackedScene(scene)
+        core.check(self._ctx, self._lib.crt_hip_set_scene(self._ctx, packed.ptr()), "set_scene")
+        self.samples_per_pixel = scene.samples_per_pixel
+
+    def render(self, pos, dir, up, fovy, camera_changed, readback_framebuffer=False) -> core.RenderStats:
+        a = [np.ascontiguousarray(v, np.float32) for v in (pos, dir, up)]
+        st = core.RenderStats()
+        core.check(self._ctx, self._lib.crt_hip_render(self._ctx, core.fptr(a[0]), core.fptr(a[1]), core.fptr(a[2]),
+                                                       float(fovy), int(bool(camera_changed)),
+                                                       int(bool(readback_framebuffer)), C.byref(st)), "render")
+        return st
+
+    @property
+    def img(self) -> np.ndarray:
+        p = self._lib.crt_hip_framebuffer(self._ctx)
+        return np.ctypeslib.as_array(p, shape=(self.height, self.width))
+
+    def frame_id(self) -> int:
+        return self._lib.crt_hip_frame_id(self._ctx)
+
+    # ---- parity / diagnostic reads ------------------------------------------------------
+    def accum(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        core.check(self._ctx, self._lib.crt_hip_read_accum(self._ctx, core.fptr(out)), "read_accum")
+        return out
+
+    def ray_counts(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width), np.uint32)
+        core.check(self._ctx, self._lib.crt_hip_read_ray_counts(
+            self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32))), "read_ray_counts")
+        return out
+
+    def trace(self, org, dirs, tmin, tmax, closest=True):
+        org = np.ascontiguousarray(org, np.float32)
+        dirs = np.ascontiguousarray(dirs, np.float32)
+        n = org.shape[0]
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        inst, geom, prim = (np.zeros(n, np.int32) for _ in range(3))
+        st = core.RenderStats()
+        ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))
+        core.check(self._ctx, self._lib.crt_hip_trace_rays(
+            self._ctx, n, core.fptr(org), core.fptr(dirs), core.fptr(tmin), core.fptr(tmax), int(closest),
+            core.fptr(t), core.fptr(u), core.fptr(v), ip(inst), ip(geom), ip(prim), C.byref(st)), "trace_rays")
+        return dict(t=t, u=u, v=v, inst=inst, geom=geom, prim=prim, stats=st)
+
+    def kat(self, fn: int, rec_in, n_out: int) -> np.ndarray:
+        rec_in = np.ascontiguousarray(rec_in, np.float32)
+        out = np.zeros((rec_in.shape[0], n_out), np.float32)
+        core.check(self._ctx, self._lib.crt_hip_kat(self._ctx, fn, rec_in.shape[0], core.fptr(rec_in),
+                                                    rec_in.shape[1], core.fptr(out), n_out), "kat")
+        return out
+
+    def bvh(self):
+        nn, nt, ni, tl = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        core.check(self._ctx, self._lib.crt_hip_bvh_info(self._ctx, C.byref(nn), C.byref(nt), C.byref(ni),
+                                                         C.byref(tl)), "bvh_info")
+        nodes = np.zeros((nn.value, 16), np.float32)
+        tris = np.zeros((nt.value, 12), np.float32)
+        core.check(self._ctx, self._lib.crt_hip_bvh_copy(self._ctx, nodes.ctypes.data_as(C.c_void_p),
+                                                         tris.ctypes.data_as(C.c_void_p)), "bvh_copy")
+        return dict(nodes=nodes, tris=tris, n_instances=ni.value, two_level=bool(tl.value))
+
+    # ---- multi-GPU tile assembly ---------------------------------------------------------
+    def tile_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        core.check(self._ctx, self._lib.crt_hip_tile_buffer(self._ctx, C.byref(p), C.byref(n)), "tile_buffer")
+        return p.value, n.value
+
+    def assemble_tiles(self, gathered_device_ptr: int, world: int, readback: bool = True):
+        core.check(self._ctx, self._lib.crt_hip_assemble_tiles(self._ctx, C.c_void_p(gathered_device_ptr), world,
+                                                               int(readback)), "assemble_tiles")

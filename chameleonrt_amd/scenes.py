@@ -1,0 +1,544 @@
+"""Deterministic synthetic stand-ins for the benchmark scenes named in BASELINE.json.
+
+The real assets (Cornell Box, Sponza, Rungholt, San Miguel; McGuire archive, reference
+README.md:9-10) are not in this image and there is no network, so every scene is generated
+from a seed. All of them mimic what the reference's OBJ importer produces
+(util/scene.cpp:94-228): ONE Mesh with one Geometry per shape, one ParameterizedMesh, one
+identity Instance, and the auto-generated quad light of util/scene.cpp:218-227. The
+``instanced_grove`` scene additionally exercises the single-level instancing the glTF path
+produces (util/mesh.h:40-47).
+
+    S1  cornell(...)            34 tris               BASELINE config C1
+    S2  sponza_like(...)        ~262 k tris, 16 tex   C2
+    S3  rungholt_like(...)      ~6.7 M tris           C3
+    S4  sanmiguel_like(...)     ~10 M tris, 64 tex    C4, C5
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import numpy as np
+
+from .scene import (SRGB, LINEAR, Camera, Geometry, Image, Instance, Mesh, ParameterizedMesh,
+                    Scene, disney_material, obj_default_light, textured_param)
+
+F = np.float32
+
+
+# ---------------------------------------------------------------- mesh building blocks
+
+
+def _grid(nu: int, nv: int, fn, uv_lo=(0.0, 0.0), uv_hi=(1.0, 1.0), flip=False) -> Geometry:
+    """Parametric (nu x nv)-quad surface; fn(u, v) -> (x, y, z) arrays for u, v in [0, 1]."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="xy")
+    x, y, z = fn(uu, vv)
+    verts = np.stack([np.broadcast_to(x, uu.shape), np.broadcast_to(y, uu.shape),
+                      np.broadcast_to(z, uu.shape)], axis=-1).reshape(-1, 3).astype(F)
+    uvs = np.stack([uv_lo[0] + uu * (uv_hi[0] - uv_lo[0]), uv_lo[1] + vv * (uv_hi[1] - uv_lo[1])],
+                   axis=-1).reshape(-1, 2).astype(F)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="xy")
+    a = (j * (nu + 1) + i).reshape(-1)
+    b, c, d = a + 1, a + nu + 2, a + nu + 1
+    if flip:
+        tris = np.concatenate([np.stack([a, c, b], -1), np.stack([a, d, c], -1)])
+    else:
+        tris = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)])
+    return Geometry(verts, tris.astype(np.uint32), uvs)
+
+
+def _quad(p0, p1, p2, p3, uv_scale=1.0) -> Geometry:
+    verts = np.array([p0, p1, p2, p3], dtype=F)
+    uvs = np.array([[0, 0], [uv_scale, 0], [uv_scale, uv_scale], [0, uv_scale]], dtype=F)
+    return Geometry(verts, np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32), uvs)
+
+
+def _box(center, half, rot_y=0.0, uv_scale=1.0) -> Geometry:
+    """12-triangle box, 24 vertices (own UVs per face), rotated about +y."""
+    cx, cy, cz = center
+    hx, hy, hz = half
+    c, s = math.cos(rot_y), math.sin(rot_y)
+    faces = [((1, 0, 0), (0, 1, 0), (0, 0, 1)), ((-1, 0, 0), (0, 0, 1), (0, 1, 0)),
+             ((0, 1, 0), (0, 0, 1), (1, 0, 0)), ((0, -1, 0), (1, 0, 0), (0, 0, 1)),
+             ((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (0, 1, 0), (1, 0, 0))]
+    verts, tris, uvs = [], [], []
+    for n, a, b in faces:
+        n, a, b = np.array(n, float), np.array(a, float), np.array(b, float)
+        base = len(verts)
+        for (sa, sb) in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+            p = (n + sa * a + sb * b) * np.array([hx, hy, hz])
+            x, z = p[0] * c + p[2] * s, -p[0] * s + p[2] * c
+            verts.append([cx + x, cy + p[1], cz + z])
+            uvs.append([(sa + 1) * 0.5 * uv_scale, (sb + 1) * 0.5 * uv_scale])
+        tris += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+    return Geometry(np.array(verts, dtype=F), np.array(tris, dtype=np.uint32), np.array(uvs, dtype=F))
+
+
+def _merge(geoms: List[Geometry]) -> Geometry:
+    verts, tris, uvs, off = [], [], [], 0
+    for g in geoms:
+        verts.append(g.vertices)
+        tris.append(g.indices.astype(np.int64) + off)
+        uvs.append(g.uvs if g.uvs is not None else np.zeros((g.vertices.shape[0], 2), F))
+        off += g.vertices.shape[0]
+    return Geometry(np.concatenate(verts).astype(F), np.concatenate(tris).astype(np.uint32),
+                    np.concatenate(uvs).astype(F))
+
+
+def _finish(name, geoms, mat_ids, materials, textures, camera, spp) -> Scene:
+    s = Scene(name=name)
+    s.meshes = [Mesh(geoms)]
+    s.parameterized_meshes = [ParameterizedMesh(0, list(mat_ids))]
+    s.instances = [Instance(np.eye(4, dtype=F).reshape(16), 0)]
+    s.materials = materials
+    s.textures = textures
+    s.lights = [obj_default_light()]
+    s.cameras = [camera]
+    s.samples_per_pixel = spp
+    return s
+
+
+# ---------------------------------------------------------------- procedural textures
+
+
+def _value_noise(rng, size, cells):
+    g = rng.random((cells + 1, cells + 1)).astype(F)
+    t = np.linspace(0, cells, size, endpoint=False, dtype=F)
+    i = t.astype(np.int32)
+    f = t - i
+    f = f * f * (3 - 2 * f)
+    a = g[i][:, i] * (1 - f)[None, :] + g[i][:, i + 1] * f[None, :]
+    b = g[i + 1][:, i] * (1 - f)[None, :] + g[i + 1][:, i + 1] * f[None, :]
+    return a * (1 - f)[:, None] + b * f[:, None]
+
+
+def _color_texture(rng, size, channels=4) -> Image:
+    """sRGB base-colour texture: tinted value noise + stripes."""
+    n = 0.6 * _value_noise(rng, size, 8) + 0.4 * _value_noise(rng, size, 64)
+    yy = np.arange(size, dtype=F)[:, None] / size
+    stripes = 0.5 + 0.5 * np.sin(2 * np.pi * yy * rng.integers(4, 24))
+    tint = rng.random(3).astype(F) * 0.7 + 0.25
+    img = np.zeros((size, size, channels), dtype=F)
+    for c in range(min(3, channels)):
+        img[..., c] = tint[c] * (0.35 + 0.65 * n) * (0.8 + 0.2 * stripes)
+    if channels == 4:
+        img[..., 3] = 1.0
+    return Image(size, size, channels, (np.clip(img, 0, 1) * 255).astype(np.uint8), SRGB)
+
+
+def _param_texture(rng, size, channels=4) -> Image:
+    """Linear parameter texture (glTF-style: g = roughness, b = metallic)."""
+    img = np.zeros((size, size, channels), dtype=F)
+    img[..., 0] = _value_noise(rng, size, 4)
+    img[..., 1] = 0.2 + 0.75 * _value_noise(rng, size, 16)
+    if channels > 2:
+        img[..., 2] = (_value_noise(rng, size, 6) > 0.6).astype(F)
+    if channels == 4:
+        img[..., 3] = 1.0
+    return Image(size, size, channels, (np.clip(img, 0, 1) * 255).astype(np.uint8), LINEAR)
+
+
+# ---------------------------------------------------------------- S1: Cornell box
+
+
+def cornell(spp: int = 1) -> Scene:
+    """S1: 5 walls + 2 boxes = 34 triangles, white/red/green diffuse."""
+    geoms = [
+        _quad((-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)),    # floor
+        _quad((-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)),    # ceiling
+        _quad((-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)),  # back
+        _quad((-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)),  # left (red)
+        _quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)),      # right (green)
+        _box((0.33, 0.3, 0.35), (0.3, 0.3, 0.3), rot_y=-0.3),     # short box
+        _box((-0.35, 0.6, -0.3), (0.3, 0.6, 0.3), rot_y=0.3),     # tall box
+    ]
+    white = disney_material((0.73, 0.73, 0.73))
+    red = disney_material((0.65, 0.05, 0.05))
+    green = disney_material((0.12, 0.45, 0.15))
+    cam = Camera(np.array([0, 1, 3.4], F), np.array([0, 1, 0], F), np.array([0, 1, 0], F), 40.0)
+    return _finish("cornell", geoms, [0, 0, 0, 1, 2, 0, 0], [white, red, green], [], cam, spp)
+
+
+# ---------------------------------------------------------------- S2: Sponza-like atrium
+
+
+def _cylinder(cx, cz, y0, y1, r, nseg, nstack, uv_rep=(2.0, 4.0), bulge=0.0) -> Geometry:
+    def fn(u, v):
+        rr = r * (1.0 + bulge * np.sin(np.pi * v) + 0.04 * np.cos(16 * np.pi * u))
+        a = 2 * np.pi * u
+        return cx + rr * np.cos(a), y0 + (y1 - y0) * v, cz + rr * np.sin(a)
+    return _grid(nseg, nstack, fn, (-uv_rep[0], -uv_rep[1]), (uv_rep[0], uv_rep[1]))
+
+
+def _arch(x0, x1, z, y0, rise, depth, nseg, nd) -> Geometry:
+    def fn(u, v):
+        a = np.pi * u
+        xm, hw = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+        return xm - hw * np.cos(a), y0 + rise * np.sin(a), z + depth * (v - 0.5)
+    return _grid(nseg, nd, fn, (-1.0, 0.0), (2.0, 1.0))
+
+
+def sponza_like(spp: int = 4, seed: int = 2, tex_size: int = 1024, detail: float = 1.0) -> Scene:
+    """S2: two-storey colonnaded atrium, ~262 k triangles at detail=1, 24 materials,
+    16 RGBA8 textures (8 sRGB base colour + 8 linear parameter maps)."""
+    rng = np.random.default_rng(seed)
+    d = lambda n: max(2, int(round(n * math.sqrt(detail))))
+    geoms: List[Geometry] = []
+    mats: List[int] = []
+
+    def add(g, m):
+        geoms.append(g)
+        mats.append(m)
+
+    L, Wd, H = 24.0, 8.0, 10.0
+    # floor / ceiling / walls (UVs run over [-2, 3] so wrap + negative-coordinate quirk Q12 is hit)
+    add(_grid(d(160), d(64), lambda u, v: (-L / 2 + L * u, 0 * u, Wd / 2 - Wd * v), (-2, -2), (3, 3)), 0)
+    add(_grid(d(96), d(40), lambda u, v: (-L / 2 + L * u, H + 0 * u, -Wd / 2 + Wd * v), (0, 0), (6, 2)), 1)
+    add(_grid(d(96), d(48), lambda u, v: (-L / 2 + L * u, H * v, -Wd / 2 + 0 * u), (-2, 0), (3, 2)), 2)
+    add(_grid(d(96), d(48), lambda u, v: (L / 2 - L * u, H * v, Wd / 2 + 0 * u), (-2, 0), (3, 2)), 2)
+    add(_grid(d(40), d(48), lambda u, v: (-L / 2 + 0 * u, H * v, Wd / 2 - Wd * u), (0, 0), (2, 2)), 3)
+    add(_grid(d(40), d(48), lambda u, v: (L / 2 + 0 * u, H * v, -Wd / 2 + Wd * u), (0, 0), (2, 2)), 3)
+    # colonnades: 2 storeys x 2 sides x 10 columns, arches between neighbours
+    ncol = 10
+    xs = np.linspace(-L / 2 + 1.5, L / 2 - 1.5, ncol)
+    for storey in range(2):
+        y0, y1 = storey * 4.6, storey * 4.6 + 3.4
+        for side in (-1, 1):
+            z = side * (Wd / 2 - 1.6)
+            for ci, x in enumerate(xs):
+                add(_cylinder(x, z, y0, y1, 0.28, d(32), d(20), bulge=0.08), 4 + (ci + storey) % 4)
+                add(_box((x, y1 + 0.12, z), (0.42, 0.12, 0.42), uv_scale=2.0), 8)
+                if ci + 1 < ncol:
+                    add(_arch(x + 0.3, xs[ci + 1] - 0.3, z, y1 + 0.24, 0.9, 0.6, d(32), d(12)), 9 + storey)
+        # gallery floor slabs
+        if storey == 1:
+            for side in (-1, 1):
+                zc = side * (Wd / 2 - 0.8)
+                add(_grid(d(96), d(12), lambda u, v, zc=zc: (-L / 2 + L * u, 4.5 + 0 * u, zc - 0.8 + 1.6 * v),
+                          (-2, 0), (3, 1)), 11)
+    # drapes: sine-displaced cloth
+    for k in range(8):
+        x = -L / 2 + 3.0 + 2.6 * k
+        ph = rng.random() * 6.28
+        def fn(u, v, x=x, ph=ph):
+            return (x + 1.8 * u, 8.6 - 3.6 * v, 0.25 * np.sin(10 * u + ph) * v + 0.1 * np.sin(23 * u) + (k % 2) * 1.2 - 0.6)
+        add(_grid(d(72), d(64), fn, (0, 0), (1, 1)), 12 + k % 4)
+    # vases / urns: lathe surfaces, some metallic / clear-coated
+    for k in range(14):
+        x = -L / 2 + 1.8 + 1.6 * k
+        z = (1 if k % 2 else -1) * 0.9
+        def fn(u, v, x=x, z=z):
+            r = 0.18 + 0.22 * np.sin(np.pi * v) ** 2 * (1 + 0.3 * np.sin(3 * np.pi * v))
+            return x + r * np.cos(2 * np.pi * u), 0.9 * v, z + r * np.sin(2 * np.pi * u)
+        add(_grid(d(48), d(36), fn, (0, 0), (2, 1)), 16 + k % 8)
+
+    tex = [_color_texture(rng, tex_size) for _ in range(8)] + [_param_texture(rng, tex_size) for _ in range(8)]
+    materials = []
+    for m in range(24):
+        r = np.random.default_rng(seed * 1000 + m)
+        kind = m % 6
+        mat = disney_material(base_color=tuple(0.2 + 0.7 * r.random(3)), roughness=0.35 + 0.6 * r.random(),
+                              specular=0.5 * r.random())
+        if m < 16:  # textured base colour
+            mat[0] = textured_param(m % 8)
+        if kind in (1, 4):  # roughness / metallic from parameter map channels
+            mat[5] = textured_param(8 + m % 8, 1)
+            mat[3] = textured_param(8 + m % 8, 2)
+        if kind == 2:
+            mat[3], mat[5] = 1.0, 0.2 + 0.3 * r.random()  # metal
+        if kind == 3:
+            mat[10], mat[11] = 1.0, 0.8  # clear coat
+        if kind == 5:
+            mat[8], mat[9] = 0.8, 0.5  # sheen (cloth)
+        if m in (17, 21):
+            mat[7] = 0.6  # anisotropy
+        materials.append(mat)
+    cam = Camera(np.array([-10.5, 1.9, 0.3], F), np.array([0, 3.2, 0], F), np.array([0, 1, 0], F), 65.0)
+    return _finish("sponza_like", geoms, mats, materials, tex, cam, spp)
+
+
+# ---------------------------------------------------------------- S3: Rungholt-like voxel city
+
+
+def _heightfield(rng, n):
+    h = np.zeros((n, n), dtype=F)
+    for cells, amp in ((6, 14.0), (24, 7.0), (96, 3.0)):
+        v = _value_noise(rng, n, cells)
+        h += amp * (1.0 - np.abs(2 * v - 1))  # ridged
+    # city blocks: flat plateaus with towers
+    blocks = rng.random((n // 12 + 1, n // 12 + 1)) > 0.55
+    tow = np.kron(blocks, np.ones((12, 12), dtype=bool))[:n, :n]
+    tower_h = np.kron((rng.random(blocks.shape) * 24).astype(F), np.ones((12, 12), dtype=F))[:n, :n]
+    inner = (np.indices((n, n)) % 12)
+    inner = (inner[0] > 1) & (inner[0] < 10) & (inner[1] > 1) & (inner[1] < 10)
+    h = np.where(tow & inner, np.floor(h * 0.3) + tower_h, h)
+    return np.floor(h).astype(np.int32)
+
+
+def rungholt_like(spp: int = 8, seed: int = 3, n: int = 1160, n_mats: int = 64) -> Scene:
+    """S3: voxel height-field city: one quad per cell top + one quad per unit of exposed side
+    height. n=1160 gives ~6.7 M triangles; 64 flat materials, no textures."""
+    rng = np.random.default_rng(seed)
+    h = _heightfield(rng, n)
+    cell = 0.25
+    quads = []  # (n,4,3) float arrays
+    mids = []
+
+    def emit(p, m):
+        quads.append(p.reshape(-1, 4, 3))
+        mids.append(m.reshape(-1))
+
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    x0, x1 = (ii - n / 2) * cell, (ii + 1 - n / 2) * cell
+    z0, z1 = (jj - n / 2) * cell, (jj + 1 - n / 2) * cell
+    y = h * cell
+    mat_top = (h * 3 + (ii // 12) * 7 + (jj // 12) * 13) % n_mats
+    top = np.stack([np.stack([x0, y, z1], -1), np.stack([x1, y, z1], -1), np.stack([x1, y, z0], -1),
+                    np.stack([x0, y, z0], -1)], axis=-2)
+    emit(top, mat_top)
+    # side walls: for each of 4 neighbours, one quad per unit step of exposed height (Minecraft-like)
+    hp = np.pad(h, 1, mode="edge")
+    for (di, dj) in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+        nb = hp[1 + di:n + 1 + di, 1 + dj:n + 1 + dj]
+        diff = np.clip(h - nb, 0, 48)
+        maxd = int(diff.max())
+        for k in range(maxd):
+            sel = diff > k
+            if not sel.any():
+                break
+            i_s, j_s = ii[sel], jj[sel]
+            yt = (h[sel] - k) * cell
+            yb = yt - cell
+            if di != 0:
+                xs = ((i_s + (1 if di > 0 else 0)) - n / 2) * cell
+                za, zb = (j_s - n / 2) * cell, (j_s + 1 - n / 2) * cell
+                if di > 0:
+                    za, zb = zb, za
+                p = np.stack([np.stack([xs, yb, za], -1), np.stack([xs, yb, zb], -1),
+                              np.stack([xs, yt, zb], -1), np.stack([xs, yt, za], -1)], axis=-2)
+            else:
+                zs = ((j_s + (1 if dj > 0 else 0)) - n / 2) * cell
+                xa, xb = (i_s - n / 2) * cell, (i_s + 1 - n / 2) * cell
+                if dj < 0:
+                    xa, xb = xb, xa
+                p = np.stack([np.stack([xa, yb, zs], -1), np.stack([xb, yb, zs], -1),
+                              np.stack([xb, yt, zs], -1), np.stack([xa, yt, zs], -1)], axis=-2)
+            emit(p, (mat_top[sel] + 1 + k // 4) % n_mats)
+    allq = np.concatenate(quads).astype(F)
+    allm = np.concatenate(mids)
+    geoms, mat_ids = [], []
+    order = np.argsort(allm, kind="stable")
+    allq, allm = allq[order], allm[order]
+    bounds = np.searchsorted(allm, np.arange(n_mats + 1))
+    for m in range(n_mats):
+        q = allq[bounds[m]:bounds[m + 1]]
+        if q.shape[0] == 0:
+            continue
+        verts = q.reshape(-1, 3)
+        base = (np.arange(q.shape[0], dtype=np.int64) * 4)[:, None]
+        tris = np.concatenate([base + np.array([0, 1, 2]), base + np.array([0, 2, 3])]).astype(np.uint32)
+        geoms.append(Geometry(verts, tris, None))
+        mat_ids.append(m)
+    materials = []
+    for m in range(n_mats):
+        r = np.random.default_rng(seed * 1000 + m)
+        materials.append(disney_material(base_color=tuple(0.15 + 0.75 * r.random(3)),
+                                         roughness=0.5 + 0.5 * r.random(), specular=0.3 * r.random()))
+    ext = n * cell / 2
+    cam = Camera(np.array([-0.8 * ext, 0.55 * ext, 0.9 * ext], F), np.array([0, 2.0, 0], F),
+                 np.array([0, 1, 0], F), 55.0)
+    return _finish("rungholt_like", geoms, mat_ids, materials, [], cam, spp)
+
+
+# ---------------------------------------------------------------- S4: San-Miguel-like courtyard
+
+
+def _tree(rng, n_leaves: int, trunk_seg=12) -> Tuple[Geometry, Geometry]:
+    """(trunk, leaves) in object space: leaves are small random quads in a crown volume."""
+    trunk = _cylinder(0.0, 0.0, 0.0, 2.2, 0.16, trunk_seg, 8, uv_rep=(1.0, 2.0))
+    c = rng.normal(size=(n_leaves, 3)).astype(F)
+    c *= (rng.random((n_leaves, 1)) ** (1 / 3) / np.linalg.norm(c, axis=1, keepdims=True)).astype(F)
+    c = c * np.array([1.6, 1.2, 1.6], F) + np.array([0, 3.1, 0], F)
+    a = rng.normal(size=(n_leaves, 3)).astype(F)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = np.cross(a, rng.normal(size=(n_leaves, 3)).astype(F))
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    s = (0.05 + 0.05 * rng.random((n_leaves, 1))).astype(F)
+    p = np.stack([c - s * a - s * b, c + s * a - s * b, c + s * a + s * b, c - s * a + s * b], axis=1)
+    verts = p.reshape(-1, 3).astype(F)
+    base = (np.arange(n_leaves, dtype=np.int64) * 4)[:, None]
+    tris = np.concatenate([base + np.array([0, 1, 2]), base + np.array([0, 2, 3])]).astype(np.uint32)
+    uvs = np.tile(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], F), (n_leaves, 1))
+    return trunk, Geometry(verts, tris, uvs)
+
+
+def _xform(g: Geometry, m: np.ndarray) -> Geometry:
+    v = g.vertices @ m[:3, :3].T.astype(F) + m[:3, 3].astype(F)
+    return Geometry(v.astype(F), g.indices, g.uvs)
+
+
+def _trs(tx, ty, tz, rot_y, s) -> np.ndarray:
+    c, sn = math.cos(rot_y), math.sin(rot_y)
+    m = np.eye(4, dtype=np.float64)
+    m[:3, :3] = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]]) * s
+    m[:3, 3] = (tx, ty, tz)
+    return m
+
+
+def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
+    mats = []
+    for m in range(n_mats):
+        r = np.random.default_rng(seed * 1000 + m)
+        mat = disney_material(base_color=tuple(0.15 + 0.8 * r.random(3)), roughness=0.2 + 0.8 * r.random(),
+                              specular=r.random() * 0.8, specular_tint=r.random() * 0.5)
+        kind = m % 8
+        if n_tex_color and m % 4 != 3:
+            mat[0] = textured_param(m % n_tex_color)
+        if n_tex_param and kind in (1, 5):
+            mat[5] = textured_param(n_tex_color + m % n_tex_param, 1)
+            mat[3] = textured_param(n_tex_color + m % n_tex_param, 2)
+        if kind == 2:
+            mat[3] = 1.0
+            mat[5] = 0.15 + 0.4 * r.random()
+        if kind == 3:
+            mat[10], mat[11] = 1.0, r.random()
+        if kind == 4:
+            mat[8], mat[9] = r.random(), r.random()
+        if kind == 6:
+            mat[7] = 0.3 + 0.6 * r.random()  # anisotropic
+            mat[5] = 0.3
+        if kind == 7 and m % 16 == 7:
+            mat[13], mat[12], mat[5] = 0.9, 1.45, 0.05  # glass: specular_transmission > 0
+        mats.append(mat)
+    return mats
+
+
+def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per_tree: int = 2300,
+                   tex_size: int = 2048, n_tex: int = 64, n_mats: int = 128, detail: float = 1.0) -> Scene:
+    """S4: courtyard with arcades, tiled floor, furniture and flattened foliage. Defaults give
+    ~10 M triangles in one mesh (like the San Miguel OBJ), 128 materials covering every Disney
+    lobe, 64 textures."""
+    rng = np.random.default_rng(seed)
+    d = lambda n: max(2, int(round(n * math.sqrt(detail))))
+    n_tc = n_tex * 3 // 4
+    n_tp = n_tex - n_tc
+    geoms: List[Geometry] = []
+    mats: List[int] = []
+
+    def add(g, m):
+        geoms.append(g)
+        mats.append(m % n_mats)
+
+    S = 40.0
+    # tiled floor: bumpy tiles
+    add(_grid(d(700), d(700), lambda u, v: (-S / 2 + S * u, 0.02 * np.sin(80 * np.pi * u) * np.sin(80 * np.pi * v),
+                                            S / 2 - S * v), (-2, -2), (3, 3)), 0)
+    # perimeter walls with arcades
+    for k, (ax, sg) in enumerate(((0, 1), (0, -1), (1, 1), (1, -1))):
+        def wall(u, v, ax=ax, sg=sg):
+            a = -S / 2 + S * u
+            bump = 0.05 * np.sin(40 * np.pi * u) * np.sin(9 * np.pi * v)
+            return ((a, 9 * v, sg * (S / 2) + bump) if ax == 0 else (sg * (S / 2) + bump, 9 * v, a))
+        add(_grid(d(420), d(200), wall, (-2, 0), (3, 2), flip=(sg > 0) == (ax == 0)), 1 + k)
+        for ci in range(14):
+            a = -S / 2 + 2.0 + ci * (S - 4.0) / 13
+            x, z = (a, sg * (S / 2 - 3.0)) if ax == 0 else (sg * (S / 2 - 3.0), a)
+            add(_cylinder(x, z, 0.0, 4.0, 0.3, d(40), d(40), bulge=0.06), 8 + (ci + k) % 8)
+            add(_box((x, 4.15, z), (0.5, 0.15, 0.5), uv_scale=2.0), 16 + k)
+    # furniture: tables (boxes) + chairs + lathe-turned pots
+    for k in range(60):
+        x, z = (rng.random(2) - 0.5) * (S - 12)
+        add(_box((x, 0.75, z), (0.7, 0.04, 0.7), rot_y=rng.random() * 3.0), 20 + k % 12)
+        for lx, lz in ((-0.6, -0.6), (0.6, -0.6), (0.6, 0.6), (-0.6, 0.6)):
+            add(_cylinder(x + lx, z + lz, 0.0, 0.72, 0.035, d(12), d(6)), 32 + k % 6)
+        def pot(u, v, x=x, z=z):
+            r = 0.12 + 0.1 * np.sin(np.pi * v) ** 2
+            return x + r * np.cos(2 * np.pi * u), 0.8 + 0.4 * v, z + r * np.sin(2 * np.pi * u)
+        add(_grid(d(40), d(30), pot, (0, 0), (2, 1)), 40 + k % 24)
+    # flattened foliage
+    proto = [_tree(np.random.default_rng(seed * 77 + i), leaves_per_tree) for i in range(4)]
+    trunks, leaves = [[] for _ in range(8)], [[] for _ in range(8)]
+    for t in range(n_trees):
+        x, z = (rng.random(2) - 0.5) * (S - 6)
+        m = _trs(x, 0.0, z, rng.random() * 6.28, 0.7 + 0.6 * rng.random())
+        tr, lv = proto[t % 4]
+        trunks[t % 8].append(_xform(tr, m))
+        leaves[t % 8].append(_xform(lv, m))
+    for k in range(8):
+        if trunks[k]:
+            add(_merge(trunks[k]), 64 + k)
+            add(_merge(leaves[k]), 72 + k * 3)
+    tex = [_color_texture(np.random.default_rng(seed * 31 + i), tex_size) for i in range(n_tc)] + \
+          [_param_texture(np.random.default_rng(seed * 37 + i), tex_size) for i in range(n_tp)]
+    materials = _sanmiguel_materials(seed, n_mats, n_tc, n_tp)
+    cam = Camera(np.array([-13.0, 1.7, 12.0], F), np.array([2.0, 2.4, -1.0], F), np.array([0, 1, 0], F), 60.0)
+    return _finish("sanmiguel_like", geoms, mats, materials, tex, cam, spp)
+
+
+# ---------------------------------------------------------------- instanced test scene
+
+
+def instanced_grove(spp: int = 2, seed: int = 7, n_instances: int = 64, leaves_per_tree: int = 300,
+                    tex_size: int = 64) -> Scene:
+    """Small two-level scene: a ground mesh plus `n_instances` rotated/scaled/translated
+    instances of two tree meshes (multi-geometry BLAS, non-identity transforms, textures,
+    glass and anisotropic materials)."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name="instanced_grove")
+    ground = _grid(32, 32, lambda u, v: (-12 + 24 * u, 0.15 * np.sin(9 * u) * np.cos(7 * v), 12 - 24 * v),
+                   (-2, -2), (3, 3))
+    ball = _grid(24, 16, lambda u, v: (0.8 * np.sin(np.pi * v) * np.cos(2 * np.pi * u), 0.8 - 0.8 * np.cos(np.pi * v),
+                                       0.8 * np.sin(np.pi * v) * np.sin(2 * np.pi * u)), (0, 0), (1, 1), flip=True)
+    s.meshes = [Mesh([ground])]
+    for i in range(2):
+        tr, lv = _tree(np.random.default_rng(seed + 10 + i), leaves_per_tree)
+        s.meshes.append(Mesh([tr, lv]))
+    s.meshes.append(Mesh([ball]))
+    s.parameterized_meshes = [ParameterizedMesh(0, [0]), ParameterizedMesh(1, [1, 2]),
+                              ParameterizedMesh(2, [1, 3]), ParameterizedMesh(1, [4, 5]),
+                              ParameterizedMesh(3, [6]), ParameterizedMesh(3, [7])]
+    s.instances = [Instance(np.eye(4, dtype=F).reshape(16), 0)]
+    for k in range(n_instances):
+        x, z = (rng.random(2) - 0.5) * 20
+        m = _trs(x, 0.0, z, rng.random() * 6.28, 0.5 + 0.8 * rng.random())
+        if k % 9 == 0:
+            m[:3, :3] = m[:3, :3] @ np.diag([1.0, 1.4, 0.7])  # non-uniform scale
+        pm = 4 + (k // 5) % 2 if k % 5 == 0 else 1 + k % 3
+        if k % 5 == 0:
+            m = _trs(x, 0.0, z, 0.0, 0.6 + 0.5 * rng.random())
+        s.instances.append(Instance(m.T.astype(F).reshape(16), pm))  # column-major
+    tex = [_color_texture(rng, tex_size), _color_texture(rng, tex_size, channels=3), _param_texture(rng, tex_size)]
+    s.textures = tex
+    glass = disney_material((0.9, 0.95, 1.0), roughness=0.05, ior=1.45, specular_transmission=0.9)
+    aniso = disney_material((0.8, 0.6, 0.2), metallic=1.0, roughness=0.3, anisotropy=0.8)
+    ground_m = disney_material(roughness=0.9)
+    ground_m[0] = textured_param(0)
+    bark = disney_material((0.35, 0.25, 0.15), roughness=0.8, sheen=0.4, sheen_tint=0.5)
+    leaf_a = disney_material(roughness=0.6, specular=0.4)
+    leaf_a[0] = textured_param(1)
+    leaf_a[5] = textured_param(2, 1)
+    leaf_b = disney_material((0.2, 0.5, 0.1), roughness=0.5, clearcoat=1.0, clearcoat_gloss=0.7)
+    s.materials = [ground_m, bark, leaf_a, leaf_b, aniso, leaf_b, glass, aniso]
+    s.lights = [obj_default_light()]
+    s.cameras = [Camera(np.array([0, 3.0, 14.0], F), np.array([0, 1.5, 0], F), np.array([0, 1, 0], F), 55.0)]
+    s.samples_per_pixel = spp
+    return s
+
+
+WORKLOADS = {
+    # name: (generator, kwargs, width, height, spp)  -- BASELINE.json configs C1..C5
+    "C1": (cornell, {}, 512, 512, 1),
+    "C2": (sponza_like, {}, 1280, 720, 4),
+    "C3": (rungholt_like, {}, 1920, 1080, 8),
+    "C4": (sanmiguel_like, {}, 1920, 1080, 16),
+    "C5": (sanmiguel_like, {}, 3840, 2160, 64),
+}
+
+
+def make_workload(name: str, **overrides):
+    gen, kw, w, h, spp = WORKLOADS[name]
+    kw = dict(kw)
+    kw.update(overrides)
+    return gen(spp=spp, **kw), w, h, spp

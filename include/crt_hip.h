@@ -1,0 +1,211 @@
+/* crt_hip.h — C-ABI of the MI355X wavefront path-tracing core (libcrt_hip_core.so).
+ *
+ * This is the drop-in boundary for ChameleonRT's render hot path. Every entry point
+ * replaces one piece of the reference's `RenderBackend` contract as implemented by the
+ * Embree backend; citations are into the reference tree (Twinklebear/ChameleonRT):
+ *
+ *   crt_hip_create / crt_hip_destroy   RenderEmbree::RenderEmbree / ~RenderEmbree
+ *                                      (backends/embree/render_embree.cpp:19-31)
+ *   crt_hip_initialize                 RenderBackend::initialize (util/render_backend.h:20,
+ *                                      backends/embree/render_embree.cpp:38-56)
+ *   crt_hip_set_scene                  RenderBackend::set_scene (util/render_backend.h:23,
+ *                                      backends/embree/render_embree.cpp:58-133)
+ *   crt_hip_render                     RenderBackend::render (util/render_backend.h:26-31,
+ *                                      backends/embree/render_embree.cpp:135-216)
+ *   crt_hip_framebuffer                RenderBackend::img (util/render_backend.h:13)
+ *   crt_hip_name                       RenderBackend::name (util/render_backend.h:18)
+ *
+ * The C++ plugin shim `backends/hip/render_hip.{h,cpp}` (struct RenderHIP : RenderBackend)
+ * and the Python ctypes binding `chameleonrt_amd/core.py` both sit on exactly these
+ * symbols. Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Conventions: every function returning int returns 0 on success and a negative
+ * CRT_HIP_E* code on failure; nothing throws across the boundary. `crt_hip_last_error`
+ * gives the message. A context is single-threaded (the reference calls its backend from
+ * the main thread only, main.cpp:231-380). There is no CPU fallback: if no gfx950 device
+ * is usable, crt_hip_create fails.
+ */
+#ifndef CRT_HIP_H
+#define CRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_HIP_ABI_VERSION 1
+
+enum {
+    CRT_HIP_OK = 0,
+    CRT_HIP_EINVAL = -1,  /* bad argument / malformed scene */
+    CRT_HIP_EDEVICE = -2, /* HIP runtime error (no device, OOM, launch failure) */
+    CRT_HIP_ESTATE = -3   /* call order violated (render before initialize/set_scene) */
+};
+
+/* Image colour spaces, util/material.h:9 (enum ColorSpace { LINEAR, SRGB }). */
+enum { CRT_COLORSPACE_LINEAR = 0, CRT_COLORSPACE_SRGB = 1 };
+
+/* One `Geometry` (util/mesh.h:6-12). Per-vertex normals are not part of the hot path:
+ * the reference ignores them (render_embree.ispc:269-270), so they are not passed. */
+typedef struct crt_geometry_desc {
+    const float *vertices;   /* n_vertices * 3 floats (glm::vec3) */
+    uint64_t n_vertices;
+    const uint32_t *indices; /* n_triangles * 3 (glm::uvec3) */
+    uint64_t n_triangles;
+    const float *uvs;        /* n_vertices * 2 floats (glm::vec2) or NULL */
+} crt_geometry_desc;
+
+/* One `Mesh` (util/mesh.h:14-22): a contiguous range of the geometry array. The position
+ * of a geometry inside its mesh is Embree's geomID (embree_utils.cpp:63-76). */
+typedef struct crt_mesh_desc {
+    uint32_t first_geometry;
+    uint32_t n_geometries;
+} crt_mesh_desc;
+
+/* One `ParameterizedMesh` (util/mesh.h:28-36): one material id per geometry. */
+typedef struct crt_parameterized_mesh_desc {
+    uint32_t mesh_id;
+    uint32_t n_material_ids;
+    const uint32_t *material_ids;
+} crt_parameterized_mesh_desc;
+
+/* One `Instance` (util/mesh.h:40-47): glm::mat4 is column-major, m[c*4+r]. */
+typedef struct crt_instance_desc {
+    float transform[16];
+    uint32_t parameterized_mesh_id;
+} crt_instance_desc;
+
+/* One `Image` (util/material.h:11-27). */
+typedef struct crt_image_desc {
+    int32_t width, height, channels;
+    int32_t color_space; /* CRT_COLORSPACE_* */
+    const uint8_t *data; /* width*height*channels bytes, row 0 first */
+} crt_image_desc;
+
+/* `Scene` as handed to set_scene (util/scene.h:23-32). All pointers are borrowed for the
+ * duration of crt_hip_set_scene only; the core copies what it needs (the reference
+ * destroys its Scene right after set_scene, main.cpp:185-214).
+ *
+ * materials: n_materials * 16 floats, the 64-byte `DisneyMaterial` of util/material.h:29-46
+ *   (base_color.rgb, metallic, specular, roughness, specular_tint, anisotropy, sheen,
+ *   sheen_tint, clearcoat, clearcoat_gloss, ior, specular_transmission, pad.xy). Textured
+ *   parameters are encoded in the float bits per util/texture_channel_mask.h:16-23.
+ * lights: n_lights * 20 floats, the 80-byte `QuadLight` of util/lights.h:6-18
+ *   (emission.xyzw, position.xyzw, normal.xyzw, v_x.xyz, width, v_y.xyz, height). */
+typedef struct crt_scene_desc {
+    const crt_geometry_desc *geometries;
+    uint32_t n_geometries;
+    const crt_mesh_desc *meshes;
+    uint32_t n_meshes;
+    const crt_parameterized_mesh_desc *parameterized_meshes;
+    uint32_t n_parameterized_meshes;
+    const crt_instance_desc *instances;
+    uint32_t n_instances;
+    const float *materials;
+    uint32_t n_materials;
+    const crt_image_desc *textures;
+    uint32_t n_textures;
+    const float *lights;
+    uint32_t n_lights;
+    uint32_t samples_per_pixel; /* Scene::samples_per_pixel, util/scene.h:31 */
+} crt_scene_desc;
+
+/* RenderStats (util/render_backend.h:7-10) plus what the roofline needs.
+ * rays follow REPORT_RAY_STATS semantics (render_embree.ispc:145-147,171-173,246-248):
+ * one per closest-hit trace and one per occlusion trace, misses included. Counted in
+ * 64 bits (the reference's uint16/int accumulation overflows at 4K/64spp). */
+typedef struct crt_render_stats {
+    float render_time_ms;  /* all kernels of the frame incl. tonemap + stat reduction */
+    float rays_per_second; /* rays / (render_time_ms * 1e-3) */
+    uint64_t rays;
+    uint64_t closest_rays; /* rays traced by the closest-hit traversal kernel */
+    uint64_t shadow_rays;  /* rays traced by the any-hit traversal kernel */
+    float closest_ms;      /* summed duration of the closest-hit traversal launches */
+    float shadow_ms;       /* summed duration of the any-hit traversal launches */
+    float shade_ms;        /* raygen + shade + accumulate launches */
+    /* only when CRT_HIP_FLAG_COUNTERS: nodes fetched / triangles tested by traversal */
+    uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris;
+} crt_render_stats;
+
+typedef struct crt_hip_ctx crt_hip_ctx;
+
+enum {
+    CRT_HIP_FLAG_NONE = 0,
+    CRT_HIP_FLAG_COUNTERS = 1, /* count BVH nodes / triangles touched (instrumented kernels) */
+    CRT_HIP_FLAG_TIMING = 2    /* per-kernel-class HIP event timing in crt_render_stats */
+};
+
+int crt_hip_abi_version(void);
+int crt_hip_device_count(void);
+
+/* device_id: HIP device ordinal. NULL on failure (message via crt_hip_last_error(NULL)). */
+crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags);
+void crt_hip_destroy(crt_hip_ctx *ctx);
+const char *crt_hip_last_error(const crt_hip_ctx *ctx);
+const char *crt_hip_name(const crt_hip_ctx *ctx);
+
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*),
+ * e.g. torch.cuda.current_stream().cuda_stream. NULL = the context's own stream. */
+int crt_hip_set_stream(crt_hip_ctx *ctx, void *hip_stream);
+
+/* Image-tile partition for multi-GPU rendering (new functionality): the
+ * framebuffer is cut into the reference's 64x64 tiles (render_embree.h:25) and this
+ * context renders the tiles with tile_id % world == rank. Must precede initialize. */
+int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world);
+
+int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height);
+int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *scene);
+
+/* One frame. fovy in degrees; camera_changed resets accumulation (frame_id = 0). When
+ * readback != 0 the RGBA8 image is copied to the host buffer behind crt_hip_framebuffer
+ * (for world > 1 only this rank's tiles are valid; see crt_hip_assemble_tiles). */
+int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir[3], const float up[3],
+                   float fovy_deg, int camera_changed, int readback, crt_render_stats *stats);
+
+/* W*H RGBA8 (8-bit sRGB, A=255), row 0 = top: RenderBackend::img. */
+const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx);
+
+/* Parity/diagnostic reads (synchronise the stream). Row-major W*H. */
+int crt_hip_read_accum(crt_hip_ctx *ctx, float *rgb /* W*H*3 */);
+int crt_hip_read_ray_counts(crt_hip_ctx *ctx, uint32_t *counts /* W*H, last frame */);
+uint32_t crt_hip_frame_id(const crt_hip_ctx *ctx);
+
+/* Multi-GPU assembly. Each rank exposes its compact tile-major RGBA8 buffer
+ * (n_local_tiles_padded * 64*64 uint32, same size on every rank) as a device pointer; the
+ * caller gathers them (RCCL gather/all_gather) into world consecutive slabs on the root,
+ * which un-permutes them into its row-major image (kernel K8). */
+int crt_hip_tile_buffer(crt_hip_ctx *ctx, void **device_ptr, size_t *n_bytes);
+int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered_device_ptr, int world,
+                           int readback);
+
+/* ---- Diagnostic entry points used by the parity tests and the roofline bench ---- */
+
+/* Trace n arbitrary world-space rays through the scene with the production traversal
+ * kernels. Host arrays. closest: out_t/out_u/out_v/out_inst/out_geom/out_prim (inst = -1
+ * on a miss). any-hit (closest == 0): out_t[i] = 1 if the segment (tmin, tmax] is
+ * unoccluded else 0, other outputs may be NULL. */
+int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
+                       const float *dir /* n*3 */, const float *tmin, const float *tmax,
+                       int closest, float *out_t, float *out_u, float *out_v,
+                       int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
+                       crt_render_stats *stats);
+
+/* Known-answer tests of the device shading functions: run device function `fn` on n
+ * input records of in_stride floats, producing out_stride floats each (see
+ * chameleonrt_amd/csrc/kat.h for the record layouts). */
+int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_stride,
+                float *out, int out_stride);
+
+/* BVH introspection for tests: copy out the traversal arrays the kernels use. Pass NULL
+ * buffers to query sizes. Nodes are 64-byte records, triangles 48-byte records
+ * (DESIGN.md "Data layout in HBM"). */
+int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,
+                     uint64_t *n_instances, int32_t *two_level);
+int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_HIP_H */

@@ -1,0 +1,78 @@
+/* crt_oracle.h — C API of the CPU oracle (liborc.so).
+ *
+ * TEST INFRASTRUCTURE ONLY. The oracle is a scalar CPU restatement of the reference's
+ * Embree-backend path tracer. Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it, and only as the checker. Nothing under chameleonrt_amd/
+ * or backends/hip/ may include, link or call it.
+ *
+ * PARITY STATUS: "parity unpinned" at the ray/triangle boundary. The reference delegates
+ * BVH build, traversal and triangle intersection to Embree 4 (pinned 4.0.1 in
+ * .github/workflows/cmake.yml:12; call sites backends/embree/render_embree.ispc:144,170,245),
+ * which is not in /root/reference and not installable here, and the reference ships no
+ * tests, golden images or scenes. Everything the reference DOES define (RNG, camera,
+ * shading, lights, textures, accumulation, sRGB) is restated line by line; the integer
+ * RNG is pinned against an independent MurmurHash3/LCG implementation in
+ * tests/test_oracle_rng.py.
+ */
+#ifndef CRT_ORACLE_H
+#define CRT_ORACLE_H
+
+#include "../include/crt_hip.h" /* scene POD types only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+typedef struct orc_renderer orc_renderer;
+
+typedef struct orc_stats {
+    double render_time_ms;
+    double rays_per_second;
+    uint64_t rays;
+    uint64_t closest_rays, shadow_rays;
+    uint64_t nodes_visited, tris_tested; /* of the oracle's own BVH */
+} orc_stats;
+
+orc_scene *orc_scene_create(const crt_scene_desc *desc);
+void orc_scene_destroy(orc_scene *s);
+uint64_t orc_scene_num_triangles(const orc_scene *s);
+
+orc_renderer *orc_renderer_create(orc_scene *s, int fb_width, int fb_height, int n_threads);
+void orc_renderer_destroy(orc_renderer *r);
+
+/* RenderEmbree::render (backends/embree/render_embree.cpp:135-216). tile_begin/tile_end
+ * restrict the frame to a range of the reference's 64x64 tiles (row-major tile ids) so
+ * the CPU baseline can time a bounded sample; pass 0, -1 for the whole frame. */
+int orc_render(orc_renderer *r, const float pos[3], const float dir[3], const float up[3],
+               float fovy_deg, int camera_changed, int tile_begin, int tile_end,
+               orc_stats *stats);
+const uint32_t *orc_framebuffer(const orc_renderer *r);
+int orc_read_accum(const orc_renderer *r, float *rgb /* W*H*3 row-major */);
+int orc_read_ray_counts(const orc_renderer *r, uint32_t *counts /* W*H */);
+int orc_num_tiles(const orc_renderer *r);
+
+/* rtcIntersectV / rtcOccludedV stand-in. brute_force != 0 tests every triangle of every
+ * instance (no BVH): the definition of the right answer. Outputs as crt_hip_trace_rays. */
+int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, const float *dir,
+                   const float *tmin, const float *tmax, int closest, int brute_force,
+                   float *out_t, float *out_u, float *out_v, int32_t *out_inst,
+                   int32_t *out_geom, int32_t *out_prim, orc_stats *stats);
+
+/* Walk a FOREIGN BVH (the product's 64-byte nodes / 48-byte triangles) with the
+ * product's documented visit rule and count nodes fetched / triangles tested, to
+ * cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers. Single-level only. */
+int orc_count_foreign_bvh(const void *nodes, uint64_t n_nodes, const void *tris,
+                          uint64_t n_tris, uint64_t n, const float *org, const float *dir,
+                          const float *tmin, const float *tmax, int closest,
+                          uint64_t *nodes_visited, uint64_t *tris_tested);
+
+/* Shading-function KATs, record layouts in include/crt_kat.h. scene may be NULL for the
+ * functions that need none. */
+int orc_kat(const orc_scene *s, int fn, uint64_t n, const float *in, int in_stride, float *out,
+            int out_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
