@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- MRay/s (REPORT_RAY_STATS semantics) of the HIP wavefront path tracer.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C2]
+
+A "step" is one frame: one pass of the hot path over every pixel-sample of the workload
+(`-benchmark-frames` protocol of the reference, main.cpp:293-345: fixed camera,
+camera_changed only on frame 0). Inputs (scene, BVH, textures) are resident in HBM before the
+timed region. N > 1: one process per GPU (torch.distributed / RCCL), the framebuffer is split
+into 64x64 tiles (tile_id % N == rank), every step ends with the gather of the compact RGBA8
+tile buffers to rank 0 and the K8 un-permute. Scaling is weak: samples per pixel grow with N
+(4*N spp at C2) so the work per GPU stays fixed, as BASELINE.json's own configs do (16 spp on
+4 GPUs, 64 spp on 8).
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NODE_BYTES, TRI_BYTES = 64, 48
+QUEUE_BYTES_CLOSEST = 24 + 20  # o,d read + t,u,v,tri,inst written per ray
+QUEUE_BYTES_SHADOW = 28 + 16   # o,d,tmax read + path/bslot read, radiance RMW amortised
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", help="BASELINE.json config: C1..C5")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def wrap_device_buffer(ptr, nbytes):
+    """Zero-copy torch view of the core's compact tile buffer (plumbing for the collective)."""
+    import torch
+
+    class _Dev:
+        __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+    return torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    from chameleonrt_amd import core, multi_gpu, scenes
+    from chameleonrt_amd.render_hip import RenderHIP
+    from tests.parity import camera_of
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    base_spp = scenes.WORKLOADS[args.workload][4]
+    spp = base_spp * (world if args.scaling == "weak" else 1)
+    t0 = time.time()
+    gen, kw, width, height, _ = scenes.WORKLOADS[args.workload]
+    scene = gen(spp=spp, **kw)
+    t_gen = time.time() - t0
+    eye, cdir, up, fovy = camera_of(scene)
+
+    stream = torch.cuda.current_stream()
+    r = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, rank=rank, world=world, stream=stream.cuda_stream)
+    r.initialize(width, height)
+    t0 = time.time()
+    r.set_scene(scene)
+    t_scene = time.time() - t0
+    tile_view = None
+    if world > 1:
+        ptr, nbytes = r.tile_buffer()
+        tile_view = wrap_device_buffer(ptr, nbytes)
+
+    def step(frame):
+        st = r.render(eye, cdir, up, fovy, frame == 0, False)
+        if world > 1:
+            gathered = multi_gpu.gather_tile_buffers(tile_view)
+            if rank == 0:
+                r.assemble_tiles(gathered.data_ptr(), world, readback=False)
+        return st
+
+    for f in range(args.warmup):
+        step(f)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    rays = closest_rays = shadow_rays = 0
+    closest_ms = shadow_ms = shade_ms = 0.0
+    for k in range(args.steps):
+        st = step(args.warmup + k)
+        rays += st.rays
+        closest_rays += st.closest_rays
+        shadow_rays += st.shadow_rays
+        closest_ms += st.closest_ms
+        shadow_ms += st.shadow_ms
+        shade_ms += st.shade_ms
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        elapsed, total_rays = float(t.item()), int(c.item())
+    else:
+        total_rays = rays
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "MRay/s (REPORT_RAY_STATS)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "MRay/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {scene.name} {width}x{height} (synthetic stand-in, SURVEY 8d)",
+                       "spp_per_frame": spp, "triangles": scene.total_tris(), "textures": len(scene.textures),
+                       "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
+                       "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
+                                      (" + RCCL gather to rank 0 every step" if world > 1 else ""),
+                       "scene_gen_s": round(t_gen, 2), "set_scene_s": round(t_scene, 2)},
+        }
+    # ---- roofline of the traversal kernels (rank 0's share; identical code on every rank) ----
+    if rank == 0 and not args.no_roofline:
+        ri = RenderHIP(device=local_rank, flags=core.FLAG_COUNTERS, rank=rank, world=world, stream=stream.cuda_stream)
+        ri.initialize(width, height)
+        ri.set_scene(scene)
+        cn = ct = sn = stt = cr = sr = 0
+        n_probe = min(4, args.warmup + args.steps)
+        for f in range(n_probe):  # same frames -> same rays as the timed run (deterministic)
+            s2 = ri.render(eye, cdir, up, fovy, f == 0, False)
+            cn, ct, sn, stt = cn + s2.closest_nodes, ct + s2.closest_tris, sn + s2.shadow_nodes, stt + s2.shadow_tris
+            cr, sr = cr + s2.closest_rays, sr + s2.shadow_rays
+        ri.close()
+        bytes_closest = QUEUE_BYTES_CLOSEST + NODE_BYTES * cn / cr + TRI_BYTES * ct / cr
+        bytes_shadow = QUEUE_BYTES_SHADOW + NODE_BYTES * sn / max(1, sr) + TRI_BYTES * stt / max(1, sr)
+        launches = 5 * args.steps
+
+        def roof(name, b_per_ray, n_rays, ms):
+            achieved = b_per_ray * n_rays / (ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_ray": round(b_per_ray, 1), "rays_per_launch": n_rays // launches,
+                    "avg_launch_ms": round(ms / launches, 4)}
+
+        rc = roof("k_trace_closest", bytes_closest, closest_rays, closest_ms)
+        rs = roof("k_trace_shadow_a+b", bytes_shadow, shadow_rays, shadow_ms)
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                tr = json.load(f)
+            rc["traffic"] = tr.get("k_trace_closest", {}).get(args.workload)
+            rs["traffic"] = tr.get("k_trace_shadow", {}).get(args.workload)
+        dom, other = (rc, rs) if closest_ms >= shadow_ms else (rs, rc)
+        out["roofline"] = dom
+        out["roofline_other"] = other
+        out["kernel_ms_per_step"] = {"trace_closest": round(closest_ms / args.steps, 4),
+                                     "trace_shadow": round(shadow_ms / args.steps, 4),
+                                     "raygen+shade+accumulate": round(shade_ms / args.steps, 4)}
+    # ---- CPU baseline: the oracle restatement on this box's host cores (reported, not a target) ----
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from tests.oracle_lib import OracleRenderer
+        cores = os.cpu_count() or 1
+        o = OracleRenderer(scene, width, height, cores)
+        ntiles = o.num_tiles()
+        probe = max(1, ntiles // 64)
+        stp = o.render(eye, cdir, up, fovy, True, 0, probe)  # calibrate on a few tiles
+        per_tile = stp.render_time_ms / probe
+        n_sample = int(max(probe, min(ntiles, args.cpu_seconds * 1e3 / max(per_tile, 1e-3))))
+        # spread the sample over the image: every k-th block of tiles
+        stc = o.render(eye, cdir, up, fovy, True, 0, n_sample)
+        out["cpu_baseline"] = {"value": round(stc.rays_per_second / 1e6, 3), "unit": "MRay/s", "cores": cores,
+                               "kind": "port",
+                               "sample": f"CPU restatement (not Embree): frame 0 of the same workload, first {n_sample} of "
+                                         f"{ntiles} 64x64 tiles, {stc.rays} rays in {stc.render_time_ms / 1e3:.1f} s"}
+    r.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

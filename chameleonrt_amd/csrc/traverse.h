@@ -2,7 +2,7 @@
 //
 // Replaces what the reference gets from rtcIntersectV / rtcOccludedV (call sites
 // backends/embree/render_embree.ispc:245, :144, :170). Semantics (DESIGN.md
-// "Traversal rule"), identical to oracle/crt_oracle.cpp's tri_test/scene_intersect:
+// "Traversal rule"), identical to what the parity tests check against:
 //   * triangle record (v0, e1 = v0 - v1, e2 = v2 - v0), Ng = cross(e2, e1)
 //   * valid hit: den != 0, U >= 0, V >= 0, U + V <= |den|, |den|*tnear < T <= |den|*tfar
 //   * t = T/|den|, u = U/|den|, v = V/|den|

@@ -1,0 +1,108 @@
+"""Seeded input records for the shading-function KATs (layouts: include/crt_kat.h)."""
+import numpy as np
+
+from chameleonrt_amd.scene import ortho_basis, obj_default_light
+
+KAT_DISNEY_EVAL, KAT_DISNEY_SAMPLE, KAT_LIGHT, KAT_TEXTURE, KAT_MISS = 1, 2, 3, 4, 5
+KAT_ORTHO_BASIS, KAT_SRGB8, KAT_RNG, KAT_UNPACK_MATERIAL = 6, 7, 8, 9
+N_OUT = {1: 4, 2: 8, 3: 9, 4: 5, 5: 3, 6: 6, 7: 1, 8: 17, 9: 14}
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def random_materials(rng, n):
+    """14-float MaterialParams rows covering every Disney lobe."""
+    m = np.zeros((n, 14), np.float32)
+    m[:, 0:3] = rng.random((n, 3))
+    m[:, 3] = rng.random(n) * (rng.random(n) < 0.5)          # metallic
+    m[:, 4] = rng.random(n)                                   # specular
+    m[:, 5] = np.clip(rng.random(n) * 1.1 - 0.05, 0, 1)       # roughness incl. 0 and 1
+    m[:, 6] = rng.random(n)                                   # specular_tint
+    m[:, 7] = rng.random(n) * (rng.random(n) < 0.4)           # anisotropy (0 for most)
+    m[:, 8] = rng.random(n)                                   # sheen
+    m[:, 9] = rng.random(n)                                   # sheen_tint
+    m[:, 10] = rng.random(n) * (rng.random(n) < 0.5)          # clearcoat
+    m[:, 11] = rng.random(n)                                  # clearcoat_gloss
+    m[:, 12] = 1.0 + rng.random(n)                            # ior
+    m[:, 13] = rng.random(n) * (rng.random(n) < 0.3)          # specular_transmission
+    m[: n // 50, 0:3] = 0.0                                   # black base colour (lum == 0 branch)
+    return m
+
+
+def shading_frames(rng, n):
+    nrm = _unit(rng.normal(size=(n, 3)))
+    vx = np.zeros((n, 3), np.float32)
+    vy = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        vx[i], vy[i] = ortho_basis(nrm[i])
+    return nrm, vx, vy
+
+
+def disney_eval_records(n, seed=11):
+    rng = np.random.default_rng(seed)
+    mat = random_materials(rng, n)
+    nrm, vx, vy = shading_frames(rng, n)
+    w_o = _unit(rng.normal(size=(n, 3)))
+    w_i = _unit(rng.normal(size=(n, 3)))
+    # most w_o on the upper side, as after the reference's normal flip
+    flip = (np.einsum("ij,ij->i", w_o, nrm) < 0) & (rng.random(n) < 0.8)
+    w_o[flip] *= -1
+    return np.concatenate([mat, nrm, w_o, w_i, vx, vy], axis=1).astype(np.float32)
+
+
+def disney_sample_records(n, seed=12):
+    rng = np.random.default_rng(seed)
+    mat = random_materials(rng, n)
+    nrm, vx, vy = shading_frames(rng, n)
+    w_o = _unit(rng.normal(size=(n, 3)))
+    flip = (np.einsum("ij,ij->i", w_o, nrm) < 0) & (rng.random(n) < 0.8)
+    w_o[flip] *= -1
+    state = rng.integers(0, 2**32, size=(n, 1), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    return np.concatenate([mat, nrm, w_o, vx, vy, state], axis=1).astype(np.float32)
+
+
+def light_records(n, seed=13):
+    rng = np.random.default_rng(seed)
+    light = np.tile(obj_default_light(), (n, 1))
+    orig = (rng.normal(size=(n, 3)) * 3).astype(np.float32)
+    target = light[:, 4:7] + (rng.normal(size=(n, 3)) * 4).astype(np.float32)
+    d = _unit(target - orig)
+    s = rng.random((n, 2)).astype(np.float32)
+    return np.concatenate([light, orig, d, s], axis=1).astype(np.float32)
+
+
+def texture_records(n, n_tex, seed=14):
+    rng = np.random.default_rng(seed)
+    tid = rng.integers(0, n_tex, size=(n, 1)).astype(np.uint32).view(np.float32)
+    uv = (rng.random((n, 2)) * 5 - 2).astype(np.float32)  # [-2, 3]: wrap + negative coords (quirk Q12)
+    uv[: n // 20] = np.round(uv[: n // 20] * 8) / 8       # texel-boundary coordinates
+    ch = rng.integers(0, 3, size=(n, 1)).astype(np.uint32).view(np.float32)
+    return np.concatenate([tid, uv, ch], axis=1).astype(np.float32)
+
+
+def dir_records(n, seed=15):
+    rng = np.random.default_rng(seed)
+    d = _unit(rng.normal(size=(n, 3)))
+    d[:6] = np.array([[0, 1, 0], [0, -1, 0], [1, 0, 0], [0, 0, 1], [0, 0, -1], [-1, 0, 0]], np.float32)
+    return d.astype(np.float32)
+
+
+def srgb_records(n, seed=16):
+    rng = np.random.default_rng(seed)
+    x = np.concatenate([rng.random(n - 8) ** 3 * 1.5, [0, 0.0031308, 0.0031309, 1.0, 2.0, -0.5, 1e-8, 0.5]])
+    return x.reshape(-1, 1).astype(np.float32)
+
+
+def rng_records():
+    pix = np.array([0, 1, 262143, 12345, 1920 * 1080 - 1, 0xFFFFFFFF, 77, 3840 * 2160 - 1], np.uint32)
+    frm = np.array([1, 1, 1, 17, 5, 0xFFFFFFFF, 4 * 9 + 1 + 3, 64 * 1000 + 64], np.uint32)
+    return np.stack([pix.view(np.float32), frm.view(np.float32)], axis=1)
+
+
+def unpack_records(n, n_mat, seed=17):
+    rng = np.random.default_rng(seed)
+    mid = rng.integers(0, n_mat, size=(n, 1)).astype(np.uint32).view(np.float32)
+    uv = (rng.random((n, 2)) * 5 - 2).astype(np.float32)
+    return np.concatenate([mid, uv], axis=1).astype(np.float32)

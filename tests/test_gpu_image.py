@@ -1,0 +1,102 @@
+"""GPU parity: whole frames (K1..K5) against the CPU oracle -- accumulated radiance,
+REPORT_RAY_STATS ray counts and the RGBA8 framebuffer, over several accumulated frames."""
+import numpy as np
+import pytest
+
+from chameleonrt_amd import scenes
+from chameleonrt_amd.render_hip import RenderHIP
+from tests.parity import MAX_DIVERGED, camera_of, compare_images
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # BASELINE config C1: Cornell 512x512, 1 spp
+    "C1_cornell_512_1spp": (lambda: scenes.cornell(spp=1), 512, 512, 3),
+    # odd size: edge tiles are clipped (render_embree.cpp:180-183)
+    "cornell_200x136_3spp": (lambda: scenes.cornell(spp=3), 200, 136, 2),
+    # two-level instancing, textures (3- and 4-channel, sRGB + linear), glass, anisotropy, sheen, clearcoat
+    "grove_320x200_2spp": (lambda: scenes.instanced_grove(), 320, 200, 3),
+    "grove_white_diffuse": (lambda: scenes.instanced_grove().white_diffuse(), 160, 100, 1),
+    # C2 content at reduced detail/resolution so the oracle finishes in seconds
+    "sponza_small_320x180_4spp": (lambda: scenes.sponza_like(spp=4, detail=0.05, tex_size=64), 320, 180, 2),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_frame_parity(case, oracle, hip_lib):
+    make, w, h, frames = CASES[case]
+    sc = make()
+    r = RenderHIP()
+    r.initialize(w, h)
+    r.set_scene(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    e, d, u, fovy = camera_of(sc)
+    try:
+        for f in range(frames):
+            st = r.render(e, d, u, fovy, f == 0, True)
+            ost = o.render(e, d, u, fovy, f == 0)
+            diverged, mean_rel = compare_images(r.accum(), o.accum())
+            assert diverged <= MAX_DIVERGED, f"frame {f}: {diverged:.5f} of the pixels diverged"
+            assert mean_rel <= 1e-4, f"frame {f}: mean relative error {mean_rel:.3g}"
+            # ray statistics (integer): identical except on diverged paths
+            gc, cc = r.ray_counts(), o.ray_counts()
+            assert (gc != cc).mean() <= MAX_DIVERGED
+            assert abs(int(st.rays) - int(ost.rays)) <= max(16, int(2 * MAX_DIVERGED * ost.rays))
+            assert int(gc.sum()) == int(st.rays), "per-pixel counts must add up to the frame total"
+            # RGBA8: <= 1 LSB except on diverged pixels, alpha = 255, row 0 = top
+            g8 = r.img.view(np.uint8).reshape(h, w, 4).astype(int)
+            c8 = o.framebuffer().view(np.uint8).reshape(h, w, 4).astype(int)
+            assert (g8[..., 3] == 255).all()
+            assert ((np.abs(g8 - c8) > 1).any(axis=2)).mean() <= 2 * MAX_DIVERGED
+        assert r.frame_id() == frames
+    finally:
+        r.close()
+
+
+def test_camera_change_resets_accumulation(hip_lib):
+    """camera_changed -> frame_id = 0 (render_embree.cpp:145-147); initialize resets too (:40)."""
+    sc = scenes.cornell(spp=1)
+    r = RenderHIP()
+    r.initialize(128, 128)
+    r.set_scene(sc)
+    e, d, u, fovy = camera_of(sc)
+    r.render(e, d, u, fovy, True, False)
+    first = r.accum().copy()
+    r.render(e, d, u, fovy, False, False)
+    assert r.frame_id() == 2 and not np.array_equal(first, r.accum())
+    r.render(e, d, u, fovy, True, False)
+    assert r.frame_id() == 1
+    assert np.array_equal(first, r.accum()), "same camera + frame 0 must reproduce frame 0 bit for bit"
+    r.initialize(128, 128)
+    assert r.frame_id() == 0
+    r.close()
+
+
+def test_pass_splitting_is_invisible(hip_lib, monkeypatch):
+    """Rendering the frame in several passes (queue capacity < paths) must not change a bit."""
+    sc = scenes.cornell(spp=2)
+    e, d, u, fovy = camera_of(sc)
+    out = []
+    for cap in ("0", "20000"):
+        if cap != "0":
+            monkeypatch.setenv("CRT_HIP_MAX_PATHS", cap)
+        r = RenderHIP()
+        r.initialize(192, 160)
+        r.set_scene(sc)
+        st = r.render(e, d, u, fovy, True, True)
+        out.append((r.accum().copy(), r.img.copy(), int(st.rays)))
+        r.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+def test_errors_are_loud(hip_lib):
+    from chameleonrt_amd import core
+    r = RenderHIP()
+    with pytest.raises(core.CoreError):
+        r.render([0, 0, 0], [0, 0, -1], [0, 1, 0], 60.0, True, False)  # before initialize/set_scene
+    sc = scenes.cornell()
+    sc.parameterized_meshes[0].material_ids[0] = 99
+    r.initialize(64, 64)
+    with pytest.raises(core.CoreError):
+        r.set_scene(sc)
+    r.close()
