@@ -42,6 +42,19 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def wrap_device_buffer(ptr, nbytes):
     """Zero-copy torch view of the core's compact tile buffer (plumbing for the collective)."""
     import torch
@@ -186,7 +199,7 @@ def main():
     # ---- CPU baseline: the oracle restatement on this box's host cores (reported, not a target) ----
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from tests.oracle_lib import OracleRenderer
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         o = OracleRenderer(scene, width, height, cores)
         ntiles = o.num_tiles()
         probe = max(1, ntiles // 64)

@@ -54,6 +54,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CoreError(f"{LIB_PATH} not found: build it with `python -m chameleonrt_amd.build` "
                         "(there is no CPU fallback for the render path)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and this
+    # library links the system one with the same SONAME. Whichever is loaded first serves both,
+    # and torch only works on top of its own copy -- so when torch is installed, let it load first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     fp, u32p, i32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p
     L.crt_hip_abi_version.restype = C.c_int

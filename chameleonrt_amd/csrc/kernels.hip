@@ -372,6 +372,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                     }
                 }
                 L.w += has_b ? 2.f : 1.f; // the occlusion rays (ispc:145-147, 171-173)
+                // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
+                // non-finite throughput (the reference's glass pdfs can be negative or overflow)
+                // turns the pixel into NaN there, so it must here too. +0 for every finite path.
+                const V3 poison = tp_in * 0.f;
+                L.x = L.x + poison.x;
+                L.y = L.y + poison.y;
+                L.z = L.z + poison.z;
 
                 // -- continue the path, ispc:313-335 --
                 float pdf;

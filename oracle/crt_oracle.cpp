@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -1207,6 +1208,9 @@ bool scene_occluded(const orc_scene &sc, f3 o, f3 d, float tnear, float tfar, bo
     return occluded;
 }
 
+static thread_local bool g_debug = false; // orc_debug_pixel
+#define DBG(...) do { if (g_debug) { std::fprintf(stderr, __VA_ARGS__); } } while (0)
+
 // render_embree.ispc:66-77
 inline float textured_scalar_param(float x, f2 uv, const std::vector<Tex> &textures)
 {
@@ -1265,6 +1269,7 @@ f3 sample_direct_light(const orc_scene &sc, const Material &mat, f3 hit_p, f3 n,
         const float light_pdf = quad_light_pdf(light, light_pos, hit_p, light_dir);
         const float bsdf_pdf = disney_pdf(mat, n, w_o, light_dir, v_x, v_y);
         const bool occluded = scene_occluded(sc, hit_p, light_dir, EPS, light_dist, false, ctr);
+        DBG("   neeA light_pdf %.9g bsdf_pdf %.9g occ %d\n", light_pdf, bsdf_pdf, (int)occluded);
         ++ray_stats;
         if (light_pdf >= EPS && bsdf_pdf >= EPS && !occluded) {
             const f3 bsdf = disney_brdf(mat, n, w_o, light_dir, v_x, v_y);
@@ -1276,6 +1281,7 @@ f3 sample_direct_light(const orc_scene &sc, const Material &mat, f3 hit_p, f3 n,
         f3 w_i;
         float bsdf_pdf;
         const f3 bsdf = sample_disney_brdf(mat, n, w_o, v_x, v_y, rng, w_i, bsdf_pdf);
+        DBG("   neeA illum (%.9g %.9g %.9g); neeB w_i (%.9g %.9g %.9g) pdf %.9g bsdf (%.9g %.9g %.9g)\n", illum.x, illum.y, illum.z, w_i.x, w_i.y, w_i.z, bsdf_pdf, bsdf.x, bsdf.y, bsdf.z);
         float light_dist;
         f3 light_pos;
         if (!all_zero(bsdf) && bsdf_pdf >= EPS && quad_intersect(light, hit_p, w_i, light_dist, light_pos)) {
@@ -1347,6 +1353,8 @@ f3 trace_pixel(const orc_scene &sc, const ViewParams &vp, uint32_t px, uint32_t 
                                        m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
             }
             unpack_material(mat, sc.materials[inst.material_ids[hit.geom]], sc.textures, uv);
+            DBG("s%u b%d hit inst %d geom %d prim %d t %.9g n (%.9g %.9g %.9g) tp (%.9g %.9g %.9g) illum (%.9g %.9g %.9g)\n", s, bounce, hit.inst, hit.geom, hit.prim, hit.t, normal.x, normal.y, normal.z, path_throughput.x, path_throughput.y, path_throughput.z, illum.x, illum.y, illum.z);
+            DBG("   mat bc (%.9g %.9g %.9g) met %.9g spec %.9g rough %.9g aniso %.9g cc %.9g ior %.9g trans %.9g\n", mat.base_color.x, mat.base_color.y, mat.base_color.z, mat.metallic, mat.specular, mat.roughness, mat.anisotropy, mat.clearcoat, mat.ior, mat.specular_transmission);
             f3 v_x, v_y;
             if (mat.specular_transmission == 0.f && dot(w_o, normal) < 0.f) {
                 normal = neg(normal);
@@ -1356,7 +1364,9 @@ f3 trace_pixel(const orc_scene &sc, const ViewParams &vp, uint32_t px, uint32_t 
                                                                   ray_stats, rng, ctr);
             float pdf;
             f3 w_i;
+            DBG("   after nee illum (%.9g %.9g %.9g)\n", illum.x, illum.y, illum.z);
             const f3 bsdf = sample_disney_brdf(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
+            DBG("   cont w_i (%.9g %.9g %.9g) pdf %.9g bsdf (%.9g %.9g %.9g)\n", w_i.x, w_i.y, w_i.z, pdf, bsdf.x, bsdf.y, bsdf.z);
             if (pdf == 0.f || all_zero(bsdf)) {
                 break;
             }
@@ -1622,6 +1632,28 @@ extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir_[
         stats->tris_tested = total_tris;
     }
     ++r->frame_id;
+    return 0;
+}
+
+extern "C" int orc_debug_pixel(orc_renderer *r, const float pos[3], const float dir_[3], const float up_[3],
+                               float fovy, uint32_t frame_id, int x, int y)
+{
+    const f3 dir = mk3(dir_[0], dir_[1], dir_[2]), up = mk3(up_[0], up_[1], up_[2]);
+    const float plane_y = 2.f * std::tan(0.5f * fovy * 0.01745329251994329576923690768489f);
+    const float plane_x = plane_y * (float)r->w / (float)r->h;
+    ViewParams vp;
+    vp.pos = mk3(pos[0], pos[1], pos[2]);
+    vp.dir_du = normalize(cross(dir, up)) * plane_x;
+    vp.dir_dv = neg(normalize(cross(vp.dir_du, dir))) * plane_y;
+    vp.dir_top_left = dir - 0.5f * vp.dir_du - 0.5f * vp.dir_dv;
+    vp.frame_id = frame_id;
+    uint32_t count = 0;
+    uint64_t closest = 0;
+    TraceCounters ctr;
+    g_debug = true;
+    const f3 illum = trace_pixel(*r->scene, vp, x, y, r->w, r->h, count, closest, ctr);
+    g_debug = false;
+    std::fprintf(stderr, "pixel (%d,%d): illum (%.9g %.9g %.9g) rays %u\n", x, y, illum.x, illum.y, illum.z, count);
     return 0;
 }
 

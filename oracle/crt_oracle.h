@@ -49,6 +49,9 @@ int orc_render(orc_renderer *r, const float pos[3], const float dir[3], const fl
                orc_stats *stats);
 const uint32_t *orc_framebuffer(const orc_renderer *r);
 int orc_read_accum(const orc_renderer *r, float *rgb /* W*H*3 row-major */);
+/* Debug aid: re-trace one pixel of frame `frame_id` printing the per-bounce state to stderr. */
+int orc_debug_pixel(orc_renderer *r, const float pos[3], const float dir[3], const float up[3], float fovy_deg,
+                    uint32_t frame_id, int x, int y);
 int orc_read_ray_counts(const orc_renderer *r, uint32_t *counts /* W*H */);
 int orc_num_tiles(const orc_renderer *r);
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_render_equals_single(world, hip_lib):
-    import torch
+    hip = C.CDLL("libamdhip64.so")  # resolves to the runtime the core already uses
     sc = scenes.instanced_grove()
     w, h = 300, 200  # 5 x 4 tiles, clipped edges, tile count not divisible by 3
     e, d, u, fovy = camera_of(sc)
@@ -38,15 +38,16 @@ def test_partitioned_render_equals_single(world, hip_lib):
     assert np.array_equal(np.nan_to_num(ref.accum()), acc)
     # gather the compact RGBA8 tile buffers as RCCL would (here: device-to-device copies) and un-permute
     _, nbytes = ranks[0].tile_buffer()
-    gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
-    hip = C.CDLL("libamdhip64.so")
+    gathered = C.c_void_p()
+    assert hip.hipMalloc(C.byref(gathered), C.c_size_t(world * nbytes)) == 0
     for k, r in enumerate(ranks):
         ptr, nb = r.tile_buffer()
         assert nb == nbytes
-        rc = hip.hipMemcpy(C.c_void_p(gathered.data_ptr() + k * nbytes), C.c_void_p(ptr), C.c_size_t(nbytes), 3)
+        rc = hip.hipMemcpy(C.c_void_p(gathered.value + k * nbytes), C.c_void_p(ptr), C.c_size_t(nbytes), 3)
         assert rc == 0
-    torch.cuda.synchronize()
-    ranks[0].assemble_tiles(gathered.data_ptr(), world, readback=True)
+    assert hip.hipDeviceSynchronize() == 0
+    ranks[0].assemble_tiles(gathered.value, world, readback=True)
     assert np.array_equal(ranks[0].img, ref.img)
+    hip.hipFree(gathered)
     for r in ranks + [ref]:
         r.close()
