@@ -12,7 +12,8 @@ import numpy as np
 from .scene import SceneDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_hip_core.so")
+# CRT_HIP_LIB selects a tuning-variant build of the same library (tools/variants.py)
+LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(_HERE, "libcrt_hip_core.so")
 
 FLAG_COUNTERS = 1
 FLAG_TIMING = 2

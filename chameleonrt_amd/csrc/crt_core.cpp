@@ -152,7 +152,10 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
     return Vec3{v.x * c, v.y * c, v.z * c};
 }
 
-constexpr int MAX_TOP_NODES_HOST = 255; // must match kernels.hip MAX_TOP_NODES
+#ifndef CRT_MAX_TOP_NODES
+#define CRT_MAX_TOP_NODES 127
+#endif
+constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // same macro as kernels.hip
 constexpr uint32_t MAX_TRAVERSAL_DEPTH = 60;
 
 } // namespace

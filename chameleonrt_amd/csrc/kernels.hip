@@ -25,8 +25,20 @@
 
 namespace crt {
 
-constexpr int TRACE_BLOCK = 256;   // 4 waves
-constexpr int MAX_TOP_NODES = 255; // top 8 levels of the BVH staged in LDS (16 KB)
+#ifndef CRT_TRACE_BLOCK
+#define CRT_TRACE_BLOCK 256
+#endif
+#ifndef CRT_MAX_TOP_NODES
+#define CRT_MAX_TOP_NODES 127
+#endif
+#ifndef CRT_FETCH
+#define CRT_FETCH 64
+#endif
+#ifndef CRT_TRACE_BLOCKS_PER_CU
+#define CRT_TRACE_BLOCKS_PER_CU 8
+#endif
+constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
+constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each)
 constexpr int SHADE_BLOCK = 256;
 
 // ---- wave-level helpers (wave64) -------------------------------------------------------------
@@ -52,14 +64,33 @@ CRT_DEV uint32_t wave_append(uint32_t *counter, bool pred)
     base = __shfl(base, leader);
     return base + rank;
 }
-// A wave grabs the next 64-element packet of a queue of n elements.
+// A wave grabs the next FETCH-element packet of a queue (FETCH/64 rounds of 64 rays). One
+// returning atomic on a single word sustains only ~88 ops/us on MI355X (MI355X_MICROARCH.md,
+// "dequeue"), so a packet must be large enough that fetching is off the critical path.
+constexpr uint32_t FETCH = CRT_FETCH;
 CRT_DEV uint32_t wave_fetch(uint32_t *cursor)
 {
     uint32_t base = 0;
     if (lane_id() == 0) {
-        base = atomicAdd(cursor, 64u);
+        base = atomicAdd(cursor, FETCH);
     }
     return __builtin_amdgcn_readfirstlane(base);
+}
+// Same compaction as wave_append but on an LDS counter (cheap, no memory-side atomic).
+CRT_DEV uint32_t wave_append_lds(uint32_t *lds_counter, bool pred)
+{
+    const uint64_t mask = __ballot(pred);
+    if (mask == 0) {
+        return 0;
+    }
+    const uint32_t rank = lanes_below(mask);
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) {
+        base = atomicAdd(lds_counter, (uint32_t)__popcll(mask));
+    }
+    base = __shfl(base, leader);
+    return base + rank;
 }
 
 // pixel slot -> pixel. Slots are tile-major over this GPU's tiles; inside a 64x64 tile they
@@ -86,21 +117,64 @@ CRT_DEV bool slot_to_pixel(const ViewParams &vp, const uint32_t *tile_ids, uint3
 }
 
 // ---- K1 raygen: render_embree.ispc:213-232 ------------------------------------------------------
+// Each block owns one contiguous chunk of paths: it counts the chunk's on-image pixel-samples,
+// reserves their queue slots with ONE atomic, then writes them in path order (edge tiles are
+// clipped, render_embree.cpp:180-183, so not every slot of a 64x64 tile is a pixel).
 __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uint32_t *tile_ids,
-                                                        uint32_t slot0, uint32_t n_paths, PathQueue q,
-                                                        float4 *radiance, PassCounters *pc)
+                                                        uint32_t slot0, uint32_t n_paths, uint32_t chunk,
+                                                        PathQueue q, float4 *radiance, PassCounters *pc)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n_paths; base += stride) {
+    __shared__ uint32_t s_wave[SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t begin = blockIdx.x * chunk;
+    const uint32_t end = min(begin + chunk, n_paths);
+    const uint32_t wave = threadIdx.x / 64;
+    uint32_t x, y, ix, iy;
+    // phase 1: count
+    uint32_t mine = 0;
+    for (uint32_t p = begin + threadIdx.x; p < end; p += SHADE_BLOCK) {
+        mine += slot_to_pixel(vp, tile_ids, slot0 + p / vp.spp, x, y, ix, iy) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mine += __shfl_down(mine, off);
+    }
+    if (lane_id() == 0) {
+        s_wave[wave] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w) {
+            total += s_wave[w];
+        }
+        s_base = total ? atomicAdd(&pc->n_queue[0], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t running = s_base;
+    // phase 2: emit
+    for (uint32_t base = begin; base < end; base += SHADE_BLOCK) {
         const uint32_t p = base + threadIdx.x;
-        bool valid = p < n_paths;
-        uint32_t x = 0, y = 0, ix, iy, s = 0;
+        bool valid = p < end;
+        uint32_t s = 0;
+        x = y = 0;
         if (valid) {
             s = p % vp.spp;
             valid = slot_to_pixel(vp, tile_ids, slot0 + p / vp.spp, x, y, ix, iy);
             radiance[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const uint32_t slot = wave_append(&pc->n_queue[0], valid);
+        const uint64_t mask = __ballot(valid);
+        __syncthreads(); // s_wave is reused
+        if (lane_id() == 0) {
+            s_wave[wave] = (uint32_t)__popcll(mask);
+        }
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < SHADE_BLOCK / 64; ++w) {
+            before += w < wave ? s_wave[w] : 0u;
+            total += s_wave[w];
+        }
+        const uint32_t slot = running + before + lanes_below(mask);
+        running += total;
         if (valid) {
             // quirk Q1: the Embree backend keys the RNG with frame_id * spp + 1 + s
             uint32_t rng = rng_seed(x + y * vp.fb_width, vp.frame_id * vp.spp + 1u + s);
@@ -158,11 +232,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
     for (;;) {
-        const uint32_t base = wave_fetch(&pc->cur_closest[bounce]);
-        if (base >= n) {
+        const uint32_t packet = wave_fetch(&pc->cur_closest[bounce]);
+        if (packet >= n) {
             break;
         }
-        const uint32_t i = base + lane_id();
+        for (uint32_t round = 0; round < FETCH / 64; ++round) {
+        const uint32_t i = packet + round * 64 + lane_id();
         if (i < n) {
             const V3 o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
             const V3 d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
@@ -173,6 +248,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
             hits.v[i] = h.v;
             hits.tri[i] = h.tri;
             hits.inst[i] = h.inst;
+        }
         }
     }
     if (COUNTERS) {
@@ -194,11 +270,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, Sh
     const uint32_t n = pc->n_shadow_a[bounce];
     uint32_t n_nodes = 0, n_tris = 0;
     for (;;) {
-        const uint32_t base = wave_fetch(&pc->cur_shadow_a[bounce]);
-        if (base >= n) {
+        const uint32_t packet = wave_fetch(&pc->cur_shadow_a[bounce]);
+        if (packet >= n) {
             break;
         }
-        const uint32_t i = base + lane_id();
+        for (uint32_t round = 0; round < FETCH / 64; ++round) {
+        const uint32_t i = packet + round * 64 + lane_id();
         if (i < n) {
             const V3 o = v3(sa.o[0][i], sa.o[1][i], sa.o[2][i]);
             const V3 d = v3(sa.d[0][i], sa.d[1][i], sa.d[2][i]);
@@ -217,6 +294,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, Sh
                 L.z = L.z + sa.c[2][i];
                 radiance[p] = L;
             }
+        }
         }
     }
     if (COUNTERS) {
@@ -238,11 +316,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, Sh
     const uint32_t n = pc->n_shadow_b[bounce];
     uint32_t n_nodes = 0, n_tris = 0;
     for (;;) {
-        const uint32_t base = wave_fetch(&pc->cur_shadow_b[bounce]);
-        if (base >= n) {
+        const uint32_t packet = wave_fetch(&pc->cur_shadow_b[bounce]);
+        if (packet >= n) {
             break;
         }
-        const uint32_t i = base + lane_id();
+        for (uint32_t round = 0; round < FETCH / 64; ++round) {
+        const uint32_t i = packet + round * 64 + lane_id();
         if (i < n) {
             const V3 o = v3(sb.o[0][i], sb.o[1][i], sb.o[2][i]);
             const V3 d = v3(sb.d[0][i], sb.d[1][i], sb.d[2][i]);
@@ -264,6 +343,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, Sh
             L.z = L.z + add.z;
             radiance[p] = L;
         }
+        }
     }
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
@@ -272,10 +352,68 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, Sh
 }
 
 // ---- K3 shade: render_embree.ispc:251-335 + sample_direct_light :105-181 -----------------------
+// Output compaction. Survivors are first appended to an LDS staging buffer (wave ballot +
+// LDS atomic); whenever a buffer holds a full block's worth, SHADE_BLOCK entries leave for HBM
+// with ONE memory-side atomic and fully coalesced 1-KiB-per-wave stores. This keeps the queue
+// counters (a single word each) far below their ~88 atomics/us ceiling.
+constexpr int STAGE_CAP = 2 * SHADE_BLOCK;
+struct ShadeStage {
+    uint32_t next[11][STAGE_CAP]; // PathQueue fields in declaration order
+    uint32_t a[12][STAGE_CAP];    // ShadowQueueA fields in declaration order
+    uint32_t n_next, n_a, base;
+};
+static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 12 * sizeof(void *),
+              "queue structs are arrays of field pointers");
+
+// Block-wide: while the staging buffer holds at least `threshold` entries, move up to
+// SHADE_BLOCK of them to the global SoA queue. Must be called by every thread of the block.
+template <int NF>
+CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &base_slot, uint32_t *global_counter,
+                         uint32_t *const *fields, uint32_t threshold)
+{
+    uint32_t n = count; // uniform: read after a barrier
+    if (n < threshold || n == 0) {
+        return;
+    }
+    const uint32_t take = min(n, (uint32_t)SHADE_BLOCK);
+    if (threadIdx.x == 0) {
+        base_slot = atomicAdd(global_counter, take);
+    }
+    __syncthreads();
+    const uint32_t base = base_slot;
+    const uint32_t t = threadIdx.x;
+    uint32_t keep[NF];
+    const bool mover = take + t < n; // entries beyond `take` slide down to the front
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        if (t < take) {
+            fields[k][base + t] = buf[k][t];
+        }
+        keep[k] = mover ? buf[k][take + t] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        if (mover) {
+            buf[k][t] = keep[k];
+        }
+    }
+    if (t == 0) {
+        count = n - take;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
                                                        PassCounters *pc, int bounce)
 {
+    __shared__ ShadeStage stage;
+    if (threadIdx.x == 0) {
+        stage.n_next = 0;
+        stage.n_a = 0;
+    }
+    __syncthreads();
     const uint32_t n = pc->n_queue[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
@@ -401,10 +539,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
             }
             radiance[path] = L;
         }
-        // compaction: B slots first (A entries point at them)
+        // ---- compaction -------------------------------------------------------------------
+        // B rays are rare: straight to HBM with one atomic per wave that has any.
         const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce], has_b);
-        const uint32_t slot_a = wave_append(&pc->n_shadow_a[bounce], is_hit);
-        const uint32_t slot_n = wave_append(&pc->n_queue[bounce + 1], alive);
         if (has_b) {
             sb.o[0][slot_b] = hit_p.x;
             sb.o[1][slot_b] = hit_p.y;
@@ -425,35 +562,47 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
             sb.path[slot_b] = path;
             sb.vis_a[slot_b] = 0;
         }
+        // A rays and continuation rays go through the LDS staging buffers
+        const uint32_t la = wave_append_lds(&stage.n_a, is_hit);
+        const uint32_t ln = wave_append_lds(&stage.n_next, alive);
         if (is_hit) {
             const V3 c = tp_in * c_a;
-            sa.o[0][slot_a] = hit_p.x;
-            sa.o[1][slot_a] = hit_p.y;
-            sa.o[2][slot_a] = hit_p.z;
-            sa.d[0][slot_a] = light_dir.x;
-            sa.d[1][slot_a] = light_dir.y;
-            sa.d[2][slot_a] = light_dir.z;
-            sa.tmax[slot_a] = light_dist;
-            sa.c[0][slot_a] = c.x;
-            sa.c[1][slot_a] = c.y;
-            sa.c[2][slot_a] = c.z;
-            sa.path[slot_a] = path;
-            sa.bslot[slot_a] = has_b ? (int32_t)slot_b : -1;
+            stage.a[0][la] = __float_as_uint(hit_p.x);
+            stage.a[1][la] = __float_as_uint(hit_p.y);
+            stage.a[2][la] = __float_as_uint(hit_p.z);
+            stage.a[3][la] = __float_as_uint(light_dir.x);
+            stage.a[4][la] = __float_as_uint(light_dir.y);
+            stage.a[5][la] = __float_as_uint(light_dir.z);
+            stage.a[6][la] = __float_as_uint(light_dist);
+            stage.a[7][la] = __float_as_uint(c.x);
+            stage.a[8][la] = __float_as_uint(c.y);
+            stage.a[9][la] = __float_as_uint(c.z);
+            stage.a[10][la] = path;
+            stage.a[11][la] = has_b ? slot_b : 0xffffffffu;
         }
         if (alive) {
-            qout.o[0][slot_n] = hit_p.x;
-            qout.o[1][slot_n] = hit_p.y;
-            qout.o[2][slot_n] = hit_p.z;
-            qout.d[0][slot_n] = w_i.x;
-            qout.d[1][slot_n] = w_i.y;
-            qout.d[2][slot_n] = w_i.z;
-            qout.path[slot_n] = path;
-            qout.rng[slot_n] = rng;
-            qout.tp[0][slot_n] = tp.x;
-            qout.tp[1][slot_n] = tp.y;
-            qout.tp[2][slot_n] = tp.z;
+            stage.next[0][ln] = __float_as_uint(hit_p.x);
+            stage.next[1][ln] = __float_as_uint(hit_p.y);
+            stage.next[2][ln] = __float_as_uint(hit_p.z);
+            stage.next[3][ln] = __float_as_uint(w_i.x);
+            stage.next[4][ln] = __float_as_uint(w_i.y);
+            stage.next[5][ln] = __float_as_uint(w_i.z);
+            stage.next[6][ln] = path;
+            stage.next[7][ln] = rng;
+            stage.next[8][ln] = __float_as_uint(tp.x);
+            stage.next[9][ln] = __float_as_uint(tp.y);
+            stage.next[10][ln] = __float_as_uint(tp.z);
         }
+        __syncthreads();
+        flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa),
+                        SHADE_BLOCK);
+        flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
+                        reinterpret_cast<uint32_t *const *>(&qout), SHADE_BLOCK);
     }
+    // drain what is left (fewer than SHADE_BLOCK entries per queue)
+    flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa), 1);
+    flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
+                    reinterpret_cast<uint32_t *const *>(&qout), 1);
 }
 
 // ---- K5 accumulate: render_embree.ispc:339-353 + tile_to_uint8 :358-370 ------------------------
@@ -675,8 +824,12 @@ static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)
 void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
                    uint32_t n_paths, PathQueue q, float4 *radiance, PassCounters *pc)
 {
-    k_raygen<<<capped_grid(cfg, n_paths, SHADE_BLOCK), SHADE_BLOCK, 0, cfg.stream>>>(vp, tile_ids, slot0, n_paths, q,
-                                                                                      radiance, pc);
+    // one contiguous chunk per block, a multiple of the block size
+    const uint32_t blocks = (uint32_t)capped_grid(cfg, n_paths, SHADE_BLOCK);
+    uint32_t chunk = (n_paths + blocks - 1) / blocks;
+    chunk = (chunk + SHADE_BLOCK - 1) / SHADE_BLOCK * SHADE_BLOCK;
+    const uint32_t grid = (n_paths + chunk - 1) / chunk;
+    k_raygen<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(vp, tile_ids, slot0, n_paths, chunk, q, radiance, pc);
 }
 
 template <typename... Args> static void launch4(bool two_level, bool counters, void (*k00)(Args...),
@@ -691,7 +844,7 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
                           int bounce)
 {
     launch4(sc.two_level != 0, cfg.counters, k_trace_closest<false, false>, k_trace_closest<false, true>,
-            k_trace_closest<true, false>, k_trace_closest<true, true>, persistent_grid(cfg, 4), cfg.stream, sc, q,
+            k_trace_closest<true, false>, k_trace_closest<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, q,
             hits, pc, bounce);
 }
 
@@ -699,7 +852,7 @@ void launch_trace_shadow_a(const LaunchCfg &cfg, const SceneView &sc, ShadowQueu
                            float4 *radiance, PassCounters *pc, int bounce)
 {
     launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_a<false, false>, k_trace_shadow_a<false, true>,
-            k_trace_shadow_a<true, false>, k_trace_shadow_a<true, true>, persistent_grid(cfg, 4), cfg.stream, sc, sa,
+            k_trace_shadow_a<true, false>, k_trace_shadow_a<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa,
             sb, radiance, pc, bounce);
 }
 

@@ -17,8 +17,11 @@
 
 namespace crt {
 
-constexpr int LDS_STACK = 16;      // per-lane stack entries kept in LDS
-constexpr int SCRATCH_STACK = 48;  // overflow entries in private memory
+#ifndef CRT_LDS_STACK
+#define CRT_LDS_STACK 8
+#endif
+constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
+constexpr int SCRATCH_STACK = 56;  // overflow entries in private memory (LDS_STACK + this = 64)
 constexpr int32_t STACK_SENTINEL = (int32_t)0x80000000; // marks "leave instance" (two-level)
 
 struct RayHit {

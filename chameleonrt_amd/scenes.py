@@ -277,9 +277,9 @@ def _heightfield(rng, n):
     return np.floor(h).astype(np.int32)
 
 
-def rungholt_like(spp: int = 8, seed: int = 3, n: int = 1160, n_mats: int = 64) -> Scene:
+def rungholt_like(spp: int = 8, seed: int = 3, n: int = 1320, n_mats: int = 64) -> Scene:
     """S3: voxel height-field city: one quad per cell top + one quad per unit of exposed side
-    height. n=1160 gives ~6.7 M triangles; 64 flat materials, no textures."""
+    height. n=1320 gives ~6.7 M triangles; 64 flat materials, no textures."""
     rng = np.random.default_rng(seed)
     h = _heightfield(rng, n)
     cell = 0.25
