@@ -1,0 +1,280 @@
+// render_hip.cpp — RenderHIP: adapts the reference's RenderBackend interface
+// (util/render_backend.h:12-32) to the C-ABI of include/crt_hip.h.
+#include "render_hip.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <stdexcept>
+
+#include "crt_hip.h"
+
+namespace {
+
+int requested_devices()
+{
+    int want = 1;
+    if (const char *s = std::getenv("CRT_HIP_DEVICES")) {
+        want = std::atoi(s);
+    }
+    const int have = crt_hip_device_count();
+    if (have < 1) {
+        throw std::runtime_error("RenderHIP: no HIP device (this backend has no CPU fallback)");
+    }
+    return want < 1 ? 1 : (want > have ? have : want);
+}
+
+void hip_ok(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        throw std::runtime_error(std::string("RenderHIP: ") + what + ": " + hipGetErrorString(e));
+    }
+}
+void nccl_ok(ncclResult_t r, const char *what)
+{
+    if (r != ncclSuccess) {
+        throw std::runtime_error(std::string("RenderHIP: ") + what + ": " + ncclGetErrorString(r));
+    }
+}
+
+} // namespace
+
+struct RenderHIP::MultiGpu {
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    void *gathered = nullptr; // on device 0: world consecutive tile slabs
+    size_t slab_bytes = 0;
+
+    explicit MultiGpu(int n)
+    {
+        std::vector<int> devs(n);
+        for (int i = 0; i < n; ++i) {
+            devs[i] = i;
+        }
+        comms.resize(n);
+        nccl_ok(ncclCommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll");
+        streams.resize(n);
+        for (int i = 0; i < n; ++i) {
+            hip_ok(hipSetDevice(i), "hipSetDevice");
+            hip_ok(hipStreamCreate(&streams[i]), "hipStreamCreate");
+        }
+    }
+    ~MultiGpu()
+    {
+        for (size_t i = 0; i < comms.size(); ++i) {
+            (void)hipSetDevice((int)i);
+            (void)hipStreamDestroy(streams[i]);
+            ncclCommDestroy(comms[i]);
+        }
+        if (gathered) {
+            (void)hipSetDevice(0);
+            (void)hipFree(gathered);
+        }
+    }
+};
+
+RenderHIP::RenderHIP()
+{
+    const int n = requested_devices();
+    if (n > 1) {
+        multi = std::make_unique<MultiGpu>(n);
+    }
+    for (int d = 0; d < n; ++d) {
+        crt_hip_ctx *c = crt_hip_create(d, CRT_HIP_FLAG_NONE);
+        if (!c) {
+            throw std::runtime_error(std::string("RenderHIP: ") + crt_hip_last_error(nullptr));
+        }
+        ctxs.push_back(c);
+        if (n > 1) {
+            check(c, crt_hip_set_partition(c, d, n), "crt_hip_set_partition");
+            check(c, crt_hip_set_stream(c, multi->streams[d]), "crt_hip_set_stream");
+        }
+    }
+}
+
+RenderHIP::~RenderHIP()
+{
+    for (crt_hip_ctx *c : ctxs) {
+        crt_hip_destroy(c);
+    }
+}
+
+void RenderHIP::check(crt_hip_ctx *ctx, int rc, const char *what) const
+{
+    if (rc != CRT_HIP_OK) { // the reference reports errors as exceptions
+        throw std::runtime_error(std::string("RenderHIP: ") + what + ": " + crt_hip_last_error(ctx));
+    }
+}
+
+std::string RenderHIP::name()
+{
+    std::string n = crt_hip_name(ctxs[0]);
+    if (ctxs.size() > 1) {
+        n += " x" + std::to_string(ctxs.size()) + " (tile split + RCCL gather)";
+    }
+    return n;
+}
+
+void RenderHIP::initialize(const int width, const int height)
+{
+    fb_width = width;
+    fb_height = height;
+    img.resize(size_t(width) * height);
+    for (crt_hip_ctx *c : ctxs) {
+        check(c, crt_hip_initialize(c, width, height), "crt_hip_initialize");
+    }
+    if (multi) {
+        void *ptr = nullptr;
+        check(ctxs[0], crt_hip_tile_buffer(ctxs[0], &ptr, &multi->slab_bytes), "crt_hip_tile_buffer");
+        hip_ok(hipSetDevice(0), "hipSetDevice");
+        if (multi->gathered) {
+            hip_ok(hipFree(multi->gathered), "hipFree");
+        }
+        hip_ok(hipMalloc(&multi->gathered, multi->slab_bytes * ctxs.size()), "hipMalloc");
+    }
+}
+
+void RenderHIP::set_scene(const Scene &scene)
+{
+    samples_per_pixel = scene.samples_per_pixel;
+
+    // Scene (util/scene.h:23-32) -> flat crt_scene_desc. glm::vec3 / vec2 / uvec3 arrays are
+    // tightly packed floats / uints, so the pointers are passed through without copying.
+    std::vector<crt_geometry_desc> geoms;
+    std::vector<crt_mesh_desc> meshes;
+    for (const auto &mesh : scene.meshes) {
+        crt_mesh_desc md;
+        md.first_geometry = uint32_t(geoms.size());
+        md.n_geometries = uint32_t(mesh.geometries.size());
+        meshes.push_back(md);
+        for (const auto &g : mesh.geometries) {
+            crt_geometry_desc gd;
+            gd.vertices = reinterpret_cast<const float *>(g.vertices.data());
+            gd.n_vertices = g.vertices.size();
+            gd.indices = reinterpret_cast<const uint32_t *>(g.indices.data());
+            gd.n_triangles = g.indices.size();
+            gd.uvs = g.uvs.empty() ? nullptr : reinterpret_cast<const float *>(g.uvs.data());
+            geoms.push_back(gd);
+        }
+    }
+    std::vector<crt_parameterized_mesh_desc> pmeshes;
+    for (const auto &pm : scene.parameterized_meshes) {
+        crt_parameterized_mesh_desc d;
+        d.mesh_id = uint32_t(pm.mesh_id);
+        d.n_material_ids = uint32_t(pm.material_ids.size());
+        d.material_ids = pm.material_ids.data();
+        pmeshes.push_back(d);
+    }
+    std::vector<crt_instance_desc> instances;
+    for (const auto &inst : scene.instances) {
+        crt_instance_desc d;
+        std::memcpy(d.transform, &inst.transform, sizeof(float) * 16); // glm::mat4 is column-major
+        d.parameterized_mesh_id = uint32_t(inst.parameterized_mesh_id);
+        instances.push_back(d);
+    }
+    std::vector<crt_image_desc> textures;
+    for (const auto &im : scene.textures) {
+        crt_image_desc d;
+        d.width = im.width;
+        d.height = im.height;
+        d.channels = im.channels;
+        d.color_space = im.color_space == SRGB ? CRT_COLORSPACE_SRGB : CRT_COLORSPACE_LINEAR;
+        d.data = im.img.data();
+        textures.push_back(d);
+    }
+    static_assert(sizeof(DisneyMaterial) == 16 * sizeof(float), "DisneyMaterial is 16 floats (util/material.h)");
+    static_assert(sizeof(QuadLight) == 20 * sizeof(float), "QuadLight is 20 floats (util/lights.h)");
+
+    crt_scene_desc desc;
+    std::memset(&desc, 0, sizeof(desc));
+    desc.geometries = geoms.data();
+    desc.n_geometries = uint32_t(geoms.size());
+    desc.meshes = meshes.data();
+    desc.n_meshes = uint32_t(meshes.size());
+    desc.parameterized_meshes = pmeshes.data();
+    desc.n_parameterized_meshes = uint32_t(pmeshes.size());
+    desc.instances = instances.data();
+    desc.n_instances = uint32_t(instances.size());
+    desc.materials = reinterpret_cast<const float *>(scene.materials.data());
+    desc.n_materials = uint32_t(scene.materials.size());
+    desc.textures = textures.data();
+    desc.n_textures = uint32_t(textures.size());
+    desc.lights = reinterpret_cast<const float *>(scene.lights.data());
+    desc.n_lights = uint32_t(scene.lights.size());
+    desc.samples_per_pixel = scene.samples_per_pixel;
+
+    // every GPU keeps a full scene replica (a San-Miguel-class scene is ~2 GB of 288 GB)
+    std::vector<std::future<int>> jobs;
+    for (crt_hip_ctx *c : ctxs) {
+        jobs.push_back(std::async(std::launch::async, [c, &desc]() { return crt_hip_set_scene(c, &desc); }));
+    }
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        check(ctxs[i], jobs[i].get(), "crt_hip_set_scene");
+    }
+}
+
+RenderStats RenderHIP::render(const glm::vec3 &pos,
+                              const glm::vec3 &dir,
+                              const glm::vec3 &up,
+                              const float fovy,
+                              const bool camera_changed,
+                              const bool readback_framebuffer)
+{
+    const float p[3] = {pos.x, pos.y, pos.z}, d[3] = {dir.x, dir.y, dir.z}, u[3] = {up.x, up.y, up.z};
+    RenderStats stats;
+    // GLDisplay uploads `img` every frame (util/display/gldisplay.cpp:113-121), so the image is
+    // always brought back, like the Embree backend which renders into host memory.
+    (void)readback_framebuffer;
+    if (!multi) {
+        crt_render_stats st;
+        check(ctxs[0], crt_hip_render(ctxs[0], p, d, u, fovy, camera_changed, 1, &st), "crt_hip_render");
+        stats.render_time = st.render_time_ms;
+        stats.rays_per_second = st.rays_per_second;
+        copy_image(true);
+        return stats;
+    }
+    const size_t n = ctxs.size();
+    std::vector<crt_render_stats> st(n);
+    std::vector<std::future<int>> jobs;
+    for (size_t i = 0; i < n; ++i) {
+        crt_hip_ctx *c = ctxs[i];
+        crt_render_stats *out = &st[i];
+        jobs.push_back(std::async(std::launch::async, [=]() {
+            return crt_hip_render(c, p, d, u, fovy, camera_changed, 0, out);
+        }));
+    }
+    double rays = 0.0;
+    float ms = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        check(ctxs[i], jobs[i].get(), "crt_hip_render");
+        rays += double(st[i].rays);
+        ms = st[i].render_time_ms > ms ? st[i].render_time_ms : ms;
+    }
+    // gather: every device sends its compact RGBA8 tile slab to device 0 (<= 4 MiB each at 4K)
+    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (size_t i = 0; i < n; ++i) {
+        void *slab = nullptr;
+        size_t bytes = 0;
+        check(ctxs[i], crt_hip_tile_buffer(ctxs[i], &slab, &bytes), "crt_hip_tile_buffer");
+        nccl_ok(ncclSend(slab, bytes, ncclUint8, 0, multi->comms[i], multi->streams[i]), "ncclSend");
+        nccl_ok(ncclRecv(static_cast<char *>(multi->gathered) + i * bytes, bytes, ncclUint8, int(i), multi->comms[0],
+                         multi->streams[0]),
+                "ncclRecv");
+    }
+    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+    check(ctxs[0], crt_hip_assemble_tiles(ctxs[0], multi->gathered, int(n), 1), "crt_hip_assemble_tiles");
+    copy_image(true);
+    stats.render_time = ms;
+    stats.rays_per_second = float(rays / (ms * 1.0e-3));
+    return stats;
+}
+
+void RenderHIP::copy_image(bool readback)
+{
+    if (readback) {
+        std::memcpy(img.data(), crt_hip_framebuffer(ctxs[0]), img.size() * sizeof(uint32_t));
+    }
+}
