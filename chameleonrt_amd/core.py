@@ -90,7 +90,7 @@ def load():
     L.crt_hip_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, fp, fp, fp, i32p, i32p, i32p,
                                      C.POINTER(RenderStats)]
     L.crt_hip_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
-    L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p]
+    L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p, fp]
     L.crt_hip_bvh_copy.argtypes = [vp, vp, vp]
     for fn in ("crt_hip_set_stream", "crt_hip_set_partition", "crt_hip_initialize", "crt_hip_set_scene",
                "crt_hip_render", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_tile_buffer",

@@ -291,13 +291,12 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     }
     out.max_depth = max_depth;
     if (!is_inner(root)) {
-        // a single leaf: wrap it in one node whose second child can never be hit
+        // a single leaf: wrap it in one node listing it twice (the repeat loses every tie, so
+        // results are unchanged; far-away dummy boxes would not survive box quantisation)
         BvhNode nd;
         std::memset(&nd, 0, sizeof(nd));
         set_box(nd.lo0, nd.hi0, b.tn[root].box);
-        for (int k = 0; k < 3; ++k) {
-            nd.lo1[k] = nd.hi1[k] = 3.0e38f;
-        }
+        set_box(nd.lo1, nd.hi1, b.tn[root].box);
         nd.c0 = nd.c1 = child_ref(root);
         out.nodes.push_back(nd);
         out.n_top = 1;

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -158,6 +159,44 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
 constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // same macro as kernels.hip
 constexpr uint32_t MAX_TRAVERSAL_DEPTH = 60;
 
+// Fixed-point frame of a BVH with bounds b: 65531 quanta span the box, 2 quanta of margin on
+// either side absorb the outward rounding below.
+QFrame make_frame(const Aabb &b)
+{
+    QFrame f;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = (double)b.hi[a] - (double)b.lo[a];
+        const double floor_step = (std::fabs((double)b.lo[a]) + std::fabs((double)b.hi[a])) * 1e-7 + 1e-30;
+        f.step[a] = (float)std::max(ext / 65531.0, floor_step);
+        f.base[a] = (float)((double)b.lo[a] - 2.0 * (double)f.step[a]);
+    }
+    return f;
+}
+
+// Outward-rounded 16-bit box: lo one quantum further down than floor(), hi one further up than
+// ceil(), so base + q*step (evaluated in fp32 on the device) still brackets the true box.
+QNode quantise(const BvhNode &n, const QFrame &f)
+{
+    QNode q;
+    auto lo = [&](float v, int a) {
+        const double x = std::floor(((double)v - (double)f.base[a]) / (double)f.step[a]) - 1.0;
+        return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
+    };
+    auto hi = [&](float v, int a) {
+        const double x = std::ceil(((double)v - (double)f.base[a]) / (double)f.step[a]) + 1.0;
+        return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
+    };
+    for (int a = 0; a < 3; ++a) {
+        q.lo0[a] = lo(n.lo0[a], a);
+        q.hi0[a] = hi(n.hi0[a], a);
+        q.lo1[a] = lo(n.lo1[a], a);
+        q.hi1[a] = hi(n.hi1[a], a);
+    }
+    q.c0 = n.c0;
+    q.c1 = n.c1;
+    return q;
+}
+
 } // namespace
 
 struct crt_hip_ctx {
@@ -180,6 +219,7 @@ struct crt_hip_ctx {
     bool has_scene = false;
     uint32_t spp = 1;
     SceneView sv{};
+    DeviceBuffer d_spill;
     DeviceBuffer d_nodes, d_tris, d_instances, d_geoms, d_indices, d_uvs, d_material_ids, d_materials, d_textures,
         d_texels, d_lights;
     uint64_t n_nodes = 0, n_tris = 0;
@@ -555,8 +595,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 
         // one BLAS per Mesh (embree_utils.cpp:63-76)
         const bool two_level = s->n_instances > 1;
-        std::vector<BvhNode> nodes;
+        std::vector<QNode> nodes;
         std::vector<TriRec> tris;
+        std::vector<QFrame> blas_frame(s->n_meshes);
         std::vector<int32_t> blas_root(s->n_meshes);
         std::vector<Aabb> blas_bounds(s->n_meshes);
         std::vector<uint32_t> blas_top(s->n_meshes);
@@ -605,6 +646,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
                 tris[tri_base + i] = recs[built[m].order[i]];
             }
             blas_bounds[m] = built[m].bounds;
+            blas_frame[m] = make_frame(built[m].bounds);
             // re-base the node / leaf references later, once the TLAS size is known
             blas_root[m] = (int32_t)tri_base; // temporarily: triangle base
         }
@@ -625,6 +667,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             r.geom_base = s->meshes[pm.mesh_id].first_geometry;
             r.mat_base = (uint32_t)material_ids.size();
             r.blas_root = (int32_t)pm.mesh_id; // temporarily: mesh id
+            r.frame = blas_frame[pm.mesh_id];
             material_ids.insert(material_ids.end(), pm.material_ids, pm.material_ids + pm.n_material_ids);
             insts[i] = r;
             const Aabb &mb = blas_bounds[pm.mesh_id];
@@ -653,12 +696,16 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         }
         uint32_t n_top = 0;
         int32_t root = 0;
+        QFrame root_frame{};
         if (two_level) {
             BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, MAX_TOP_NODES_HOST, 1);
             if (tlas.max_depth + 8 > MAX_TRAVERSAL_DEPTH / 2) {
                 throw std::runtime_error("TLAS too deep for the traversal stack");
             }
-            nodes = tlas.nodes;
+            root_frame = make_frame(tlas.bounds);
+            for (const BvhNode &nd : tlas.nodes) {
+                nodes.push_back(quantise(nd, root_frame));
+            }
             n_top = tlas.n_top;
         }
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
@@ -674,7 +721,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
                 };
                 nd.c0 = rebase(nd.c0);
                 nd.c1 = rebase(nd.c1);
-                nodes.push_back(nd);
+                nodes.push_back(quantise(nd, blas_frame[m]));
             }
             blas_root[m] = node_base;
             blas_top[m] = built[m].n_top;
@@ -687,8 +734,10 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             r.blas_root = blas_root[r.blas_root];
         }
         if (!two_level) {
+            const uint32_t mesh0 = s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id;
             root = insts[0].blas_root;
-            n_top = blas_top[s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id];
+            n_top = blas_top[mesh0];
+            root_frame = blas_frame[mesh0];
         }
 
         // textures: sRGB -> linear in 8 bits, on the host, like the reference (render_embree.cpp:90-104)
@@ -752,7 +801,8 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         ctx->n_tris = tris.size();
 
         SceneView &sv = ctx->sv;
-        sv.nodes = ctx->d_nodes.as<BvhNode>();
+        sv.nodes = ctx->d_nodes.as<QNode>();
+        sv.root_frame = root_frame;
         sv.tris = ctx->d_tris.as<TriRec>();
         sv.instances = ctx->d_instances.as<InstanceRec>();
         sv.geoms = ctx->d_geoms.as<GeomRec>();
@@ -765,6 +815,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         sv.lights = ctx->d_lights.as<float>();
         sv.n_lights = s->n_lights;
         sv.n_instances = s->n_instances;
+        sv.spill_stride = traversal_grid_threads(ctx->n_cus);
+        ctx->d_spill.alloc((size_t)sv.spill_stride * traversal_spill_depth() * sizeof(int32_t));
+        sv.stack_spill = ctx->d_spill.as<int32_t>();
         sv.root = root;
         sv.two_level = two_level ? 1u : 0u;
         sv.n_top_nodes = n_top;
@@ -893,6 +946,13 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             st.shadow_tris += pc.tris_shadow;
         }
         st.rays = st.closest_rays + st.shadow_rays;
+        if (std::getenv("CRT_HIP_DEBUG")) { // per-bounce queue sizes of the first pass
+            const PassCounters &pc = ctx->h_pc[0];
+            for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
+                std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", ctx->frame_id,
+                             b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);
+            }
+        }
         st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
         st.rays_per_second = (float)(st.rays / (st.render_time_ms * 1.0e-3));
         if (timing) {
@@ -1022,6 +1082,11 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
             (closest && (!out_u || !out_v || !out_inst || !out_geom || !out_prim))) {
             return fail(ctx, CRT_HIP_EINVAL, "trace_rays: bad arguments");
         }
+        for (uint64_t i = 1; i < n; ++i) {
+            if (tmin[i] != tmin[0]) {
+                return fail(ctx, CRT_HIP_EINVAL, "trace_rays: tmin must be the same for every ray of a batch");
+            }
+        }
         DeviceBuffer d_org, d_dir, d_tmin, d_tmax, d_t, d_u, d_v, d_inst, d_geom, d_prim, d_ctr;
         d_org.alloc(n * 12);
         d_dir.alloc(n * 12);
@@ -1033,16 +1098,16 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
         d_inst.alloc(n * 4);
         d_geom.alloc(n * 4);
         d_prim.alloc(n * 4);
-        d_ctr.alloc(16);
+        d_ctr.alloc(24);
         hipStream_t s = ctx->stream;
         HIP_CHECK(hipMemcpyAsync(d_org.ptr, org, n * 12, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_dir.ptr, dir, n * 12, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_tmin.ptr, tmin, n * 4, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_tmax.ptr, tmax, n * 4, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 16, s));
+        HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 24, s));
         hipEvent_t e0 = get_event(ctx, 0), e1 = get_event(ctx, 1);
         HIP_CHECK(hipEventRecord(e0, s));
-        launch_trace_diag(ctx->cfg(), ctx->sv, (uint32_t)n, d_org.as<float>(), d_dir.as<float>(), d_tmin.as<float>(),
+        launch_trace_diag(ctx->cfg(), ctx->sv, (uint32_t)n, d_org.as<float>(), d_dir.as<float>(), tmin[0],
                           d_tmax.as<float>(), closest != 0, d_t.as<float>(), d_u.as<float>(), d_v.as<float>(),
                           d_inst.as<int32_t>(), d_geom.as<int32_t>(), d_prim.as<int32_t>(),
                           d_ctr.as<unsigned long long>());
@@ -1106,7 +1171,7 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
 }
 
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris, uint64_t *n_instances,
-                     int32_t *two_level)
+                     int32_t *two_level, float *root_frame)
 {
     return guarded(ctx, [&]() -> int {
         if (!ctx->has_scene) {
@@ -1124,6 +1189,9 @@ int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris, uint
         if (two_level) {
             *two_level = (int32_t)ctx->sv.two_level;
         }
+        if (root_frame) {
+            std::memcpy(root_frame, &ctx->sv.root_frame, sizeof(QFrame));
+        }
         return CRT_HIP_OK;
     });
 }
@@ -1136,7 +1204,7 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
         }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (nodes) {
-            HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
         }
         if (tris) {
             HIP_CHECK(hipMemcpy(tris, ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));

@@ -6,12 +6,12 @@
 
 namespace crt {
 
-// One BVH2 node = 64 B = one quarter of a 256-B HBM burst; 4 x dwordx4 per lane.
-// Holds the boxes of BOTH children, so one fetch decides both.
 // Child reference c: c >= 0 -> inner node index (global, into Scene::nodes)
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
 //                              BLAS: triangles [first, first+count) of Scene::tris
 //                              TLAS: instance `first` (count is 1)
+// BvhNode is what the host builder produces (full-precision boxes of BOTH children); the
+// traversal kernels read the 32-byte quantised form below.
 struct alignas(16) BvhNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -19,6 +19,24 @@ struct alignas(16) BvhNode {
     int32_t pad0, pad1;
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Fixed-point frame of one BVH: world/object coordinate = base + q * step, q in [0, 65535].
+struct QFrame {
+    float base[3];
+    float step[3];
+};
+
+// One BVH2 node as the kernels see it: 32 B = 2 x dwordx4 per lane. Both children's AABBs as
+// 16-bit fixed point in the BVH's QFrame, rounded OUTWARD by at least one quantum (conservative:
+// a box may only grow, so no hit can be missed; which triangle wins never depends on the boxes).
+// Halving the node halves the traffic through the per-CU vector-memory pipeline, which is what
+// bounds incoherent traversal on MI355X (TA busy ~85 % with 64-byte nodes, profiles/).
+struct alignas(16) QNode {
+    uint16_t lo0[3], hi0[3];
+    uint16_t lo1[3], hi1[3];
+    int32_t c0, c1;
+};
+static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
 
 // One triangle = 48 B; 3 x dwordx4. Embree-style precomputed edges:
 // e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1). geom = Embree geomID (position of the
@@ -29,16 +47,17 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
-// One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 96 B.
+// One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 128 B.
 struct alignas(16) InstanceRec {
     float w2o[16];      // world_to_object, column-major like glm (m[c*4+r])
     int32_t blas_root;  // node index of the mesh's BLAS root
     uint32_t geom_base; // global geometry index of the mesh's geometry 0
     uint32_t mat_base;  // offset into Scene::material_ids for this instance's geomID 0
     uint32_t identity;  // 1 if the transform is bit-exactly the identity (ray not transformed)
-    uint32_t pad[4];
+    QFrame frame;       // fixed-point frame of the mesh's BLAS
+    uint32_t pad[6];
 };
-static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
+static_assert(sizeof(InstanceRec) == 128, "InstanceRec must be 128 bytes");
 
 // Per-geometry shading data (ISPCGeometry, backends/embree/embree_utils.h:38-46): only the
 // index buffer and UVs are ever read by the hot path (normals are ignored, quirk Q7).
@@ -65,7 +84,7 @@ struct ViewParams {
 
 // Device pointers of the whole scene, passed to kernels by value.
 struct SceneView {
-    const BvhNode *nodes;
+    const QNode *nodes;
     const TriRec *tris;
     const InstanceRec *instances;
     const GeomRec *geoms;
@@ -78,9 +97,12 @@ struct SceneView {
     const float *lights;          // 20 floats per QuadLight
     uint32_t n_lights;
     uint32_t n_instances;
+    QFrame root_frame;            // frame of the BVH `root` belongs to
     int32_t root;                 // TLAS root (two-level) or the single BLAS root
     uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly
     uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
+    int32_t *stack_spill;         // traversal-stack overflow slab, [depth][thread of the persistent grid]
+    uint32_t spill_stride;        // threads the slab was sized for
 };
 
 constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)

@@ -13,6 +13,10 @@ struct LaunchCfg {
     bool counters;  // instrumented traversal (CRT_HIP_FLAG_COUNTERS)
 };
 
+// Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).
+uint32_t traversal_grid_threads(int n_cus);
+uint32_t traversal_spill_depth();
+
 // K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.
 void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
                    uint32_t n_paths, PathQueue q, float4 *radiance, PassCounters *pc);
@@ -37,9 +41,9 @@ void launch_assemble(const LaunchCfg &cfg, const uint32_t *gathered, uint32_t sl
 
 // Diagnostics (crt_hip_trace_rays / crt_hip_kat): same traversal code, explicit rays.
 void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, const float *org, const float *dir,
-                       const float *tmin, const float *tmax, bool closest, float *out_t, float *out_u,
+                       float tmin, const float *tmax, bool closest, float *out_t, float *out_u,
                        float *out_v, int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
-                       unsigned long long *counters /* nodes, tris */);
+                       unsigned long long *counters /* nodes, tris, ray cursor */);
 int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,
                float *out, int out_stride);
 

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/crt_kat.h"
 #include "kernels.h"
 #include "pt_device.h"
@@ -38,7 +40,7 @@ namespace crt {
 #define CRT_TRACE_BLOCKS_PER_CU 8
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
-constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each)
+constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (32 B each)
 constexpr int SHADE_BLOCK = 256;
 
 // ---- wave-level helpers (wave64) -------------------------------------------------------------
@@ -200,17 +202,17 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
 struct TraceLds {
-    BvhNode top[MAX_TOP_NODES + 1];
+    QNode top[MAX_TOP_NODES + 1];
     int32_t stack[LDS_STACK][TRACE_BLOCK];
 };
 
-CRT_DEV const BvhNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
+CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
 {
     // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step.
     const uint32_t n = min(sc.n_top_nodes, (uint32_t)MAX_TOP_NODES);
     const float4 *src = reinterpret_cast<const float4 *>(sc.nodes + sc.root);
     float4 *dst = reinterpret_cast<float4 *>(lds.top);
-    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < n * 2; i += blockDim.x) {
         dst[i] = src[i];
     }
     __syncthreads();
@@ -218,39 +220,42 @@ CRT_DEV const BvhNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
 }
 
 // ---- K2 trace_closest ----------------------------------------------------------------------------
+struct ClosestSource {
+    PathQueue q;
+    HitBuf hits;
+    CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
+    {
+        o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        tfar = RAY_TFAR;
+    }
+    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    {
+        hits.t[i] = h.t;
+        hits.u[i] = h.u;
+        hits.v[i] = h.v;
+        hits.tri[i] = h.tri;
+        hits.inst[i] = h.inst;
+    }
+};
+
 template <bool TWO_LEVEL, bool COUNTERS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;
-    const BvhNode *top = stage_top_nodes(sc, lds);
+    const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    const uint32_t n = pc->n_queue[bounce];
+    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.spill_stride = sc.spill_stride;
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        const uint32_t packet = wave_fetch(&pc->cur_closest[bounce]);
-        if (packet >= n) {
-            break;
-        }
-        for (uint32_t round = 0; round < FETCH / 64; ++round) {
-        const uint32_t i = packet + round * 64 + lane_id();
-        if (i < n) {
-            const V3 o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
-            const V3 d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
-            RayHit h;
-            traverse<false, TWO_LEVEL, COUNTERS>(sc, top, o, d, tnear, RAY_TFAR, h, st, n_nodes, n_tris);
-            hits.t[i] = h.t;
-            hits.u[i] = h.u;
-            hits.v[i] = h.v;
-            hits.tri[i] = h.tri;
-            hits.inst[i] = h.inst;
-        }
-        }
-    }
+    const ClosestSource src{q, hits};
+    trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
+                                                n_nodes, n_tris);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
@@ -258,45 +263,49 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
 }
 
 // ---- K4 trace_shadow (A: light samples) ----------------------------------------------------------
+struct ShadowASource {
+    ShadowQueueA sa;
+    ShadowQueueB sb;
+    float4 *radiance;
+    CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
+    {
+        o = v3(sa.o[0][i], sa.o[1][i], sa.o[2][i]);
+        d = v3(sa.d[0][i], sa.d[1][i], sa.d[2][i]);
+        tfar = sa.tmax[i];
+    }
+    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    {
+        const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148
+        const int32_t bslot = sa.bslot[i];
+        if (bslot >= 0) {
+            sb.vis_a[bslot] = visible ? 1 : 0;
+        } else if (visible) {
+            // illum = illum + path_throughput * nee, nee = cA (ispc:151, 301)
+            const uint32_t p = sa.path[i];
+            float4 L = radiance[p];
+            L.x = L.x + sa.c[0][i];
+            L.y = L.y + sa.c[1][i];
+            L.z = L.z + sa.c[2][i];
+            radiance[p] = L;
+        }
+    }
+};
+
 template <bool TWO_LEVEL, bool COUNTERS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                                 float4 *radiance, PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;
-    const BvhNode *top = stage_top_nodes(sc, lds);
+    const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    const uint32_t n = pc->n_shadow_a[bounce];
+    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.spill_stride = sc.spill_stride;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        const uint32_t packet = wave_fetch(&pc->cur_shadow_a[bounce]);
-        if (packet >= n) {
-            break;
-        }
-        for (uint32_t round = 0; round < FETCH / 64; ++round) {
-        const uint32_t i = packet + round * 64 + lane_id();
-        if (i < n) {
-            const V3 o = v3(sa.o[0][i], sa.o[1][i], sa.o[2][i]);
-            const V3 d = v3(sa.d[0][i], sa.d[1][i], sa.d[2][i]);
-            RayHit h;
-            traverse<true, TWO_LEVEL, COUNTERS>(sc, top, o, d, RAY_EPS, sa.tmax[i], h, st, n_nodes, n_tris);
-            const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148
-            const int32_t bslot = sa.bslot[i];
-            if (bslot >= 0) {
-                sb.vis_a[bslot] = visible ? 1 : 0;
-            } else if (visible) {
-                // illum = illum + path_throughput * nee, nee = cA (ispc:151, 301)
-                const uint32_t p = sa.path[i];
-                float4 L = radiance[p];
-                L.x = L.x + sa.c[0][i];
-                L.y = L.y + sa.c[1][i];
-                L.z = L.z + sa.c[2][i];
-                radiance[p] = L;
-            }
-        }
-        }
-    }
+    const ShadowASource src{sa, sb, radiance};
+    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
+                                               src, n_nodes, n_tris);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
@@ -304,47 +313,50 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, Sh
 }
 
 // ---- K4 trace_shadow (B: BSDF samples that hit the light) ---------------------------------------
+struct ShadowBSource {
+    ShadowQueueB sb;
+    float4 *radiance;
+    CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
+    {
+        o = v3(sb.o[0][i], sb.o[1][i], sb.o[2][i]);
+        d = v3(sb.d[0][i], sb.d[1][i], sb.d[2][i]);
+        tfar = sb.tmax[i];
+    }
+    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    {
+        // sample_direct_light's return value (ispc:117,151,175): illum = 0; [illum = cA;] [illum += cB]
+        V3 nee = v3(0.f);
+        if (sb.vis_a[i]) {
+            nee = v3(sb.ca[0][i], sb.ca[1][i], sb.ca[2][i]);
+        }
+        if (h.tri < 0) {
+            nee = nee + v3(sb.cb[0][i], sb.cb[1][i], sb.cb[2][i]);
+        }
+        const V3 add = v3(sb.tp[0][i], sb.tp[1][i], sb.tp[2][i]) * nee;
+        const uint32_t p = sb.path[i];
+        float4 L = radiance[p];
+        L.x = L.x + add.x;
+        L.y = L.y + add.y;
+        L.z = L.z + add.z;
+        radiance[p] = L;
+    }
+};
+
 template <bool TWO_LEVEL, bool COUNTERS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, ShadowQueueB sb, float4 *radiance,
                                                                 PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;
-    const BvhNode *top = stage_top_nodes(sc, lds);
+    const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    const uint32_t n = pc->n_shadow_b[bounce];
+    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.spill_stride = sc.spill_stride;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        const uint32_t packet = wave_fetch(&pc->cur_shadow_b[bounce]);
-        if (packet >= n) {
-            break;
-        }
-        for (uint32_t round = 0; round < FETCH / 64; ++round) {
-        const uint32_t i = packet + round * 64 + lane_id();
-        if (i < n) {
-            const V3 o = v3(sb.o[0][i], sb.o[1][i], sb.o[2][i]);
-            const V3 d = v3(sb.d[0][i], sb.d[1][i], sb.d[2][i]);
-            RayHit h;
-            traverse<true, TWO_LEVEL, COUNTERS>(sc, top, o, d, RAY_EPS, sb.tmax[i], h, st, n_nodes, n_tris);
-            // sample_direct_light's return value (ispc:117,151,175): illum = 0; [illum = cA;] [illum += cB]
-            V3 nee = v3(0.f);
-            if (sb.vis_a[i]) {
-                nee = v3(sb.ca[0][i], sb.ca[1][i], sb.ca[2][i]);
-            }
-            if (h.tri < 0) {
-                nee = nee + v3(sb.cb[0][i], sb.cb[1][i], sb.cb[2][i]);
-            }
-            const V3 add = v3(sb.tp[0][i], sb.tp[1][i], sb.tp[2][i]) * nee;
-            const uint32_t p = sb.path[i];
-            float4 L = radiance[p];
-            L.x = L.x + add.x;
-            L.y = L.y + add.y;
-            L.z = L.z + add.z;
-            radiance[p] = L;
-        }
-        }
-    }
+    const ShadowBSource src{sb, radiance};
+    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_b[bounce], &pc->cur_shadow_b[bounce], RAY_EPS,
+                                               src, n_nodes, n_tris);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
@@ -406,7 +418,7 @@ CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
-                                                       PassCounters *pc, int bounce)
+                                                       PassCounters *pc, int bounce, int ablate)
 {
     __shared__ ShadeStage stage;
     if (threadIdx.x == 0) {
@@ -468,6 +480,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                                      m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
                 }
                 Surface mat;
+                if (ablate & 1) {
+                    const float *pm = sc.materials;
+                    mat.base_color = v3(0.8f, 0.8f, 0.8f);
+                    mat.metallic = 0.f; mat.specular = 0.f; mat.roughness = 1.f; mat.specular_tint = 0.f; mat.anisotropy = 0.f;
+                    mat.sheen = 0.f; mat.sheen_tint = 0.f; mat.clearcoat = 0.f; mat.clearcoat_gloss = 0.f; mat.ior = 1.5f;
+                    mat.specular_transmission = pm[13] * 0.f;
+                } else
                 unpack_material(sc, mat, sc.materials + 16 * (size_t)sc.material_ids[in.mat_base + geom], uv);
                 if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
                     normal = -normal;
@@ -489,23 +508,28 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                     light_dir = unit(light_dir);
                     const float l_pdf = light_pdf(light, light_pos, light_dir);
                     const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
-                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
+                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS && !(ablate & 2)) {
                         const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
                         const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
                         c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
                     }
                 }
                 {
-                    float b_pdf;
-                    const V3 bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i_b, b_pdf);
+                    // ispc:156-179. The reference evaluates the BSDF first and tests the light quad
+                    // second; the quad test is the cheap and rarely-true one, so it goes first here
+                    // (pure functions: same value, ~1/3 of the shading ALU work saved).
                     V3 light_pos;
-                    if (!is_black(bsdf) && b_pdf >= RAY_EPS &&
+                    if (disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i_b) &&
                         light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
-                        const float l_pdf = light_pdf(light, light_pos, w_i_b);
-                        if (l_pdf >= RAY_EPS) {
-                            const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
-                            c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
-                            has_b = true;
+                        const float b_pdf = disney_pdf(mat, normal, w_o, w_i_b, v_x, v_y);
+                        const V3 bsdf = disney_eval(mat, normal, w_o, w_i_b, v_x, v_y);
+                        if (!is_black(bsdf) && b_pdf >= RAY_EPS) {
+                            const float l_pdf = light_pdf(light, light_pos, w_i_b);
+                            if (l_pdf >= RAY_EPS) {
+                                const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
+                                c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
+                                has_b = true;
+                            }
                         }
                     }
                 }
@@ -519,20 +543,28 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                 L.z = L.z + poison.z;
 
                 // -- continue the path, ispc:313-335 --
-                float pdf;
-                const V3 bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
-                alive = !(pdf == 0.f || is_black(bsdf));
-                if (alive) {
-                    tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
-                    const int next_bounce = bounce + 1;
-                    if (next_bounce >= MAX_PATH_DEPTH) {
-                        alive = false; // `while (bounce < MAX_PATH_DEPTH)`: roulette outcome is unobservable
-                    } else if (next_bounce > 3) {
-                        const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
-                        if (rng_nextf(rng) < qr) {
-                            alive = false;
-                        } else {
-                            tp = tp / (1.f - qr);
+                // On the last iteration (`while (bounce < MAX_PATH_DEPTH)`) the sampled direction,
+                // throughput and roulette draw are never observed: skip them.
+                const int next_bounce = bounce + 1;
+                if (next_bounce < MAX_PATH_DEPTH) {
+                    float pdf;
+                    V3 bsdf;
+                    if (ablate & 4) {
+                        disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i);
+                        pdf = 1.f;
+                        bsdf = v3(0.3f);
+                    } else
+                    bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
+                    alive = !(pdf == 0.f || is_black(bsdf));
+                    if (alive) {
+                        tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
+                        if (next_bounce > 3) { // Russian roulette, ispc:327-335
+                            const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
+                            if (rng_nextf(rng) < qr) {
+                                alive = false;
+                            } else {
+                                tp = tp / (1.f - qr);
+                            }
                         }
                     }
                 }
@@ -656,24 +688,19 @@ __global__ void k_assemble(const uint32_t *gathered, uint32_t slab_pixels, int w
 }
 
 // ---- diagnostics: explicit rays through the production traversal -------------------------------
-template <bool ANY_HIT, bool TWO_LEVEL>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32_t n, const float *org,
-                                                            const float *dir, const float *tmin, const float *tmax,
-                                                            float *out_t, float *out_u, float *out_v,
-                                                            int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
-                                                            unsigned long long *counters)
-{
-    __shared__ TraceLds lds;
-    const BvhNode *top = stage_top_nodes(sc, lds);
-    TraversalStack st;
-    st.lds = &lds.stack[0][threadIdx.x];
-    st.stride = TRACE_BLOCK;
-    uint32_t n_nodes = 0, n_tris = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-        const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-        RayHit h;
-        traverse<ANY_HIT, TWO_LEVEL, true>(sc, top, o, d, tmin[i], tmax[i], h, st, n_nodes, n_tris);
+template <bool ANY_HIT> struct DiagSource {
+    SceneView sc;
+    const float *org, *dir, *tmax;
+    float *out_t, *out_u, *out_v;
+    int32_t *out_inst, *out_geom, *out_prim;
+    CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
+    {
+        o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        tfar = tmax[i];
+    }
+    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    {
         if (ANY_HIT) {
             out_t[i] = h.tri < 0 ? 1.f : 0.f;
         } else {
@@ -685,6 +712,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
             out_prim[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].prim;
         }
     }
+};
+
+// counters: [0] nodes, [1] triangles, [2] low word = ray cursor. tmin must be uniform over the
+// batch (as it is inside a frame: 0 for primary rays, EPSILON afterwards).
+template <bool ANY_HIT, bool TWO_LEVEL>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32_t n, const float *org,
+                                                            const float *dir, float tmin, const float *tmax,
+                                                            float *out_t, float *out_u, float *out_v,
+                                                            int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
+                                                            unsigned long long *counters)
+{
+    __shared__ TraceLds lds;
+    const QNode *top = stage_top_nodes(sc, lds);
+    TraversalStack st;
+    st.lds = &lds.stack[0][threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.spill_stride = sc.spill_stride;
+    uint32_t n_nodes = 0, n_tris = 0;
+    const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
+    trace_wavefront<ANY_HIT, TWO_LEVEL, true>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]), tmin, src,
+                                              n_nodes, n_tris);
     atomicAdd(&counters[0], (unsigned long long)n_nodes);
     atomicAdd(&counters[1], (unsigned long long)n_tris);
 }
@@ -813,6 +862,9 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
+uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
+uint32_t traversal_spill_depth() { return (uint32_t)SPILL_STACK; }
+
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
 static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)
 {
@@ -861,15 +913,16 @@ void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueu
 {
     // B rays are rare (BSDF sample must hit the light quad): a quarter-size grid is plenty
     launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_b<false, false>, k_trace_shadow_b<false, true>,
-            k_trace_shadow_b<true, false>, k_trace_shadow_b<true, true>, persistent_grid(cfg, 1), cfg.stream, sc, sb,
+            k_trace_shadow_b<true, false>, k_trace_shadow_b<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sb,
             radiance, pc, bounce);
 }
 
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce)
 {
+    static const int ablate = std::getenv("CRT_HIP_ABLATE") ? std::atoi(std::getenv("CRT_HIP_ABLATE")) : 0;
     k_shade<<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc,
-                                                                     bounce);
+                                                                     bounce, ablate);
 }
 
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
@@ -890,10 +943,10 @@ void launch_assemble(const LaunchCfg &cfg, const uint32_t *gathered, uint32_t sl
 }
 
 void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, const float *org, const float *dir,
-                       const float *tmin, const float *tmax, bool closest, float *out_t, float *out_u, float *out_v,
+                       float tmin, const float *tmax, bool closest, float *out_t, float *out_u, float *out_v,
                        int32_t *out_inst, int32_t *out_geom, int32_t *out_prim, unsigned long long *counters)
 {
-    const int grid = capped_grid(cfg, n, TRACE_BLOCK);
+    const int grid = persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU);
     if (closest) {
         if (sc.two_level) {
             k_trace_diag<false, true><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,

@@ -523,8 +523,11 @@ CRT_DEV float disney_pdf(const Surface &m, V3 n, V3 w_o, V3 w_i, V3 v_x, V3 v_y)
     }
     return (diffuse + microfacet + microfacet_transmission + clear_coat) / n_comp;
 }
-// :364-429. Draw order: lobe pick, sample x, sample y (quirk Q3).
-CRT_DEV V3 disney_sample(const Surface &m, V3 n, V3 w_o, V3 v_x, V3 v_y, uint32_t &rng, V3 &w_i, float &pdf)
+// :364-426, the direction-sampling half of sample_disney_brdf. Draw order: lobe pick, sample x,
+// sample y (quirk Q3). Returns false where the reference returns (f = 0, pdf = 0): invalid
+// reflection / total internal reflection. Splitting it from the evaluation lets the caller skip
+// disney_pdf + disney_eval when their result is provably unused (both are pure functions).
+CRT_DEV bool disney_sample_dir(const Surface &m, V3 n, V3 w_o, V3 v_x, V3 v_y, uint32_t &rng, V3 &w_i)
 {
     int component;
     if (m.specular_transmission == 0.f) {
@@ -551,18 +554,16 @@ CRT_DEV V3 disney_sample(const Surface &m, V3 n, V3 w_o, V3 v_x, V3 v_y, uint32_
         }
         w_i = reflect3(-w_o, w_h);
         if (!same_side(w_o, w_i, n)) {
-            pdf = 0.f;
             w_i = v3(0.f);
-            return v3(0.f);
+            return false;
         }
     } else if (component == 2) {
         const float alpha = mix1(0.1f, 0.001f, m.clearcoat_gloss);
         const V3 w_h = sample_gtr1_h(n, v_x, v_y, alpha, s);
         w_i = reflect3(-w_o, w_h);
         if (!same_side(w_o, w_i, n)) {
-            pdf = 0.f;
             w_i = v3(0.f);
-            return v3(0.f);
+            return false;
         }
     } else {
         const float alpha = fmaxf(0.001f, m.roughness * m.roughness);
@@ -573,9 +574,17 @@ CRT_DEV V3 disney_sample(const Surface &m, V3 n, V3 w_o, V3 v_x, V3 v_y, uint32_
         const bool entering = dot3(w_o, n) > 0.f;
         w_i = refract3(-w_o, w_h, entering ? 1.f / m.ior : m.ior);
         if (is_black(w_i)) {
-            pdf = 0.f;
-            return v3(0.f);
+            return false;
         }
+    }
+    return true;
+}
+// :364-429 sample_disney_brdf = direction + (:427-428) pdf and value at that direction
+CRT_DEV V3 disney_sample(const Surface &m, V3 n, V3 w_o, V3 v_x, V3 v_y, uint32_t &rng, V3 &w_i, float &pdf)
+{
+    if (!disney_sample_dir(m, n, w_o, v_x, v_y, rng, w_i)) {
+        pdf = 0.f;
+        return v3(0.f);
     }
     pdf = disney_pdf(m, n, w_o, w_i, v_x, v_y);
     return disney_eval(m, n, w_o, w_i, v_x, v_y);

@@ -11,7 +11,7 @@
 // Boxes are tested with a conservative slab test (exit widened by 2 ulp, NaN-ignoring
 // min/max), children visited nearest-entry first, far child pushed on a per-lane stack whose
 // first LDS_STACK entries live in LDS ([depth][lane] so a wave's accesses are conflict-free)
-// and the rest in scratch.
+// and the rest in an HBM slab.
 #pragma once
 #include "pt_device.h"
 
@@ -21,7 +21,10 @@ namespace crt {
 #define CRT_LDS_STACK 8
 #endif
 constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
-constexpr int SCRATCH_STACK = 56;  // overflow entries in private memory (LDS_STACK + this = 64)
+// Deeper entries go to an explicit HBM slab laid out [depth][thread] (coalesced across a wave).
+// Not a private array: scratch-backed kernels get their wave occupancy throttled by the
+// runtime's scratch ring, which cost this kernel most of its latency hiding.
+constexpr int SPILL_STACK = 64 - CRT_LDS_STACK;
 constexpr int32_t STACK_SENTINEL = (int32_t)0x80000000; // marks "leave instance" (two-level)
 
 struct RayHit {
@@ -31,23 +34,24 @@ struct RayHit {
 };
 
 struct TraversalStack {
-    int32_t *lds; // this lane's column: entry k at lds[k * stride]
+    int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
-    int32_t spill[SCRATCH_STACK];
+    int32_t *spill; // this lane's column of the HBM part: entry k at spill[k * spill_stride]
+    uint32_t spill_stride;
     int sp;
     CRT_DEV void push(int32_t x)
     {
         if (sp < LDS_STACK) {
             lds[sp * stride] = x;
         } else {
-            spill[sp - LDS_STACK] = x;
+            spill[(size_t)(sp - LDS_STACK) * spill_stride] = x;
         }
         ++sp;
     }
     CRT_DEV int32_t pop()
     {
         --sp;
-        return sp < LDS_STACK ? lds[sp * stride] : spill[sp - LDS_STACK];
+        return sp < LDS_STACK ? lds[sp * stride] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
     }
 };
 
@@ -62,13 +66,16 @@ CRT_DEV V3 xfm_vector(const float *m, V3 v)
               m[2] * v.x + m[6] * v.y + m[10] * v.z);
 }
 
-// Slab test of one child box; returns entry distance in tn.
-CRT_DEV bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv, float tmin,
-                  float tmax, float &tn)
+// Slab test of one quantised child box. A plane at fixed-point coordinate q lies at
+// base + q*step, so its ray parameter is ((base + q*step) - o) * inv = q*qa + qb with
+// qa = step*inv and qb = (base - o)*inv computed once per ray and frame: one FMA per plane.
+// The boxes carry a full quantum of outward slack, far more than the FMA's rounding error.
+CRT_DEV bool slab_q(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint32_t hiy, uint32_t hiz, V3 qa, V3 qb,
+                    float tmin, float tmax, float &tn)
 {
-    const float t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
-    const float t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
-    const float t0z = (loz - o.z) * inv.z, t1z = (hiz - o.z) * inv.z;
+    const float t0x = __builtin_fmaf((float)lox, qa.x, qb.x), t1x = __builtin_fmaf((float)hix, qa.x, qb.x);
+    const float t0y = __builtin_fmaf((float)loy, qa.y, qb.y), t1y = __builtin_fmaf((float)hiy, qa.y, qb.y);
+    const float t0z = __builtin_fmaf((float)loz, qa.z, qb.z), t1z = __builtin_fmaf((float)hiz, qa.z, qb.z);
     tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
     return tn <= tf * 1.0000004f;
@@ -102,140 +109,251 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
     return true;
 }
 
-// top: LDS copy of nodes [sc.root, sc.root + sc.n_top_nodes) or nullptr.
-template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS>
-CRT_DEV void traverse(const SceneView &sc, const BvhNode *top, V3 org, V3 dir, float tnear, float tfar,
-                      RayHit &hit, TraversalStack &st, uint32_t &n_nodes, uint32_t &n_tris)
-{
-    hit.t = tfar;
-    hit.u = hit.v = 0.f;
-    hit.tri = -1;
-    hit.inst = -1;
-    uint32_t best_geom = 0, best_prim = 0;
-    st.sp = 0;
+// ------------------------------------------------------------------------------------------
+// Wavefront traversal: what the production kernels run.
+//
+// A persistent wave keeps 64 rays in flight. Three things keep its lanes busy on incoherent
+// rays (PMC on the first version: 28 % of VALU lanes active, 71 % of wave cycles waiting):
+//   * a lane whose ray is finished is refilled from the queue as soon as REFILL_MIN lanes are
+//     idle (the wave owns a private pool of POOL_CHUNK consecutive ray indices, so the global
+//     cursor sees one atomic per POOL_CHUNK rays);
+//   * inner-node steps and leaf (triangle / instance-entry) steps run in separate phases, each
+//     entered only when enough lanes want it, instead of serialising both bodies every step;
+//   * results are written per ray when it retires.
+// Semantics are exactly those of traverse() above (same slab and triangle arithmetic, same
+// visit rule per ray), so hits are bit-identical; only the schedule differs.
+// ------------------------------------------------------------------------------------------
+#ifndef CRT_REFILL_MIN
+#define CRT_REFILL_MIN 16
+#endif
+#ifndef CRT_POOL_CHUNK
+#define CRT_POOL_CHUNK 128
+#endif
+constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
 
-    V3 o = org, d = dir;
+CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Source: struct with
+//   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   ray i of the queue
+//   void store(uint32_t i, const RayHit &h) const;            its result (h.tri < 0: miss / unoccluded)
+template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
+CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
+                             uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris)
+{
+    // per-lane ray state
+    int32_t ray = -1;
+    int32_t cur = CUR_DONE;
+    V3 org = v3(0.f), dir = v3(0.f); // world-space ray
+    V3 o = v3(0.f), d = v3(0.f);                 // ray in the space being traversed
+    V3 qa = v3(0.f), qb = v3(0.f);               // that ray in the fixed-point frame of the current BVH
+    float tfar = 0.f;
+    RayHit hit;
+    hit.t = 0.f;
+    hit.u = hit.v = 0.f;
+    hit.tri = hit.inst = -1;
+    uint32_t best_geom = 0, best_prim = 0;
     int32_t cur_inst = 0;
     bool in_blas = !TWO_LEVEL;
-    if (!TWO_LEVEL) {
-        const InstanceRec &in = sc.instances[0];
-        if (!in.identity) {
-            o = xfm_point(in.w2o, org);
-            d = xfm_vector(in.w2o, dir);
-        }
-    }
-    V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    int32_t cur = sc.root;
+    st.sp = 0;
+    // wave-uniform pool of ray indices
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
     const int32_t top_lo = sc.root, top_hi = sc.root + (int32_t)sc.n_top_nodes;
 
-    for (;;) {
-        if (cur >= 0) {
-            float4 q0, q1, q2, q3;
-            if (top != nullptr && cur >= top_lo && cur < top_hi) {
-                const float4 *p = reinterpret_cast<const float4 *>(top + (cur - top_lo));
-                q0 = p[0];
-                q1 = p[1];
-                q2 = p[2];
-                q3 = p[3];
-            } else {
-                const float4 *p = reinterpret_cast<const float4 *>(sc.nodes + cur);
-                q0 = p[0];
-                q1 = p[1];
-                q2 = p[2];
-                q3 = p[3];
-            }
-            if (COUNTERS) {
-                ++n_nodes;
-            }
-            float t0, t1;
-            const bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tnear, hit.t, t0);
-            const bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tnear, hit.t, t1);
-            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool first0 = t0 <= t1;
-                st.push(first0 ? c1 : c0);
-                cur = first0 ? c0 : c1;
-                continue;
-            }
-            if (h0) {
-                cur = c0;
-                continue;
-            }
-            if (h1) {
-                cur = c1;
-                continue;
-            }
-        } else {
-            const uint32_t x = ~(uint32_t)cur;
-            const uint32_t first = x >> 3;
-            if (TWO_LEVEL && !in_blas) {
-                // TLAS leaf: enter the instance (Embree transforms the ray, keeps t)
-                const InstanceRec &in = sc.instances[first];
-                cur_inst = (int32_t)first;
-                if (!in.identity) {
-                    o = xfm_point(in.w2o, org);
-                    d = xfm_vector(in.w2o, dir);
-                    inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-                }
-                in_blas = true;
-                st.push(STACK_SENTINEL);
-                cur = in.blas_root;
-                continue;
-            }
-            const uint32_t count = (x & 7u) + 1u;
-            bool occluded = false;
-            for (uint32_t k = first; k < first + count; ++k) {
-                const float4 *p = reinterpret_cast<const float4 *>(sc.tris + k);
-                const float4 a = p[0], b = p[1], c = p[2];
-                if (COUNTERS) {
-                    ++n_tris;
-                }
-                float t, u, v;
-                if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
-                    if (ANY_HIT) {
-                        occluded = true;
-                        break;
-                    }
-                    const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
-                    bool take = t < hit.t;
-                    if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
-                        take = cur_inst != hit.inst ? cur_inst < hit.inst
-                                                    : (geom != best_geom ? geom < best_geom : prim < best_prim);
-                    } else if (t == hit.t) {
-                        take = true; // first hit exactly at tfar
-                    }
-                    if (take) {
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        hit.tri = (int32_t)k;
-                        hit.inst = cur_inst;
-                        best_geom = geom;
-                        best_prim = prim;
-                    }
-                }
-            }
-            if (ANY_HIT && occluded) {
-                hit.tri = 0;
-                hit.inst = cur_inst;
-                hit.t = 0.f;
-                return;
-            }
-        }
-        // pop
+    auto set_frame = [&](const QFrame &f) {
+        const V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        qa = v3(f.step[0] * inv.x, f.step[1] * inv.y, f.step[2] * inv.z);
+        qb = v3((f.base[0] - o.x) * inv.x, (f.base[1] - o.y) * inv.y, (f.base[2] - o.z) * inv.z);
+    };
+
+    // take the next reference off the stack (or finish); handles the instance-exit sentinel
+    auto pop_next = [&]() {
         for (;;) {
             if (st.sp == 0) {
+                cur = CUR_DONE;
                 return;
             }
             cur = st.pop();
             if (TWO_LEVEL && cur == STACK_SENTINEL) {
                 o = org;
                 d = dir;
-                inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                set_frame(sc.root_frame);
                 in_blas = false;
                 continue;
             }
-            break;
+            return;
+        }
+    };
+
+    for (;;) {
+        // ---- refill idle lanes --------------------------------------------------------------
+        {
+            const bool idle = ray < 0;
+            const uint64_t idle_mask = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+            if (n_idle >= CRT_REFILL_MIN && !exhausted) {
+                if (pool_next == pool_end) {
+                    uint32_t base = 0;
+                    if (tv_lane_id() == 0) {
+                        base = atomicAdd(cursor, (uint32_t)CRT_POOL_CHUNK);
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) {
+                        exhausted = true;
+                        pool_next = pool_end = 0;
+                    } else {
+                        pool_next = base;
+                        pool_end = min(base + (uint32_t)CRT_POOL_CHUNK, n);
+                    }
+                }
+                const uint32_t take = min(n_idle, pool_end - pool_next);
+                if (idle) {
+                    const uint32_t rank = tv_lanes_below(idle_mask);
+                    if (rank < take) {
+                        ray = (int32_t)(pool_next + rank);
+                        src.load((uint32_t)ray, org, dir, tfar);
+                        o = org;
+                        d = dir;
+                        cur_inst = 0;
+                        in_blas = !TWO_LEVEL;
+                        if (!TWO_LEVEL) {
+                            const InstanceRec &in = sc.instances[0];
+                            if (!in.identity) {
+                                o = xfm_point(in.w2o, org);
+                                d = xfm_vector(in.w2o, dir);
+                            }
+                        }
+                        set_frame(sc.root_frame);
+                        hit.t = tfar;
+                        hit.u = hit.v = 0.f;
+                        hit.tri = -1;
+                        hit.inst = -1;
+                        st.sp = 0;
+                        cur = sc.root;
+                    }
+                }
+                pool_next += take;
+            }
+        }
+        const uint64_t active_mask = __ballot(ray >= 0);
+        if (active_mask == 0) {
+            if (exhausted) {
+                break;
+            }
+            continue;
+        }
+        const uint32_t n_active = (uint32_t)__popcll(active_mask);
+
+        // ---- inner-node phase: step while at least half of the active lanes are on an inner node
+        for (;;) {
+            const bool inner = ray >= 0 && cur >= 0;
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+            if (n_inner == 0 || 2 * n_inner < n_active) {
+                break;
+            }
+            if (inner) {
+                uint4 q0, q1;
+                if (top != nullptr && cur >= top_lo && cur < top_hi) {
+                    const uint4 *p = reinterpret_cast<const uint4 *>(top + (cur - top_lo));
+                    q0 = p[0];
+                    q1 = p[1];
+                } else {
+                    const uint4 *p = reinterpret_cast<const uint4 *>(sc.nodes + cur);
+                    q0 = p[0];
+                    q1 = p[1];
+                }
+                if (COUNTERS) {
+                    ++n_nodes;
+                }
+                // dwords: {lo0x|lo0y, lo0z|hi0x, hi0y|hi0z, lo1x|lo1y} {lo1z|hi1x, hi1y|hi1z, c0, c1}
+                float t0, t1;
+                const bool h0 = slab_q(q0.x & 0xffffu, q0.x >> 16, q0.y & 0xffffu, q0.y >> 16, q0.z & 0xffffu,
+                                       q0.z >> 16, qa, qb, tnear, hit.t, t0);
+                const bool h1 = slab_q(q0.w & 0xffffu, q0.w >> 16, q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu,
+                                       q1.y >> 16, qa, qb, tnear, hit.t, t1);
+                const int32_t c0 = (int32_t)q1.z, c1 = (int32_t)q1.w;
+                if (h0 && h1) {
+                    const bool first0 = t0 <= t1;
+                    st.push(first0 ? c1 : c0);
+                    cur = first0 ? c0 : c1;
+                } else if (h0) {
+                    cur = c0;
+                } else if (h1) {
+                    cur = c1;
+                } else {
+                    pop_next();
+                }
+            }
+        }
+
+        // ---- leaf phase: triangles, or entering an instance -----------------------------------
+        if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
+            const uint32_t x = ~(uint32_t)cur;
+            const uint32_t first = x >> 3;
+            if (TWO_LEVEL && !in_blas) {
+                const InstanceRec &in = sc.instances[first];
+                cur_inst = (int32_t)first;
+                if (!in.identity) {
+                    o = xfm_point(in.w2o, org);
+                    d = xfm_vector(in.w2o, dir);
+                }
+                set_frame(in.frame);
+                in_blas = true;
+                st.push(STACK_SENTINEL);
+                cur = in.blas_root;
+            } else {
+                const uint32_t count = (x & 7u) + 1u;
+                bool occluded = false;
+                for (uint32_t k = first; k < first + count; ++k) {
+                    const float4 *p = reinterpret_cast<const float4 *>(sc.tris + k);
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    if (COUNTERS) {
+                        ++n_tris;
+                    }
+                    float t, u, v;
+                    if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
+                        if (ANY_HIT) {
+                            occluded = true;
+                            break;
+                        }
+                        const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
+                        bool take = t < hit.t;
+                        if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
+                            take = cur_inst != hit.inst ? cur_inst < hit.inst
+                                                        : (geom != best_geom ? geom < best_geom : prim < best_prim);
+                        } else if (t == hit.t) {
+                            take = true; // first hit exactly at tfar
+                        }
+                        if (take) {
+                            hit.t = t;
+                            hit.u = u;
+                            hit.v = v;
+                            hit.tri = (int32_t)k;
+                            hit.inst = cur_inst;
+                            best_geom = geom;
+                            best_prim = prim;
+                        }
+                    }
+                }
+                if (ANY_HIT && occluded) {
+                    hit.tri = 0;
+                    hit.inst = cur_inst;
+                    hit.t = 0.f;
+                    cur = CUR_DONE;
+                } else {
+                    pop_next();
+                }
+            }
+        }
+
+        // ---- retire finished rays -------------------------------------------------------------
+        if (ray >= 0 && cur == CUR_DONE) {
+            src.store((uint32_t)ray, hit);
+            ray = -1;
         }
     }
 }

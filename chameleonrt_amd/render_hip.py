@@ -108,13 +108,14 @@ class RenderHIP:
 
     def bvh(self):
         nn, nt, ni, tl = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        frame = np.zeros(6, np.float32)
         core.check(self._ctx, self._lib.crt_hip_bvh_info(self._ctx, C.byref(nn), C.byref(nt), C.byref(ni),
-                                                         C.byref(tl)), "bvh_info")
-        nodes = np.zeros((nn.value, 16), np.float32)
+                                                         C.byref(tl), core.fptr(frame)), "bvh_info")
+        nodes = np.zeros((nn.value, 8), np.uint32)
         tris = np.zeros((nt.value, 12), np.float32)
         core.check(self._ctx, self._lib.crt_hip_bvh_copy(self._ctx, nodes.ctypes.data_as(C.c_void_p),
                                                          tris.ctypes.data_as(C.c_void_p)), "bvh_copy")
-        return dict(nodes=nodes, tris=tris, n_instances=ni.value, two_level=bool(tl.value))
+        return dict(nodes=nodes, tris=tris, n_instances=ni.value, two_level=bool(tl.value), frame=frame)
 
     # ---- multi-GPU tile assembly ---------------------------------------------------------
     def tile_buffer(self):

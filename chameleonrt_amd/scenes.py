@@ -104,14 +104,16 @@ def _finish(name, geoms, mat_ids, materials, textures, camera, spp) -> Scene:
 
 
 def _value_noise(rng, size, cells):
+    """Smooth value noise: random lattice, smoothstep-bilinear upsampling as two small matmuls."""
     g = rng.random((cells + 1, cells + 1)).astype(F)
     t = np.linspace(0, cells, size, endpoint=False, dtype=F)
     i = t.astype(np.int32)
     f = t - i
     f = f * f * (3 - 2 * f)
-    a = g[i][:, i] * (1 - f)[None, :] + g[i][:, i + 1] * f[None, :]
-    b = g[i + 1][:, i] * (1 - f)[None, :] + g[i + 1][:, i + 1] * f[None, :]
-    return a * (1 - f)[:, None] + b * f[:, None]
+    w = np.zeros((size, cells + 1), dtype=F)
+    w[np.arange(size), i] = 1 - f
+    w[np.arange(size), i + 1] = f
+    return (w @ g @ w.T).astype(F)
 
 
 def _color_texture(rng, size, channels=4) -> Image:
@@ -415,7 +417,7 @@ def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
     return mats
 
 
-def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per_tree: int = 2300,
+def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per_tree: int = 1900,
                    tex_size: int = 2048, n_tex: int = 64, n_mats: int = 128, detail: float = 1.0) -> Scene:
     """S4: courtyard with arcades, tiled floor, furniture and flattened foliage. Defaults give
     ~10 M triangles in one mesh (like the San Miguel OBJ), 128 materials covering every Disney

@@ -183,7 +183,8 @@ int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered_device_ptr, in
 /* ---- Diagnostic entry points used by the parity tests and the roofline bench ---- */
 
 /* Trace n arbitrary world-space rays through the scene with the production traversal
- * kernels. Host arrays. closest: out_t/out_u/out_v/out_inst/out_geom/out_prim (inst = -1
+ * kernels. Host arrays; tmin must hold one value for the whole batch (inside a frame it is 0
+ * for primary rays and EPSILON for all others, util.ih:8). closest: out_t/out_u/out_v/out_inst/out_geom/out_prim (inst = -1
  * on a miss). any-hit (closest == 0): out_t[i] = 1 if the segment (tmin, tmax] is
  * unoccluded else 0, other outputs may be NULL. */
 int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
@@ -198,11 +199,11 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
 int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_stride,
                 float *out, int out_stride);
 
-/* BVH introspection for tests: copy out the traversal arrays the kernels use. Pass NULL
- * buffers to query sizes. Nodes are 64-byte records, triangles 48-byte records
- * (DESIGN.md "Data layout in HBM"). */
+/* BVH introspection for tests: copy out the traversal arrays the kernels use. Nodes are
+ * 32-byte quantised records, triangles 48-byte records (DESIGN.md "Data layout in HBM");
+ * root_frame receives the 6 floats {base.xyz, step.xyz} of the root BVH's fixed-point frame. */
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,
-                     uint64_t *n_instances, int32_t *two_level);
+                     uint64_t *n_instances, int32_t *two_level, float *root_frame);
 int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris);
 
 #ifdef __cplusplus

@@ -1761,28 +1761,34 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 }
 
 // Foreign (product) BVH walk with the product's documented visit rule (DESIGN.md "Traversal
-// rule"): 64-byte nodes {lo0[3] hi0[3] lo1[3] hi1[3] c0 c1 pad pad}; c >= 0 inner node index;
-// c < 0 leaf with x = ~c, first = x >> 3, count = (x & 7) + 1; 48-byte triangle records.
+// rule"): 32-byte nodes {lo0[3] hi0[3] lo1[3] hi1[3] as uint16 fixed point, c0, c1}; a plane at
+// fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv); c >= 0 inner node
+// index; c < 0 leaf with x = ~c, first = x >> 3, count = (x & 7) + 1; 48-byte triangle records.
 namespace {
 struct FNode {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
-    int32_t c0, c1, pad0, pad1;
+    uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;
 };
 struct FTri {
     f3 v0, e1, e2;
     uint32_t geom, prim, pad;
 };
-static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48, "product BVH record sizes");
-inline bool fbox(const float lo[3], const float hi[3], f3 o, f3 inv, float tmin, float tmax, float &tn)
+static_assert(sizeof(FNode) == 32 && sizeof(FTri) == 48, "product BVH record sizes");
+inline bool fbox(const uint16_t lo[3], const uint16_t hi[3], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
-    const Box b{mk3(lo[0], lo[1], lo[2]), mk3(hi[0], hi[1], hi[2])};
-    return box_test(b, o, inv, tmin, tmax, tn);
+    const float t0x = std::fma((float)lo[0], qa.x, qb.x), t1x = std::fma((float)hi[0], qa.x, qb.x);
+    const float t0y = std::fma((float)lo[1], qa.y, qb.y), t1y = std::fma((float)hi[1], qa.y, qb.y);
+    const float t0z = std::fma((float)lo[2], qa.z, qb.z), t1z = std::fma((float)hi[2], qa.z, qb.z);
+    tn = std::fmax(std::fmax(std::fmin(t0x, t1x), std::fmin(t0y, t1y)), std::fmax(std::fmin(t0z, t1z), tmin));
+    const float tf = std::fmin(std::fmin(std::fmax(t0x, t1x), std::fmax(t0y, t1y)),
+                               std::fmin(std::fmax(t0z, t1z), tmax));
+    return tn <= tf * 1.0000004f;
 }
 } // namespace
 
 extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const void *tris_,
-                                     uint64_t n_tris, uint64_t n, const float *org, const float *dir,
-                                     const float *tmin, const float *tmax, int closest,
+                                     uint64_t n_tris, const float frame[6], uint64_t n, const float *org,
+                                     const float *dir, const float *tmin, const float *tmax, int closest,
                                      uint64_t *nodes_visited, uint64_t *tris_tested)
 {
     (void)n_nodes;
@@ -1794,6 +1800,8 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
         const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
         const f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
         const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        const f3 qa = mk3(frame[3] * inv.x, frame[4] * inv.y, frame[5] * inv.z);
+        const f3 qb = mk3((frame[0] - o.x) * inv.x, (frame[1] - o.y) * inv.y, (frame[2] - o.z) * inv.z);
         float best = tmax[i];
         int32_t stack[128];
         int sp = 0;
@@ -1804,8 +1812,8 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
                 const FNode &nd = nodes[cur];
                 ++nv;
                 float t0, t1;
-                const bool h0 = fbox(nd.lo0, nd.hi0, o, inv, tmin[i], best, t0);
-                const bool h1 = fbox(nd.lo1, nd.hi1, o, inv, tmin[i], best, t1);
+                const bool h0 = fbox(nd.lo0, nd.hi0, qa, qb, tmin[i], best, t0);
+                const bool h1 = fbox(nd.lo1, nd.hi1, qa, qb, tmin[i], best, t1);
                 if (h0 && h1) {
                     const bool first0 = t0 <= t1;
                     stack[sp++] = first0 ? nd.c1 : nd.c0;

@@ -62,11 +62,11 @@ int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, const float
                    float *out_t, float *out_u, float *out_v, int32_t *out_inst,
                    int32_t *out_geom, int32_t *out_prim, orc_stats *stats);
 
-/* Walk a FOREIGN BVH (the product's 64-byte nodes / 48-byte triangles) with the
- * product's documented visit rule and count nodes fetched / triangles tested, to
- * cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers. Single-level only. */
+/* Walk a FOREIGN BVH (the product's 32-byte quantised nodes + frame / 48-byte triangles,
+ * DESIGN.md) with the product's documented visit rule and count nodes fetched / triangles
+ * tested, to cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers. Single-level only. */
 int orc_count_foreign_bvh(const void *nodes, uint64_t n_nodes, const void *tris,
-                          uint64_t n_tris, uint64_t n, const float *org, const float *dir,
+                          uint64_t n_tris, const float frame[6], uint64_t n, const float *org, const float *dir,
                           const float *tmin, const float *tmax, int closest,
                           uint64_t *nodes_visited, uint64_t *tris_tested);
 

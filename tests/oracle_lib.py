@@ -45,7 +45,7 @@ def lib():
         L.orc_num_tiles.argtypes = [vp]
         L.orc_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                      i32p, i32p, i32p, C.POINTER(OrcStats)]
-        L.orc_count_foreign_bvh.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, fp, fp, fp, fp,
+        L.orc_count_foreign_bvh.argtypes = [vp, C.c_uint64, vp, C.c_uint64, fp, C.c_uint64, fp, fp, fp, fp,
                                             C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
         _LIB = L

@@ -110,7 +110,7 @@ def test_counters_match_oracle_walk_of_the_same_bvh(pair, oracle):
     nv, tt = C.c_uint64(), C.c_uint64()
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     rc = oracle.lib().orc_count_foreign_bvh(bvh["nodes"].ctypes.data_as(C.c_void_p), len(bvh["nodes"]),
-                                            bvh["tris"].ctypes.data_as(C.c_void_p), len(bvh["tris"]), n,
+                                            bvh["tris"].ctypes.data_as(C.c_void_p), len(bvh["tris"]), fp(bvh["frame"]), n,
                                             fp(org), fp(dirs), fp(tmin), fp(tmax), 1, C.byref(nv), C.byref(tt))
     assert rc == 0
     assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (nv.value, tt.value)
