@@ -368,7 +368,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, Sh
 // LDS atomic); whenever a buffer holds a full block's worth, SHADE_BLOCK entries leave for HBM
 // with ONE memory-side atomic and fully coalesced 1-KiB-per-wave stores. This keeps the queue
 // counters (a single word each) far below their ~88 atomics/us ceiling.
-constexpr int STAGE_CAP = 2 * SHADE_BLOCK;
+#ifndef CRT_SHADE_FLUSH
+#define CRT_SHADE_FLUSH 128 // staged entries that trigger a flush; LDS = (256 + this) * 23 * 4 B
+#endif
+#ifndef CRT_SHADE_WAVES
+#define CRT_SHADE_WAVES 4 // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int STAGE_CAP = SHADE_BLOCK + CRT_SHADE_FLUSH;
 struct ShadeStage {
     uint32_t next[11][STAGE_CAP]; // PathQueue fields in declaration order
     uint32_t a[12][STAGE_CAP];    // ShadowQueueA fields in declaration order
@@ -377,8 +383,9 @@ struct ShadeStage {
 static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 12 * sizeof(void *),
               "queue structs are arrays of field pointers");
 
-// Block-wide: while the staging buffer holds at least `threshold` entries, move up to
-// SHADE_BLOCK of them to the global SoA queue. Must be called by every thread of the block.
+// Block-wide: if the staging buffer holds at least `threshold` entries, move up to SHADE_BLOCK of
+// them to the global SoA queue (what is left is < threshold, so the buffer never overflows when
+// the next iteration appends up to SHADE_BLOCK more). Must be called by every thread of the block.
 template <int NF>
 CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &base_slot, uint32_t *global_counter,
                          uint32_t *const *fields, uint32_t threshold)
@@ -416,9 +423,9 @@ CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
+__global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
-                                                       PassCounters *pc, int bounce, int ablate)
+                                                       PassCounters *pc, int bounce)
 {
     __shared__ ShadeStage stage;
     if (threadIdx.x == 0) {
@@ -431,24 +438,27 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
-        bool is_hit = false, alive = false, has_b = false;
-        V3 hit_p = v3(0.f), light_dir = v3(0.f), w_i_b = v3(0.f), w_i = v3(0.f);
-        V3 c_a = v3(0.f), c_b = v3(0.f), tp = v3(0.f), tp_in = v3(0.f);
+        // Phase 1 (per lane): hit -> surface, next-event estimation (sample_direct_light, ispc:105-181).
+        // Its outputs are staged immediately (phase 2) so their registers are free again before the
+        // BSDF is sampled for the continuation ray (phase 3).
+        bool is_hit = false, has_b = false;
+        V3 hit_p = v3(0.f), normal = v3(0.f), w_o = v3(0.f), tp_in = v3(0.f);
+        V3 light_dir = v3(0.f), w_i_b = v3(0.f), c_a = v3(0.f), c_b = v3(0.f);
         float light_dist = 0.f, light_dist_b = 0.f;
         uint32_t path = 0, rng = 0;
+        Surface mat;
         if (valid) {
             const V3 o = v3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
             const V3 d = v3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
             path = qin.path[i];
             rng = qin.rng[i];
             tp_in = v3(qin.tp[0][i], qin.tp[1][i], qin.tp[2][i]);
-            tp = tp_in;
             const int32_t tri = hits.tri[i];
             float4 L = radiance[path];
             L.w += 1.f; // the closest-hit ray (REPORT_RAY_STATS, ispc:246-248)
             if (tri < 0) {
                 // ispc:258-262
-                const V3 m = tp * miss_color(d);
+                const V3 m = tp_in * miss_color(d);
                 L.x = L.x + m.x;
                 L.y = L.y + m.y;
                 L.z = L.z + m.z;
@@ -459,10 +469,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                 const float4 *tr = reinterpret_cast<const float4 *>(sc.tris + tri);
                 const float4 ta = tr[0], tb = tr[1], tc = tr[2];
                 const uint32_t geom = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
-                const V3 w_o = -d;
+                w_o = -d;
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
                 // hit.Ng = cross(e2, e1), instance-local, unnormalised
-                V3 normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
+                normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
                 V2 uv = v2(0.f, 0.f);
                 const GeomRec g = sc.geoms[in.geom_base + geom];
                 if (g.uv_base >= 0) { // ispc:277-285
@@ -479,14 +489,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                                      m[4] * normal.x + m[5] * normal.y + m[6] * normal.z,
                                      m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
                 }
-                Surface mat;
-                if (ablate & 1) {
-                    const float *pm = sc.materials;
-                    mat.base_color = v3(0.8f, 0.8f, 0.8f);
-                    mat.metallic = 0.f; mat.specular = 0.f; mat.roughness = 1.f; mat.specular_tint = 0.f; mat.anisotropy = 0.f;
-                    mat.sheen = 0.f; mat.sheen_tint = 0.f; mat.clearcoat = 0.f; mat.clearcoat_gloss = 0.f; mat.ior = 1.5f;
-                    mat.specular_transmission = pm[13] * 0.f;
-                } else
                 unpack_material(sc, mat, sc.materials + 16 * (size_t)sc.material_ids[in.mat_base + geom], uv);
                 if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
                     normal = -normal;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                     light_dir = unit(light_dir);
                     const float l_pdf = light_pdf(light, light_pos, light_dir);
                     const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
-                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS && !(ablate & 2)) {
+                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
                         const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
                         const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
                         c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
@@ -541,37 +543,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
                 L.x = L.x + poison.x;
                 L.y = L.y + poison.y;
                 L.z = L.z + poison.z;
-
-                // -- continue the path, ispc:313-335 --
-                // On the last iteration (`while (bounce < MAX_PATH_DEPTH)`) the sampled direction,
-                // throughput and roulette draw are never observed: skip them.
-                const int next_bounce = bounce + 1;
-                if (next_bounce < MAX_PATH_DEPTH) {
-                    float pdf;
-                    V3 bsdf;
-                    if (ablate & 4) {
-                        disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i);
-                        pdf = 1.f;
-                        bsdf = v3(0.3f);
-                    } else
-                    bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
-                    alive = !(pdf == 0.f || is_black(bsdf));
-                    if (alive) {
-                        tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
-                        if (next_bounce > 3) { // Russian roulette, ispc:327-335
-                            const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
-                            if (rng_nextf(rng) < qr) {
-                                alive = false;
-                            } else {
-                                tp = tp / (1.f - qr);
-                            }
-                        }
-                    }
-                }
             }
             radiance[path] = L;
         }
-        // ---- compaction -------------------------------------------------------------------
+
+        // Phase 2 (wave-uniform): stage the occlusion rays.
         // B rays are rare: straight to HBM with one atomic per wave that has any.
         const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce], has_b);
         if (has_b) {
@@ -594,9 +570,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
             sb.path[slot_b] = path;
             sb.vis_a[slot_b] = 0;
         }
-        // A rays and continuation rays go through the LDS staging buffers
         const uint32_t la = wave_append_lds(&stage.n_a, is_hit);
-        const uint32_t ln = wave_append_lds(&stage.n_next, alive);
         if (is_hit) {
             const V3 c = tp_in * c_a;
             stage.a[0][la] = __float_as_uint(hit_p.x);
@@ -612,6 +586,33 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
             stage.a[10][la] = path;
             stage.a[11][la] = has_b ? slot_b : 0xffffffffu;
         }
+
+        // Phase 3 (per lane): continue the path, ispc:313-335. On the last iteration
+        // (`while (bounce < MAX_PATH_DEPTH)`) the sampled direction, throughput and roulette
+        // draw are never observed: skipped.
+        bool alive = false;
+        V3 w_i = v3(0.f), tp = tp_in;
+        if (is_hit && bounce + 1 < MAX_PATH_DEPTH) {
+            V3 v_x, v_y;
+            ortho_basis(v_x, v_y, normal); // recomputed rather than kept live across phase 2
+            float pdf;
+            const V3 bsdf = disney_sample(mat, normal, w_o, v_x, v_y, rng, w_i, pdf);
+            alive = !(pdf == 0.f || is_black(bsdf));
+            if (alive) {
+                tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
+                if (bounce + 1 > 3) { // Russian roulette, ispc:327-335
+                    const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
+                    if (rng_nextf(rng) < qr) {
+                        alive = false;
+                    } else {
+                        tp = tp / (1.f - qr);
+                    }
+                }
+            }
+        }
+
+        // Phase 4 (wave-uniform): stage the continuation rays, flush full staging buffers.
+        const uint32_t ln = wave_append_lds(&stage.n_next, alive);
         if (alive) {
             stage.next[0][ln] = __float_as_uint(hit_p.x);
             stage.next[1][ln] = __float_as_uint(hit_p.y);
@@ -627,11 +628,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneView sc, PathQueue q
         }
         __syncthreads();
         flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa),
-                        SHADE_BLOCK);
+                        CRT_SHADE_FLUSH);
         flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
-                        reinterpret_cast<uint32_t *const *>(&qout), SHADE_BLOCK);
+                        reinterpret_cast<uint32_t *const *>(&qout), CRT_SHADE_FLUSH);
     }
-    // drain what is left (fewer than SHADE_BLOCK entries per queue)
+    // drain what is left (fewer than CRT_SHADE_FLUSH entries per queue)
     flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa), 1);
     flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
                     reinterpret_cast<uint32_t *const *>(&qout), 1);
@@ -920,9 +921,8 @@ void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueu
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce)
 {
-    static const int ablate = std::getenv("CRT_HIP_ABLATE") ? std::atoi(std::getenv("CRT_HIP_ABLATE")) : 0;
     k_shade<<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc,
-                                                                     bounce, ablate);
+                                                                     bounce);
 }
 
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
