@@ -351,7 +351,7 @@ void setup_queues(crt_hip_ctx *c)
         c->sb.tp[a] = f32();
     }
     c->sb.path = u32();
-    c->sb.vis_a = i32();
+    c->sb.reserved = i32();
     c->radiance = reinterpret_cast<float4 *>(base + k * cap);
     c->d_pc.alloc(sizeof(PassCounters));
     const uint64_t total_paths = total_slots * c->spp;
@@ -912,8 +912,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                              ctx->radiance, d_pc, b);
                 mark_end();
                 mark(1);
-                launch_trace_shadow_a(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
-                launch_trace_shadow_b(cfg, ctx->sv, ctx->sb, ctx->radiance, d_pc, b);
+                launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
                 mark_end();
             }
             mark(2);

@@ -26,11 +26,10 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
 // K3: hit shading: material unpack, NEE set-up, BSDF sampling, Russian roulette, compaction.
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce);
-// K4: any-hit traversal of the NEE shadow rays (A: light samples, B: BSDF samples).
-void launch_trace_shadow_a(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
-                           float4 *radiance, PassCounters *pc, int bounce);
-void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueB sb, float4 *radiance,
-                           PassCounters *pc, int bounce);
+// K4: any-hit traversal of the NEE occlusion rays (light sample, then the rare BSDF-sample ray of
+// the same hit, by the same lane).
+void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
+                         float4 *radiance, PassCounters *pc, int bounce);
 // K5: per-pixel sample sum, running mean over frames, sRGB8, ray statistics.
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
                        uint32_t n_slots, const float4 *radiance, float4 *accum, uint32_t *tile_fb,

@@ -229,13 +229,14 @@ struct ClosestSource {
         d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
         tfar = RAY_TFAR;
     }
-    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    CRT_DEV bool retire(uint32_t i, uint32_t &, const RayHit &h, V3 &, V3 &, float &, uint32_t &) const
     {
         hits.t[i] = h.t;
         hits.u[i] = h.u;
         hits.v[i] = h.v;
         hits.tri[i] = h.tri;
         hits.inst[i] = h.inst;
+        return false;
     }
 };
 
@@ -262,8 +263,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     }
 }
 
-// ---- K4 trace_shadow (A: light samples) ----------------------------------------------------------
-struct ShadowASource {
+// ---- K4 trace_shadow: the NEE occlusion rays of one bounce -------------------------------------
+// One queue item per hit (ShadowQueueA). Its first ray goes to the sampled light point
+// (ispc:131-153); the few hits whose BSDF sample also lands on the light carry a second ray in
+// ShadowQueueB (ispc:156-179), traced by the same lane right after the first. The lane then
+// evaluates  illum += tp * (cA*visA + cB*visB)  in the reference's order (ispc:117,151,175,301):
+// one thread per path and stream order between kernels, so no atomics on the radiance.
+struct ShadowSource {
     ShadowQueueA sa;
     ShadowQueueB sb;
     float4 *radiance;
@@ -273,78 +279,51 @@ struct ShadowASource {
         d = v3(sa.d[0][i], sa.d[1][i], sa.d[2][i]);
         tfar = sa.tmax[i];
     }
-    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    CRT_DEV bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const
     {
-        const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148
-        const int32_t bslot = sa.bslot[i];
-        if (bslot >= 0) {
-            sb.vis_a[bslot] = visible ? 1 : 0;
-        } else if (visible) {
-            // illum = illum + path_throughput * nee, nee = cA (ispc:151, 301)
-            const uint32_t p = sa.path[i];
-            float4 L = radiance[p];
-            L.x = L.x + sa.c[0][i];
-            L.y = L.y + sa.c[1][i];
-            L.z = L.z + sa.c[2][i];
-            radiance[p] = L;
+        const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148,174
+        const int32_t b = sa.bslot[i];
+        if (stage == 0) {
+            if (b < 0) {
+                if (visible) { // nee = cA
+                    const uint32_t p = sa.path[i];
+                    float4 L = radiance[p];
+                    L.x = L.x + sa.c[0][i];
+                    L.y = L.y + sa.c[1][i];
+                    L.z = L.z + sa.c[2][i];
+                    radiance[p] = L;
+                }
+                return false;
+            }
+            carry = visible ? 1u : 0u;
+            o = v3(sb.o[0][b], sb.o[1][b], sb.o[2][b]); // same origin, BSDF-sampled direction
+            d = v3(sb.d[0][b], sb.d[1][b], sb.d[2][b]);
+            tfar = sb.tmax[b];
+            stage = 1;
+            return true;
         }
-    }
-};
-
-template <bool TWO_LEVEL, bool COUNTERS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_a(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
-                                                                float4 *radiance, PassCounters *pc, int bounce)
-{
-    __shared__ TraceLds lds;
-    const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack st;
-    st.lds = &lds.stack[0][threadIdx.x];
-    st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    st.spill_stride = sc.spill_stride;
-    uint32_t n_nodes = 0, n_tris = 0;
-    const ShadowASource src{sa, sb, radiance};
-    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
-                                               src, n_nodes, n_tris);
-    if (COUNTERS) {
-        atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
-        atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
-    }
-}
-
-// ---- K4 trace_shadow (B: BSDF samples that hit the light) ---------------------------------------
-struct ShadowBSource {
-    ShadowQueueB sb;
-    float4 *radiance;
-    CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
-    {
-        o = v3(sb.o[0][i], sb.o[1][i], sb.o[2][i]);
-        d = v3(sb.d[0][i], sb.d[1][i], sb.d[2][i]);
-        tfar = sb.tmax[i];
-    }
-    CRT_DEV void store(uint32_t i, const RayHit &h) const
-    {
-        // sample_direct_light's return value (ispc:117,151,175): illum = 0; [illum = cA;] [illum += cB]
+        // sample_direct_light's return value: illum = 0; [illum = cA;] [illum = illum + cB]
         V3 nee = v3(0.f);
-        if (sb.vis_a[i]) {
-            nee = v3(sb.ca[0][i], sb.ca[1][i], sb.ca[2][i]);
+        if (carry) {
+            nee = v3(sb.ca[0][b], sb.ca[1][b], sb.ca[2][b]);
         }
-        if (h.tri < 0) {
-            nee = nee + v3(sb.cb[0][i], sb.cb[1][i], sb.cb[2][i]);
+        if (visible) {
+            nee = nee + v3(sb.cb[0][b], sb.cb[1][b], sb.cb[2][b]);
         }
-        const V3 add = v3(sb.tp[0][i], sb.tp[1][i], sb.tp[2][i]) * nee;
-        const uint32_t p = sb.path[i];
+        const V3 add = v3(sb.tp[0][b], sb.tp[1][b], sb.tp[2][b]) * nee;
+        const uint32_t p = sb.path[b];
         float4 L = radiance[p];
         L.x = L.x + add.x;
         L.y = L.y + add.y;
         L.z = L.z + add.z;
         radiance[p] = L;
+        return false;
     }
 };
 
 template <bool TWO_LEVEL, bool COUNTERS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, ShadowQueueB sb, float4 *radiance,
-                                                                PassCounters *pc, int bounce)
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
+                                                              float4 *radiance, PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;
     const QNode *top = stage_top_nodes(sc, lds);
@@ -354,8 +333,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow_b(SceneView sc, Sh
     st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
     st.spill_stride = sc.spill_stride;
     uint32_t n_nodes = 0, n_tris = 0;
-    const ShadowBSource src{sb, radiance};
-    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_b[bounce], &pc->cur_shadow_b[bounce], RAY_EPS,
+    const ShadowSource src{sa, sb, radiance};
+    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
                                                src, n_nodes, n_tris);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
@@ -568,7 +547,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             sb.tp[1][slot_b] = tp_in.y;
             sb.tp[2][slot_b] = tp_in.z;
             sb.path[slot_b] = path;
-            sb.vis_a[slot_b] = 0;
         }
         const uint32_t la = wave_append_lds(&stage.n_a, is_hit);
         if (is_hit) {
@@ -700,7 +678,7 @@ template <bool ANY_HIT> struct DiagSource {
         d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
         tfar = tmax[i];
     }
-    CRT_DEV void store(uint32_t i, const RayHit &h) const
+    CRT_DEV bool retire(uint32_t i, uint32_t &, const RayHit &h, V3 &, V3 &, float &, uint32_t &) const
     {
         if (ANY_HIT) {
             out_t[i] = h.tri < 0 ? 1.f : 0.f;
@@ -712,6 +690,7 @@ template <bool ANY_HIT> struct DiagSource {
             out_geom[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].geom;
             out_prim[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].prim;
         }
+        return false;
     }
 };
 
@@ -901,21 +880,12 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
             hits, pc, bounce);
 }
 
-void launch_trace_shadow_a(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
-                           float4 *radiance, PassCounters *pc, int bounce)
+void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
+                         float4 *radiance, PassCounters *pc, int bounce)
 {
-    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_a<false, false>, k_trace_shadow_a<false, true>,
-            k_trace_shadow_a<true, false>, k_trace_shadow_a<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa,
+    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow<false, false>, k_trace_shadow<false, true>,
+            k_trace_shadow<true, false>, k_trace_shadow<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa,
             sb, radiance, pc, bounce);
-}
-
-void launch_trace_shadow_b(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueB sb, float4 *radiance,
-                           PassCounters *pc, int bounce)
-{
-    // B rays are rare (BSDF sample must hit the light quad): a quarter-size grid is plenty
-    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow_b<false, false>, k_trace_shadow_b<false, true>,
-            k_trace_shadow_b<true, false>, k_trace_shadow_b<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sb,
-            radiance, pc, bounce);
 }
 
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,

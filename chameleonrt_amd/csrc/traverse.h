@@ -138,8 +138,12 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 }
 
 // Source: struct with
-//   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   ray i of the queue
-//   void store(uint32_t i, const RayHit &h) const;            its result (h.tri < 0: miss / unoccluded)
+//   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   first ray of queue item i
+//   bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const;
+//        consume a finished ray's result (h.tri < 0: miss / unoccluded). Returning true hands the
+//        lane a follow-up ray of the same item (o, d, tfar, stage updated): the two NEE occlusion
+//        rays of one hit are traced back to back by one lane, which costs nothing in a wave whose
+//        lanes are refilled independently.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
 CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris)
@@ -159,6 +163,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     int32_t cur_inst = 0;
     bool in_blas = !TWO_LEVEL;
     st.sp = 0;
+    uint32_t stage = 0, carry = 0; // multi-ray items (Source::retire)
     // wave-uniform pool of ray indices
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
@@ -168,6 +173,28 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         const V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
         qa = v3(f.step[0] * inv.x, f.step[1] * inv.y, f.step[2] * inv.z);
         qb = v3((f.base[0] - o.x) * inv.x, (f.base[1] - o.y) * inv.y, (f.base[2] - o.z) * inv.z);
+    };
+
+    // start traversing the world-space ray (org, dir, tfar)
+    auto begin_ray = [&]() {
+        o = org;
+        d = dir;
+        cur_inst = 0;
+        in_blas = !TWO_LEVEL;
+        if (!TWO_LEVEL) {
+            const InstanceRec &in = sc.instances[0];
+            if (!in.identity) {
+                o = xfm_point(in.w2o, org);
+                d = xfm_vector(in.w2o, dir);
+            }
+        }
+        set_frame(sc.root_frame);
+        hit.t = tfar;
+        hit.u = hit.v = 0.f;
+        hit.tri = -1;
+        hit.inst = -1;
+        st.sp = 0;
+        cur = sc.root;
     };
 
     // take the next reference off the stack (or finish); handles the instance-exit sentinel
@@ -216,24 +243,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     if (rank < take) {
                         ray = (int32_t)(pool_next + rank);
                         src.load((uint32_t)ray, org, dir, tfar);
-                        o = org;
-                        d = dir;
-                        cur_inst = 0;
-                        in_blas = !TWO_LEVEL;
-                        if (!TWO_LEVEL) {
-                            const InstanceRec &in = sc.instances[0];
-                            if (!in.identity) {
-                                o = xfm_point(in.w2o, org);
-                                d = xfm_vector(in.w2o, dir);
-                            }
-                        }
-                        set_frame(sc.root_frame);
-                        hit.t = tfar;
-                        hit.u = hit.v = 0.f;
-                        hit.tri = -1;
-                        hit.inst = -1;
-                        st.sp = 0;
-                        cur = sc.root;
+                        stage = 0;
+                        begin_ray();
                     }
                 }
                 pool_next += take;
@@ -352,8 +363,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
 
         // ---- retire finished rays -------------------------------------------------------------
         if (ray >= 0 && cur == CUR_DONE) {
-            src.store((uint32_t)ray, hit);
-            ray = -1;
+            if (src.retire((uint32_t)ray, stage, hit, org, dir, tfar, carry)) {
+                begin_ray();
+            } else {
+                ray = -1;
+            }
         }
     }
 }

@@ -34,7 +34,7 @@ struct HitBuf {
 
 // First NEE shadow ray of a hit (render_embree.ispc:131-153). c = throughput * contribution,
 // added to the path's radiance if the ray is unoccluded and the hit has no B ray. If the hit
-// also spawned a B ray, the visibility is handed to that entry instead (bslot).
+// also spawned a B ray (bslot >= 0), the same lane traces it next and resolves both.
 struct ShadowQueueA {
     float *o[3];
     float *d[3];
@@ -55,7 +55,7 @@ struct ShadowQueueB {
     float *cb[3];
     float *tp[3];
     uint32_t *path;
-    int32_t *vis_a; // written by the A kernel
+    int32_t *reserved;
 };
 
 struct PassCounters {
