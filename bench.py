@@ -25,9 +25,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-NODE_BYTES, TRI_BYTES = 64, 48
-QUEUE_BYTES_CLOSEST = 24 + 20  # o,d read + t,u,v,tri,inst written per ray
-QUEUE_BYTES_SHADOW = 28 + 16   # o,d,tmax read + path/bslot read, radiance RMW amortised
+NODE_BYTES, TRI_BYTES = 32, 48  # quantised BVH2 node / triangle record
+QUEUE_BYTES_CLOSEST = 24 + 20   # o,d read + t,u,v,tri,inst written per ray
+QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
 
 
 def parse():
@@ -183,11 +183,12 @@ def main():
                     "avg_launch_ms": round(ms / launches, 4)}
 
         rc = roof("k_trace_closest", bytes_closest, closest_rays, closest_ms)
-        rs = roof("k_trace_shadow_a+b", bytes_shadow, shadow_rays, shadow_ms)
+        rs = roof("k_trace_shadow", bytes_shadow, shadow_rays, shadow_ms)
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file) as f:
                 tr = json.load(f)
+            # measured HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
             rc["traffic"] = tr.get("k_trace_closest", {}).get(args.workload)
             rs["traffic"] = tr.get("k_trace_shadow", {}).get(args.workload)
         dom, other = (rc, rs) if closest_ms >= shadow_ms else (rs, rc)
