@@ -84,7 +84,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun the process group is used even for N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -97,25 +97,35 @@ def main():
     t_gen = time.time() - t0
     eye, cdir, up, fovy = camera_of(scene)
 
-    stream = torch.cuda.current_stream()
-    r = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, rank=rank, world=world, stream=stream.cuda_stream)
+    # a dedicated (non-default) torch stream: the legacy default stream serialises against every
+    # other stream of the process, which RCCL's internal streams do not like
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    own_stream = os.environ.get("CRT_BENCH_OWN_STREAM") == "1"
+    r = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, rank=rank, world=world,
+                  stream=None if own_stream else stream.cuda_stream)
     r.initialize(width, height)
     t0 = time.time()
     r.set_scene(scene)
     t_scene = time.time() - t0
     tile_view = None
-    if world > 1:
+    if dist:
         ptr, nbytes = r.tile_buffer()
         tile_view = wrap_device_buffer(ptr, nbytes)
 
     def step(frame):
         st = r.render(eye, cdir, up, fovy, frame == 0, False)
-        if world > 1:
+        if dist:
             gathered = multi_gpu.gather_tile_buffers(tile_view)
             if rank == 0:
                 r.assemble_tiles(gathered.data_ptr(), world, readback=False)
         return st
 
+    # keep the Python cyclic GC (tens of ms per full collection with torch imported) out of the
+    # timed region; the frame loop itself allocates almost nothing
+    import gc
+    gc.collect()
+    gc.disable()
     for f in range(args.warmup):
         step(f)
     if dist:
@@ -124,8 +134,13 @@ def main():
     t_start = time.perf_counter()
     rays = closest_rays = shadow_rays = 0
     closest_ms = shadow_ms = shade_ms = 0.0
+    dbg = os.environ.get("CRT_BENCH_DEBUG") == "1"
     for k in range(args.steps):
+        t_k = time.perf_counter()
         st = step(args.warmup + k)
+        if dbg and rank == 0:
+            print(f"step {k}: wall {(time.perf_counter() - t_k) * 1e3:.3f} ms, render_time {st.render_time_ms:.3f} ms, "
+                  f"kernels {st.closest_ms + st.shadow_ms + st.shade_ms:.3f} ms", file=sys.stderr)
         rays += st.rays
         closest_rays += st.closest_rays
         shadow_rays += st.shadow_rays
@@ -156,7 +171,7 @@ def main():
                        "spp_per_frame": spp, "triangles": scene.total_tris(), "textures": len(scene.textures),
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
-                                      (" + RCCL gather to rank 0 every step" if world > 1 else ""),
+                                      (" + RCCL gather to rank 0 every step" if dist else ""),
                        "scene_gen_s": round(t_gen, 2), "set_scene_s": round(t_scene, 2)},
         }
     # ---- roofline of the traversal kernels (rank 0's share; identical code on every rank) ----

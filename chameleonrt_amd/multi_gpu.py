@@ -38,8 +38,6 @@ def gather_tile_buffers(local, group=None, dst: int = 0):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
-        return local
     if rank == dst:
         import torch
         out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
