@@ -947,6 +947,9 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         st.rays = st.closest_rays + st.shadow_rays;
         if (std::getenv("CRT_HIP_DEBUG")) { // per-bounce queue sizes of the first pass
             const PassCounters &pc = ctx->h_pc[0];
+            std::fprintf(stderr, "[crt_hip] frame %u worst closest ray: %u nodes, o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) t %.9g\n",
+                         ctx->frame_id, pc.max_ray_nodes, pc.worst_ray[0], pc.worst_ray[1], pc.worst_ray[2], pc.worst_ray[3],
+                         pc.worst_ray[4], pc.worst_ray[5], pc.worst_ray[6]);
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", ctx->frame_id,
                              b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);
@@ -955,10 +958,14 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
         st.rays_per_second = (float)(st.rays / (st.render_time_ms * 1.0e-3));
         if (timing) {
+            const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
             for (const Span &sp : spans) {
                 float ms = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&ms, ctx->events[sp.a], ctx->events[sp.b]));
                 (sp.kind == 0 ? st.closest_ms : (sp.kind == 1 ? st.shadow_ms : st.shade_ms)) += ms;
+                if (dbg) {
+                    std::fprintf(stderr, "[crt_hip] frame %u span kind %d: %.3f ms\n", ctx->frame_id, sp.kind, ms);
+                }
             }
         }
         if (stats) {

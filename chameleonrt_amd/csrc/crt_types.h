@@ -101,7 +101,7 @@ struct SceneView {
     int32_t root;                 // TLAS root (two-level) or the single BLAS root
     uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly
     uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
-    int32_t *stack_spill;         // traversal-stack overflow slab, [depth][thread of the persistent grid]
+    int32_t *stack_spill;         // traversal-stack overflow slab, [wave of the persistent grid][depth][lane]
     uint32_t spill_stride;        // threads the slab was sized for
 };
 

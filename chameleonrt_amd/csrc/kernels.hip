@@ -249,14 +249,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    st.spill_stride = sc.spill_stride;
+    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+               (threadIdx.x & 63);
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
     const ClosestSource src{q, hits};
     trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
-                                                n_nodes, n_tris);
+                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(SceneView sc, Shad
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    st.spill_stride = sc.spill_stride;
+    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+               (threadIdx.x & 63);
     uint32_t n_nodes = 0, n_tris = 0;
     const ShadowSource src{sa, sb, radiance};
     trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
@@ -708,8 +708,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     TraversalStack st;
     st.lds = &lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    st.spill_stride = sc.spill_stride;
+    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+               (threadIdx.x & 63);
     uint32_t n_nodes = 0, n_tris = 0;
     const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
     trace_wavefront<ANY_HIT, TWO_LEVEL, true>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]), tmin, src,

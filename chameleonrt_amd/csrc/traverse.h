@@ -21,7 +21,8 @@ namespace crt {
 #define CRT_LDS_STACK 8
 #endif
 constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
-// Deeper entries go to an explicit HBM slab laid out [depth][thread] (coalesced across a wave).
+// Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
+// and compact per wave (14 KB), so deep traversals stay within a few pages.
 // Not a private array: scratch-backed kernels get their wave occupancy throttled by the
 // runtime's scratch ring, which cost this kernel most of its latency hiding.
 constexpr int SPILL_STACK = 64 - CRT_LDS_STACK;
@@ -36,22 +37,21 @@ struct RayHit {
 struct TraversalStack {
     int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
-    int32_t *spill; // this lane's column of the HBM part: entry k at spill[k * spill_stride]
-    uint32_t spill_stride;
+    int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
     int sp;
     CRT_DEV void push(int32_t x)
     {
         if (sp < LDS_STACK) {
             lds[sp * stride] = x;
         } else {
-            spill[(size_t)(sp - LDS_STACK) * spill_stride] = x;
+            spill[(sp - LDS_STACK) * 64] = x;
         }
         ++sp;
     }
     CRT_DEV int32_t pop()
     {
         --sp;
-        return sp < LDS_STACK ? lds[sp * stride] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
+        return sp < LDS_STACK ? lds[sp * stride] : spill[(sp - LDS_STACK) * 64];
     }
 };
 
@@ -65,6 +65,8 @@ CRT_DEV V3 xfm_vector(const float *m, V3 v)
     return v3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
               m[2] * v.x + m[6] * v.y + m[10] * v.z);
 }
+
+CRT_DEV float box_dir(float x) { return fabsf(x) < 1e-18f ? copysignf(1e-18f, x) : x; }
 
 // Slab test of one quantised child box. A plane at fixed-point coordinate q lies at
 // base + q*step, so its ray parameter is ((base + q*step) - o) * inv = q*qa + qb with
@@ -146,8 +148,10 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 //        lanes are refilled independently.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
 CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
-                             uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris)
+                             uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
+                             uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr)
 {
+    uint32_t ray_nodes = 0;
     // per-lane ray state
     int32_t ray = -1;
     int32_t cur = CUR_DONE;
@@ -169,8 +173,12 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     bool exhausted = false;
     const int32_t top_lo = sc.root, top_hi = sc.root + (int32_t)sc.n_top_nodes;
 
+    // Box tests use 1/d with |d| clamped to >= 1e-18 (sign kept): with an exactly zero component
+    // q*inf + (-inf) would be NaN for every plane of that axis and switch its culling off (one such
+    // ray then walks ~10^4 nodes). The clamp moves the ray by < 1e-15 inside any scene, far less
+    // than the boxes' one-quantum margin, so the test stays conservative. Triangles use the true d.
     auto set_frame = [&](const QFrame &f) {
-        const V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        const V3 inv = v3(1.f / box_dir(d.x), 1.f / box_dir(d.y), 1.f / box_dir(d.z));
         qa = v3(f.step[0] * inv.x, f.step[1] * inv.y, f.step[2] * inv.z);
         qb = v3((f.base[0] - o.x) * inv.x, (f.base[1] - o.y) * inv.y, (f.base[2] - o.z) * inv.z);
     };
@@ -279,6 +287,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 }
                 if (COUNTERS) {
                     ++n_nodes;
+                    ++ray_nodes;
                 }
                 // dwords: {lo0x|lo0y, lo0z|hi0x, hi0y|hi0z, lo1x|lo1y} {lo1z|hi1x, hi1y|hi1z, c0, c1}
                 float t0, t1;
@@ -363,6 +372,19 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
 
         // ---- retire finished rays -------------------------------------------------------------
         if (ray >= 0 && cur == CUR_DONE) {
+            if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
+                if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
+                    worst_ray[0] = org.x;
+                    worst_ray[1] = org.y;
+                    worst_ray[2] = org.z;
+                    worst_ray[3] = dir.x;
+                    worst_ray[4] = dir.y;
+                    worst_ray[5] = dir.z;
+                    worst_ray[6] = hit.t;
+                    worst_ray[7] = (float)ray_nodes;
+                }
+            }
+            ray_nodes = 0;
             if (src.retire((uint32_t)ray, stage, hit, org, dir, tfar, carry)) {
                 begin_ray();
             } else {

@@ -65,8 +65,9 @@ struct PassCounters {
     uint32_t cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
     uint32_t cur_shadow_a[MAX_PATH_DEPTH];
     uint32_t cur_shadow_b[MAX_PATH_DEPTH];
-    uint32_t pad;
+    uint32_t max_ray_nodes; // CRT_HIP_FLAG_COUNTERS: most node fetches spent on one ray, and that ray
     unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow; // CRT_HIP_FLAG_COUNTERS
+    float worst_ray[8];
 };
 
 } // namespace crt

@@ -411,8 +411,10 @@ def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
         if kind == 6:
             mat[7] = 0.3 + 0.6 * r.random()  # anisotropic
             mat[5] = 0.3
-        if kind == 7 and m % 16 == 7:
-            mat[13], mat[12], mat[5] = 0.9, 1.45, 0.05  # glass: specular_transmission > 0
+        # no specular_transmission here: the OBJ importer never produces it (util/scene.cpp:196 sets
+        # it to 0), and the reference's transmission lobe yields negative pdfs / inf throughput that
+        # would flood a benchmark image with NaNs. instanced_grove() keeps a glass material so the
+        # parity tests still cover that code path.
         mats.append(mat)
     return mats
 
@@ -420,8 +422,8 @@ def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
 def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per_tree: int = 1900,
                    tex_size: int = 2048, n_tex: int = 64, n_mats: int = 128, detail: float = 1.0) -> Scene:
     """S4: courtyard with arcades, tiled floor, furniture and flattened foliage. Defaults give
-    ~10 M triangles in one mesh (like the San Miguel OBJ), 128 materials covering every Disney
-    lobe, 64 textures."""
+    ~10 M triangles in one mesh (like the San Miguel OBJ), 128 materials (diffuse, metallic,
+    clear-coat, sheen, anisotropic; textured base colour and parameter maps), 64 textures."""
     rng = np.random.default_rng(seed)
     d = lambda n: max(2, int(round(n * math.sqrt(detail))))
     n_tc = n_tex * 3 // 4

@@ -1799,7 +1799,9 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
     for (uint64_t i = 0; i < n; ++i) {
         const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
         const f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-        const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        // the product clamps |d| to >= 1e-18 for the box tests (exactly zero components)
+        auto box_dir = [](float x) { return std::fabs(x) < 1e-18f ? std::copysign(1e-18f, x) : x; };
+        const f3 inv = mk3(1.f / box_dir(d.x), 1.f / box_dir(d.y), 1.f / box_dir(d.z));
         const f3 qa = mk3(frame[3] * inv.x, frame[4] * inv.y, frame[5] * inv.z);
         const f3 qb = mk3((frame[0] - o.x) * inv.x, (frame[1] - o.y) * inv.y, (frame[2] - o.z) * inv.z);
         float best = tmax[i];

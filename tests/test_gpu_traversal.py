@@ -93,6 +93,29 @@ def test_secondary_rays_from_surfaces(pair):
     assert np.array_equal(g["t"][h2].view(np.uint32), c["t"][h2].view(np.uint32))
 
 
+def test_axis_parallel_rays(pair):
+    """Rays with exactly zero direction components (1/d = inf): they occur about once per 2e7 rays
+    in a frame, must give the brute-force answer, and must not disable box culling (a regression
+    here made single rays walk 10^4 nodes)."""
+    r, o, sc = pair
+    org, _ = probe_rays(sc, 6000, seed=9)
+    rng = np.random.default_rng(10)
+    dirs = rng.normal(size=org.shape).astype(np.float32)
+    dirs[:2000, 0] = 0.0
+    dirs[2000:4000, 1] = 0.0
+    dirs[4000:, 2] = 0.0
+    dirs[::7, 1] = 0.0  # some with two zero components
+    dirs[dirs.sum(axis=1) == 0] = [1, 0, 0]
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    g = r.trace(org, dirs, 0.0, 1e20, closest=True)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    assert np.array_equal(g["prim"], c["prim"]) and np.array_equal(g["inst"], c["inst"])
+    hit = c["inst"] >= 0
+    assert np.array_equal(g["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    n_nodes, n_tris = r.bvh()["nodes"].shape[0], r.bvh()["tris"].shape[0]
+    assert g["stats"].closest_nodes / len(org) < max(64.0, 0.05 * n_nodes), "box culling is off for axis-parallel rays"
+
+
 def test_counters_match_oracle_walk_of_the_same_bvh(pair, oracle):
     """The instrumented kernel's node/triangle counts (roofline input) equal the oracle walking
     the product's own BVH arrays with the documented visit rule. Single-level scenes only."""
