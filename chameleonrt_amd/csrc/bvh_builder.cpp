@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -14,7 +15,8 @@ namespace crt {
 namespace {
 
 constexpr int N_BINS = 16;
-constexpr float NODE_COST = 1.0f; // SAH: cost of fetching+testing one node relative to one triangle
+// SAH: cost of fetching+testing one node relative to one triangle (CRT_BVH_NODE_COST overrides, tuning)
+static const float NODE_COST = std::getenv("CRT_BVH_NODE_COST") ? (float)std::atof(std::getenv("CRT_BVH_NODE_COST")) : 1.0f;
 constexpr size_t PARALLEL_MIN = 1 << 15;
 
 inline void box_reset(Aabb &b)

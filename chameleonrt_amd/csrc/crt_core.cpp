@@ -219,7 +219,7 @@ struct crt_hip_ctx {
     bool has_scene = false;
     uint32_t spp = 1;
     SceneView sv{};
-    DeviceBuffer d_spill;
+    DeviceBuffer d_spill, d_tri_uvs;
     DeviceBuffer d_nodes, d_tris, d_instances, d_geoms, d_indices, d_uvs, d_material_ids, d_materials, d_textures,
         d_texels, d_lights;
     uint64_t n_nodes = 0, n_tris = 0;
@@ -297,7 +297,7 @@ void setup_queues(crt_hip_ctx *c)
     const uint64_t slots_per_pass = std::max<uint64_t>(64, (cap / c->spp) / 64 * 64);
     cap = slots_per_pass * c->spp;
     c->capacity = cap;
-    const size_t n_fields = 2 * 11 + 5 + 12 + 18 + 4;
+    const size_t n_fields = 2 * 11 + 9 + 12 + 18 + 4;
     c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
     uint32_t *base = c->d_queue_mem.as<uint32_t>();
     size_t k = 0;
@@ -322,6 +322,10 @@ void setup_queues(crt_hip_ctx *c)
     c->hits.v = f32();
     c->hits.tri = i32();
     c->hits.inst = i32();
+    for (int a = 0; a < 3; ++a) {
+        c->hits.ng[a] = f32();
+    }
+    c->hits.mat = u32();
     for (int a = 0; a < 3; ++a) {
         c->sa.o[a] = f32();
     }
@@ -597,6 +601,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         const bool two_level = s->n_instances > 1;
         std::vector<QNode> nodes;
         std::vector<TriRec> tris;
+        std::vector<float> tri_uvs; // 6 per TriRec
         std::vector<QFrame> blas_frame(s->n_meshes);
         std::vector<int32_t> blas_root(s->n_meshes);
         std::vector<Aabb> blas_bounds(s->n_meshes);
@@ -634,7 +639,8 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             if (recs.empty()) {
                 throw std::runtime_error("mesh without triangles");
             }
-            built[m] = build_bvh(boxes.data(), boxes.size(), 4, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
+            static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 4;
+            built[m] = build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
                                  n_threads);
             if (built[m].max_depth > MAX_TRAVERSAL_DEPTH - 8) {
                 throw std::runtime_error("BVH too deep for the traversal stack");
@@ -642,8 +648,18 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             // triangles in leaf order
             const size_t tri_base = tris.size();
             tris.resize(tri_base + recs.size());
+            tri_uvs.resize(6 * tris.size(), 0.f);
             for (size_t i = 0; i < recs.size(); ++i) {
-                tris[tri_base + i] = recs[built[m].order[i]];
+                const TriRec &r = recs[built[m].order[i]];
+                tris[tri_base + i] = r;
+                const crt_geometry_desc &gd = s->geometries[md.first_geometry + r.geom];
+                if (gd.uvs) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
+                        tri_uvs[6 * (tri_base + i) + 2 * c] = gd.uvs[2 * (size_t)vi];
+                        tri_uvs[6 * (tri_base + i) + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
+                    }
+                }
             }
             blas_bounds[m] = built[m].bounds;
             blas_frame[m] = make_frame(built[m].bounds);
@@ -788,6 +804,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 
         upload(ctx->d_nodes, nodes, ctx->stream);
         upload(ctx->d_tris, tris, ctx->stream);
+        upload(ctx->d_tri_uvs, tri_uvs, ctx->stream);
         upload(ctx->d_instances, insts, ctx->stream);
         upload(ctx->d_geoms, geoms, ctx->stream);
         upload(ctx->d_indices, indices, ctx->stream);
@@ -804,6 +821,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         sv.nodes = ctx->d_nodes.as<QNode>();
         sv.root_frame = root_frame;
         sv.tris = ctx->d_tris.as<TriRec>();
+        sv.tri_uvs = ctx->d_tri_uvs.as<float>();
         sv.instances = ctx->d_instances.as<InstanceRec>();
         sv.geoms = ctx->d_geoms.as<GeomRec>();
         sv.indices = ctx->d_indices.as<uint32_t>();

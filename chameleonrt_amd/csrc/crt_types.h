@@ -88,7 +88,8 @@ struct SceneView {
     const TriRec *tris;
     const InstanceRec *instances;
     const GeomRec *geoms;
-    const uint32_t *indices;      // 3 per triangle
+    const float *tri_uvs;         // 6 floats per TriRec (uv of v0, v1, v2), same order as `tris`
+    const uint32_t *indices;      // 3 per triangle (kept for introspection; the hot path reads tri_uvs)
     const float *uvs;             // 2 per vertex
     const uint32_t *material_ids; // per instance per geomID
     const float *materials;       // 16 floats per material (14 used, MaterialParams order)

@@ -37,7 +37,7 @@ namespace crt {
 #define CRT_FETCH 64
 #endif
 #ifndef CRT_TRACE_BLOCKS_PER_CU
-#define CRT_TRACE_BLOCKS_PER_CU 8
+#define CRT_TRACE_BLOCKS_PER_CU 7
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
 constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (32 B each)
@@ -223,6 +223,9 @@ CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
 struct ClosestSource {
     PathQueue q;
     HitBuf hits;
+    const TriRec *tris;
+    const InstanceRec *instances;
+    const uint32_t *material_ids;
     CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
     {
         o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
@@ -236,6 +239,19 @@ struct ClosestSource {
         hits.v[i] = h.v;
         hits.tri[i] = h.tri;
         hits.inst[i] = h.inst;
+        if (h.tri >= 0) {
+            // Embree's hit.Ng (render_embree.ispc:269) and the material the reference looks up as
+            // materials[instance->material_ids[geomID]] (ispc:292-293). Resolved here, where the
+            // triangle and instance are still in cache and 8 waves/SIMD hide the latency, because in
+            // K3 each of these dependent gathers would lengthen its load chain by a level.
+            const float4 *tr = reinterpret_cast<const float4 *>(tris + h.tri);
+            const float4 ta = tr[0], tb = tr[1], tc = tr[2];
+            const V3 ng = cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)); // cross(e2, e1)
+            hits.ng[0][i] = ng.x;
+            hits.ng[1][i] = ng.y;
+            hits.ng[2][i] = ng.z;
+            hits.mat[i] = material_ids[instances[h.inst].mat_base + __float_as_uint(tc.y)];
+        }
         return false;
     }
 };
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
-    const ClosestSource src{q, hits};
+    const ClosestSource src{q, hits, sc.tris, sc.instances, sc.material_ids};
     trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
                                                 n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray);
     if (COUNTERS) {
@@ -445,22 +461,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 is_hit = true;
                 const float t = hits.t[i], bu = hits.u[i], bv = hits.v[i];
                 const InstanceRec &in = sc.instances[hits.inst[i]];
-                const float4 *tr = reinterpret_cast<const float4 *>(sc.tris + tri);
-                const float4 ta = tr[0], tb = tr[1], tc = tr[2];
-                const uint32_t geom = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+                const uint32_t mat_id = hits.mat[i];
                 w_o = -d;
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
-                // hit.Ng = cross(e2, e1), instance-local, unnormalised
-                normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
-                V2 uv = v2(0.f, 0.f);
-                const GeomRec g = sc.geoms[in.geom_base + geom];
-                if (g.uv_base >= 0) { // ispc:277-285
-                    const uint32_t *ix = sc.indices + 3 * ((size_t)g.index_base + prim);
-                    const float *uvb = sc.uvs + 2 * (size_t)g.uv_base;
-                    const V2 uva = v2(uvb[2 * ix[0]], uvb[2 * ix[0] + 1]);
-                    const V2 uvb_ = v2(uvb[2 * ix[1]], uvb[2 * ix[1] + 1]);
-                    const V2 uvc = v2(uvb[2 * ix[2]], uvb[2 * ix[2] + 1]);
-                    uv = (1.f - bu - bv) * uva + bu * uvb_ + bv * uvc;
+                // hit.Ng = cross(e2, e1), instance-local, unnormalised (written by K2)
+                normal = unit(v3(hits.ng[0][i], hits.ng[1][i], hits.ng[2][i]));
+                V2 uv;
+                { // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
+                  // triangle at set_scene; all zeros for a geometry without UVs, which interpolates
+                  // to the reference's uv = (0, 0)
+                    const float2 *tu = reinterpret_cast<const float2 *>(sc.tri_uvs + 6 * (size_t)tri);
+                    const float2 a = tu[0], b = tu[1], c = tu[2];
+                    uv = (1.f - bu - bv) * v2(a.x, a.y) + bu * v2(b.x, b.y) + bv * v2(c.x, c.y);
                 }
                 { // normal = normalize(transpose(world_to_object) * normal), ispc:288-290
                     const float *m = in.w2o;
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                                      m[4] * normal.x + m[5] * normal.y + m[6] * normal.z,
                                      m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
                 }
-                unpack_material(sc, mat, sc.materials + 16 * (size_t)sc.material_ids[in.mat_base + geom], uv);
+                unpack_material(sc, mat, sc.materials + 16 * (size_t)mat_id, uv);
                 if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
                     normal = -normal;
                 }

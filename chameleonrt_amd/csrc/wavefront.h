@@ -6,7 +6,7 @@
 //
 //   PathQueue (x2, ping-pong)  closest-hit rays of one bounce: origin, direction, path id,
 //                              RNG state, throughput                       11 dwords / ray
-//   HitBuf                     t, u, v, triangle record index, instance     5 dwords / ray
+//   HitBuf                     t, u, v, triangle index, instance, Ng, material 9 dwords / ray
 //   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray
 //   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare) 18 dwords / ray
 //   radiance                   float4 per path: rgb = radiance so far, w = rays traced
@@ -30,6 +30,8 @@ struct HitBuf {
     float *t, *u, *v;
     int32_t *tri; // index into SceneView::tris, -1 on a miss
     int32_t *inst;
+    float *ng[3];  // Embree's hit.Ng: cross(e2, e1) of the hit triangle (valid on a hit)
+    uint32_t *mat; // material id = instance->material_ids[hit.geomID] (valid on a hit)
 };
 
 // First NEE shadow ray of a hit (render_embree.ispc:131-153). c = throughput * contribution,
