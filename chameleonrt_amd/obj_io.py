@@ -1,0 +1,208 @@
+"""OBJ/MTL scene ingest for the headless harness.
+
+Follows what the reference's importer makes of an OBJ file (util/scene.cpp:94-228, which sits on
+tinyobjloader): every `o`/`g` group becomes one Geometry of ONE Mesh; vertices are re-indexed on
+unique (position, normal, uv) index triples in order of first use; the group's material is the
+material of its first face; one ParameterizedMesh, one identity Instance; Disney parameters from
+the MTL per scene.cpp:191-216 (quirk Q14: specular = clamp(Ns/500), roughness = 1 - specular,
+transmission forced to 0, `map_Kd` becomes an sRGB base-colour texture loaded flipped and forced
+to 4 channels, util/material.cpp:5-17, quirk Q13); faces without a material get the default
+DisneyMaterial (validate_materials, scene.cpp:935-958); one generated quad light (scene.cpp:218-227).
+
+`save_obj` writes a Scene of that shape back out, so the synthetic benchmark scenes can be fed to
+a real ChameleonRT build for cross-checking.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import numpy as np
+
+from .scene import (SRGB, Geometry, Image, Instance, Mesh, ParameterizedMesh, Scene, disney_material,
+                    obj_default_light, textured_param)
+
+
+def _parse_mtl(path: str) -> List[dict]:
+    mats: List[dict] = []
+    cur = None
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if not tok or tok[0].startswith("#"):
+                continue
+            if tok[0] == "newmtl":
+                cur = {"name": " ".join(tok[1:]), "Kd": (0.6, 0.6, 0.6), "Ns": 1.0, "map_Kd": ""}  # tinyobj defaults
+                mats.append(cur)
+            elif cur is not None:
+                if tok[0] == "Kd":
+                    cur["Kd"] = tuple(float(x) for x in tok[1:4])
+                elif tok[0] == "Ns":
+                    cur["Ns"] = float(tok[1])
+                elif tok[0] == "map_Kd":
+                    cur["map_Kd"] = tok[-1]
+    return mats
+
+
+def _load_texture(path: str, name: str) -> Image:
+    from PIL import Image as PILImage
+    im = PILImage.open(path).convert("RGBA")  # forced to 4 channels
+    a = np.asarray(im, dtype=np.uint8)[::-1].copy()  # stbi_set_flip_vertically_on_load(1)
+    return Image(a.shape[1], a.shape[0], 4, a, SRGB, name)
+
+
+def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int = 1) -> Scene:
+    base_dir = os.path.dirname(os.path.abspath(path))
+    positions: List[List[float]] = []
+    normals: List[List[float]] = []
+    texcoords: List[List[float]] = []
+    obj_materials: List[dict] = []
+    mat_index: Dict[str, int] = {}
+    shapes: List[dict] = []
+    cur = None
+    cur_mat = -1
+
+    def shape():
+        nonlocal cur
+        if cur is None:
+            cur = {"faces": [], "mats": []}
+            shapes.append(cur)
+        return cur
+
+    def resolve(i: int, n: int) -> int:
+        return i - 1 if i > 0 else n + i  # OBJ indices are 1-based; negative = relative
+
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if not tok or tok[0].startswith("#"):
+                continue
+            k = tok[0]
+            if k == "v":
+                positions.append([float(x) for x in tok[1:4]])
+            elif k == "vn":
+                normals.append([float(x) for x in tok[1:4]])
+            elif k == "vt":
+                texcoords.append([float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0])
+            elif k in ("o", "g"):
+                if cur is not None and not cur["faces"]:
+                    continue  # tinyobj does not emit empty shapes
+                cur = None
+            elif k == "mtllib":
+                for m in _parse_mtl(os.path.join(base_dir, tok[1])):
+                    mat_index[m["name"]] = len(obj_materials)
+                    obj_materials.append(m)
+            elif k == "usemtl":
+                cur_mat = mat_index.get(" ".join(tok[1:]), -1)
+            elif k == "f":
+                corners = []
+                for c in tok[1:]:
+                    parts = c.split("/")
+                    vi = resolve(int(parts[0]), len(positions))
+                    ti = resolve(int(parts[1]), len(texcoords)) if len(parts) > 1 and parts[1] else -1
+                    ni = resolve(int(parts[2]), len(normals)) if len(parts) > 2 and parts[2] else -1
+                    corners.append((vi, ni, ti))
+                s = shape()
+                for j in range(1, len(corners) - 1):  # triangulate as a fan
+                    s["faces"].append((corners[0], corners[j], corners[j + 1]))
+                    s["mats"].append(cur_mat)
+    shapes = [s for s in shapes if s["faces"]]
+    if not shapes:
+        raise ValueError(f"no faces in {path}")
+    pos = np.asarray(positions, np.float32)
+    tc = np.asarray(texcoords, np.float32) if texcoords else np.zeros((0, 2), np.float32)
+
+    geoms, material_ids = [], []
+    for s in shapes:
+        material_ids.append(s["mats"][0] if material_mode == "default" else -1)  # first face's material
+        remap: Dict[tuple, int] = {}
+        verts, uvs, tris = [], [], []
+        has_uv = False
+        for face in s["faces"]:
+            tri = []
+            for idx in face:
+                v = remap.get(idx)
+                if v is None:
+                    v = len(verts)
+                    remap[idx] = v
+                    verts.append(pos[idx[0]])
+                    if idx[2] >= 0:
+                        uvs.append(tc[idx[2]])
+                        has_uv = True
+                tri.append(v)
+            tris.append(tri)
+        if has_uv and len(uvs) != len(verts):
+            raise ValueError("OBJ group mixes vertices with and without texture coordinates")
+        geoms.append(Geometry(np.asarray(verts, np.float32), np.asarray(tris, np.uint32),
+                              np.asarray(uvs, np.float32) if has_uv else None))
+
+    sc = Scene(name=os.path.basename(path))
+    sc.meshes = [Mesh(geoms)]
+    sc.instances = [Instance(np.eye(4, dtype=np.float32).reshape(16), 0)]
+    sc.samples_per_pixel = samples_per_pixel
+    if material_mode == "default":
+        tex_ids: Dict[str, int] = {}
+        for m in obj_materials:
+            specular = float(np.clip(np.float32(m["Ns"]) / np.float32(500.0), 0.0, 1.0))
+            d = disney_material(base_color=m["Kd"], specular=specular,
+                                roughness=float(np.clip(np.float32(1.0) - np.float32(specular), 0.0, 1.0)),
+                                specular_transmission=0.0)
+            if m["map_Kd"]:
+                name = m["map_Kd"]
+                if name not in tex_ids:
+                    tex_ids[name] = len(sc.textures)
+                    sc.textures.append(_load_texture(os.path.join(base_dir, name.replace("\\", "/")), name))
+                d[0] = textured_param(tex_ids[name])
+            sc.materials.append(d)
+    # validate_materials: ids of -1 get one default material appended at the end
+    if any(m == -1 for m in material_ids):
+        default_id = len(sc.materials)
+        sc.materials.append(disney_material())
+        material_ids = [default_id if m == -1 else m for m in material_ids]
+    sc.parameterized_meshes = [ParameterizedMesh(0, material_ids)]
+    sc.lights = [obj_default_light()]
+    return sc
+
+
+def save_obj(scene: Scene, path: str) -> None:
+    """Write a single-mesh / identity-instance Scene as OBJ + MTL (+ PNG textures)."""
+    if len(scene.meshes) != 1 or len(scene.instances) != 1:
+        raise ValueError("save_obj handles the OBJ-shaped scenes only (one mesh, one instance)")
+    base_dir = os.path.dirname(os.path.abspath(path))
+    stem = os.path.splitext(os.path.basename(path))[0]
+    with open(os.path.join(base_dir, stem + ".mtl"), "w") as f:
+        for i, m in enumerate(scene.materials):
+            bits = int(np.asarray(m[0:1], np.float32).view(np.uint32)[0])
+            f.write(f"newmtl m{i}\n")
+            if bits & 0x80000000:
+                tid = bits & 0x1FFFFFFF
+                f.write("Kd 1 1 1\n" f"map_Kd {stem}_tex{tid}.png\n")
+            else:
+                f.write("Kd %.9g %.9g %.9g\n" % tuple(float(x) for x in m[0:3]))
+            f.write("Ns %.9g\n" % (float(m[4]) * 500.0))
+    if scene.textures:
+        from PIL import Image as PILImage
+        for t, im in enumerate(scene.textures):
+            a = np.asarray(im.img, np.uint8).reshape(im.height, im.width, im.channels)[::-1]
+            mode = {1: "L", 3: "RGB", 4: "RGBA"}[im.channels]
+            PILImage.fromarray(a[..., 0] if im.channels == 1 else a, mode).save(
+                os.path.join(base_dir, f"{stem}_tex{t}.png"))
+    mat_ids = scene.parameterized_meshes[0].material_ids
+    with open(path, "w") as f:
+        f.write(f"mtllib {stem}.mtl\n")
+        voff = toff = 1
+        for gi, g in enumerate(scene.meshes[0].geometries):
+            f.write(f"o shape{gi}\nusemtl m{mat_ids[gi]}\n")
+            for v in g.vertices:
+                f.write("v %.9g %.9g %.9g\n" % (float(v[0]), float(v[1]), float(v[2])))
+            if g.uvs is not None:
+                for uv in g.uvs:
+                    f.write("vt %.9g %.9g\n" % (float(uv[0]), float(uv[1])))
+            for tri in g.indices:
+                if g.uvs is not None:
+                    f.write("f %d/%d %d/%d %d/%d\n" % tuple(x for i in tri for x in (voff + int(i), toff + int(i))))
+                else:
+                    f.write("f %d %d %d\n" % tuple(voff + int(i) for i in tri))
+            voff += len(g.vertices)
+            if g.uvs is not None:
+                toff += len(g.uvs)

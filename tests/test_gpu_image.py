@@ -100,3 +100,22 @@ def test_errors_are_loud(hip_lib):
     with pytest.raises(core.CoreError):
         r.set_scene(sc)
     r.close()
+
+
+def test_cli_benchmark_and_validation_dumps(hip_lib, tmp_path, monkeypatch):
+    """The headless restatement of the reference app's frame loop (main.cpp:113-345): an OBJ file
+    through the importer, `-benchmark-frames`, `-validation` dumps and chameleonrt.png."""
+    import os
+    from PIL import Image as PILImage
+    from chameleonrt_amd import cli
+    from chameleonrt_amd.obj_io import save_obj
+    obj = os.path.join(tmp_path, "cornell.obj")
+    save_obj(scenes.cornell(), obj)
+    monkeypatch.chdir(tmp_path)
+    rc = cli.main(["hip", obj, "-img", "96", "64", "-spp", "2", "-benchmark-frames", "3", "-validation", "v_",
+                   "-eye", "0", "1", "3.4", "-center", "0", "1", "0", "-fov", "40"])
+    assert rc == 0
+    final = np.asarray(PILImage.open("chameleonrt.png"))
+    assert final.shape == (64, 96, 4) and (final[..., 3] == 255).all() and final[..., :3].max() > 0
+    frames = [np.asarray(PILImage.open(f"v_crt_hip-f{f}.png")) for f in (1, 2, 3)]
+    assert np.array_equal(frames[2], final) and not np.array_equal(frames[0], frames[2])

@@ -1,0 +1,77 @@
+"""CPU: OBJ/MTL ingest (util/scene.cpp:94-228 semantics) -- round trip of synthetic scenes, vertex
+re-indexing on (position, normal, uv) triples, first-face material, MTL -> Disney mapping (quirk
+Q14), texture flip + 4 channels (quirk Q13), default material for material-less groups."""
+import os
+
+import numpy as np
+
+from chameleonrt_amd import scenes
+from chameleonrt_amd.obj_io import load_obj, save_obj
+
+
+def _tri_soup(g):
+    return g.vertices[g.indices.reshape(-1)].reshape(-1, 3, 3)
+
+
+def test_round_trip_cornell(tmp_path):
+    sc = scenes.cornell()
+    p = os.path.join(tmp_path, "cornell.obj")
+    save_obj(sc, p)
+    ld = load_obj(p)
+    assert len(ld.meshes) == 1 and len(ld.instances) == 1 and len(ld.parameterized_meshes) == 1
+    assert ld.total_tris() == 34 and len(ld.meshes[0].geometries) == 7
+    assert ld.parameterized_meshes[0].material_ids == sc.parameterized_meshes[0].material_ids
+    for a, b in zip(sc.meshes[0].geometries, ld.meshes[0].geometries):
+        assert np.array_equal(_tri_soup(a), _tri_soup(b))
+    for a, b in zip(sc.materials, ld.materials):
+        assert np.allclose(a, b, atol=1e-7)
+    assert np.array_equal(ld.lights[0], sc.lights[0])  # the generated light of scene.cpp:218-227
+
+
+def test_textured_round_trip_and_uv_dedup(tmp_path):
+    sc = scenes.sponza_like(detail=0.01, tex_size=16)
+    p = os.path.join(tmp_path, "s.obj")
+    save_obj(sc, p)
+    ld = load_obj(p)
+    assert ld.total_tris() == sc.total_tris()
+    assert len(ld.textures) <= len(sc.textures) and all(t.channels == 4 and t.color_space == 1 for t in ld.textures)
+    for a, b in zip(sc.meshes[0].geometries[:10], ld.meshes[0].geometries[:10]):
+        assert np.array_equal(_tri_soup(a), _tri_soup(b))
+        assert np.array_equal(a.uvs[a.indices.reshape(-1)], b.uvs[b.indices.reshape(-1)])
+        assert len(b.vertices) <= len(a.vertices)
+    # texture survives: PNG written flipped, loaded flipped back
+    m0 = ld.materials[0]
+    bits = int(np.asarray(m0[0:1]).view(np.uint32)[0])
+    assert bits & 0x80000000
+    t_loaded = ld.textures[bits & 0x1FFFFFFF]
+    t_orig = sc.textures[int(np.asarray(sc.materials[0][0:1]).view(np.uint32)[0]) & 0x1FFFFFFF]
+    assert np.array_equal(np.asarray(t_loaded.img).reshape(-1), np.asarray(t_orig.img).reshape(-1))
+
+
+def test_hand_written_obj_semantics(tmp_path):
+    open(os.path.join(tmp_path, "m.mtl"), "w").write(
+        "newmtl shiny\nKd 0.2 0.4 0.6\nNs 250\n" "newmtl dull\nKd 1 0 0\nNs 0\n")
+    open(os.path.join(tmp_path, "t.obj"), "w").write(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+        "o quad\nusemtl shiny\nf 1 2 3 4\n"            # quad -> fan of 2 triangles, 4 shared vertices
+        "o mixed\nusemtl dull\nf 1 2 5\nusemtl shiny\nf -1 -2 -3\n"  # first face's material wins; negative indices
+        "g nomat_group\n" "g tail\nf 1 3 5\n")
+    sc = load_obj(os.path.join(tmp_path, "t.obj"))
+    g = sc.meshes[0].geometries
+    assert [x.num_tris() for x in g] == [2, 2, 1]
+    assert len(g[0].vertices) == 4 and np.array_equal(g[0].indices, [[0, 1, 2], [0, 2, 3]])
+    assert sc.parameterized_meshes[0].material_ids == [0, 1, 0]  # 'tail' inherits the current usemtl (shiny)
+    shiny = sc.materials[0]
+    assert np.allclose(shiny[0:3], [0.2, 0.4, 0.6]) and np.isclose(shiny[4], 0.5) and np.isclose(shiny[5], 0.5)
+    assert sc.materials[1][4] == 0 and sc.materials[1][5] == 1 and shiny[13] == 0
+    # f -1 -2 -3 = v5 v4 v3; v5 was already used by the first face of the group (re-indexing)
+    assert np.array_equal(g[1].vertices[2:5], [[0, 0, 1], [0, 1, 0], [1, 1, 0]])
+    assert np.array_equal(g[1].indices, [[0, 1, 2], [2, 3, 4]])
+
+
+def test_groups_without_material_get_the_default(tmp_path):
+    open(os.path.join(tmp_path, "n.obj"), "w").write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    sc = load_obj(os.path.join(tmp_path, "n.obj"))
+    assert sc.parameterized_meshes[0].material_ids == [0] and np.allclose(sc.materials[0][0:3], 0.9)
+    wd = load_obj(os.path.join(tmp_path, "n.obj"), material_mode="white_diffuse")
+    assert len(wd.materials) == 1 and wd.materials[0][5] == 1.0
