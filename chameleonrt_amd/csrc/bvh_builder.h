@@ -3,6 +3,7 @@
 // (reference backends/embree/embree_utils.cpp:63-76, 121-129); static scenes only, so the build
 // runs once per set_scene on the host cores and the result is uploaded to HBM.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 

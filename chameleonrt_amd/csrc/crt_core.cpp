@@ -561,7 +561,18 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
 int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 {
     return guarded(ctx, [&]() -> int {
+        const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
+        auto t_phase = std::chrono::high_resolution_clock::now();
+        auto phase = [&](const char *what) {
+            const auto now = std::chrono::high_resolution_clock::now();
+            if (dbg) {
+                std::fprintf(stderr, "[crt_hip] set_scene %-22s %8.1f ms\n", what,
+                             std::chrono::duration<double, std::milli>(now - t_phase).count());
+            }
+            t_phase = now;
+        };
         check_scene(s);
+        phase("validate");
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->frame_id = 0;
         ctx->has_scene = false;
@@ -597,6 +608,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             }
         }
 
+        phase("geometry tables");
         // one BLAS per Mesh (embree_utils.cpp:63-76)
         const bool two_level = s->n_instances > 1;
         std::vector<QNode> nodes;
@@ -612,10 +624,16 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             const crt_mesh_desc &md = s->meshes[m];
             std::vector<TriRec> recs;
             std::vector<Aabb> boxes;
+            {
+                uint64_t n_mesh_tris = 0; // reserve ONCE: growing per geometry re-copies everything each time
+                for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                    n_mesh_tris += s->geometries[md.first_geometry + k].n_triangles;
+                }
+                recs.reserve(n_mesh_tris);
+                boxes.reserve(n_mesh_tris);
+            }
             for (uint32_t k = 0; k < md.n_geometries; ++k) {
                 const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                recs.reserve(recs.size() + gd.n_triangles);
-                boxes.reserve(boxes.size() + gd.n_triangles);
                 for (uint64_t t = 0; t < gd.n_triangles; ++t) {
                     const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
                     const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
@@ -667,6 +685,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             blas_root[m] = (int32_t)tri_base; // temporarily: triangle base
         }
 
+        phase("leaf-order triangles");
         // instances + TLAS (embree_utils.cpp:90-104, 121-129)
         std::vector<InstanceRec> insts(s->n_instances);
         std::vector<uint32_t> material_ids;
@@ -756,6 +775,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             root_frame = blas_frame[mesh0];
         }
 
+        phase("TLAS + quantisation");
         // textures: sRGB -> linear in 8 bits, on the host, like the reference (render_embree.cpp:90-104)
         std::vector<TexRec> tex(s->n_textures);
         std::vector<uint8_t> texels;
@@ -802,6 +822,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         std::vector<float> lights((size_t)s->n_lights * 20);
         std::memcpy(lights.data(), s->lights, lights.size() * sizeof(float));
 
+        phase("textures");
         upload(ctx->d_nodes, nodes, ctx->stream);
         upload(ctx->d_tris, tris, ctx->stream);
         upload(ctx->d_tri_uvs, tri_uvs, ctx->stream);
@@ -814,6 +835,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         upload(ctx->d_textures, tex, ctx->stream);
         upload(ctx->d_texels, texels, ctx->stream);
         upload(ctx->d_lights, lights, ctx->stream);
+        phase("upload");
         ctx->n_nodes = nodes.size();
         ctx->n_tris = tris.size();
 
