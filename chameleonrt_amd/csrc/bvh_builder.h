@@ -30,4 +30,9 @@ struct BuiltBvh {
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
                    bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads);
 
+// Fixed-point frame of a BVH with bounds b, and the outward-rounded 32-byte form of a node in it
+// (crt_types.h QFrame / QNode): what the traversal kernels actually read.
+QFrame make_frame(const Aabb &b);
+QNode quantise(const BvhNode &n, const QFrame &f);
+
 } // namespace crt

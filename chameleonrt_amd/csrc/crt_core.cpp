@@ -159,44 +159,6 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
 constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // same macro as kernels.hip
 constexpr uint32_t MAX_TRAVERSAL_DEPTH = 60;
 
-// Fixed-point frame of a BVH with bounds b: 65531 quanta span the box, 2 quanta of margin on
-// either side absorb the outward rounding below.
-QFrame make_frame(const Aabb &b)
-{
-    QFrame f;
-    for (int a = 0; a < 3; ++a) {
-        const double ext = (double)b.hi[a] - (double)b.lo[a];
-        const double floor_step = (std::fabs((double)b.lo[a]) + std::fabs((double)b.hi[a])) * 1e-7 + 1e-30;
-        f.step[a] = (float)std::max(ext / 65531.0, floor_step);
-        f.base[a] = (float)((double)b.lo[a] - 2.0 * (double)f.step[a]);
-    }
-    return f;
-}
-
-// Outward-rounded 16-bit box: lo one quantum further down than floor(), hi one further up than
-// ceil(), so base + q*step (evaluated in fp32 on the device) still brackets the true box.
-QNode quantise(const BvhNode &n, const QFrame &f)
-{
-    QNode q;
-    auto lo = [&](float v, int a) {
-        const double x = std::floor(((double)v - (double)f.base[a]) / (double)f.step[a]) - 1.0;
-        return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
-    };
-    auto hi = [&](float v, int a) {
-        const double x = std::ceil(((double)v - (double)f.base[a]) / (double)f.step[a]) + 1.0;
-        return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
-    };
-    for (int a = 0; a < 3; ++a) {
-        q.lo0[a] = lo(n.lo0[a], a);
-        q.hi0[a] = hi(n.hi0[a], a);
-        q.lo1[a] = lo(n.lo1[a], a);
-        q.hi1[a] = hi(n.hi1[a], a);
-    }
-    q.c0 = n.c0;
-    q.c1 = n.c1;
-    return q;
-}
-
 } // namespace
 
 struct crt_hip_ctx {
