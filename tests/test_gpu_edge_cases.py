@@ -1,0 +1,83 @@
+"""GPU: edge cases of the render path against the oracle -- degenerate framebuffers, frames in
+which every ray misses (all later queues are empty), many samples per pixel, resize
+(`initialize` again, main.cpp:284-285) and scene replacement (`set_scene` again)."""
+import numpy as np
+import pytest
+
+from chameleonrt_amd import scenes
+from chameleonrt_amd.render_hip import RenderHIP
+from tests.parity import MAX_DIVERGED, camera_of, compare_images
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(r, o, e, d, u, fovy, frames=2):
+    for f in range(frames):
+        st = r.render(e, d, u, fovy, f == 0, True)
+        ost = o.render(e, d, u, fovy, f == 0)
+    diverged, mean_rel = compare_images(r.accum(), o.accum())
+    assert diverged <= max(MAX_DIVERGED, 1.5 / r.accum()[..., 0].size) and mean_rel <= 1e-4
+    assert abs(int(st.rays) - int(ost.rays)) <= max(4, int(2 * MAX_DIVERGED * ost.rays))
+    return st
+
+
+@pytest.mark.parametrize("size", [(1, 1), (1, 70), (65, 1), (63, 65), (129, 7)])
+def test_degenerate_framebuffers(size, oracle, hip_lib):
+    w, h = size
+    sc = scenes.cornell(spp=3)
+    r = RenderHIP()
+    r.initialize(w, h)
+    r.set_scene(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    _check(r, o, *camera_of(sc))
+    assert r.img.shape == (h, w) and (r.img.view(np.uint8).reshape(h, w, 4)[..., 3] == 255).all()
+    r.close()
+
+
+def test_every_ray_misses(oracle, hip_lib):
+    """Camera looking away from the scene: one closest-hit ray per sample, nothing else; the image
+    is the checkerboard miss shader (render_embree.ispc:184-196)."""
+    sc = scenes.cornell(spp=2)
+    w, h = 96, 80
+    r = RenderHIP()
+    r.initialize(w, h)
+    r.set_scene(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    e, d, u, fovy = camera_of(sc)
+    st = _check(r, o, e + np.float32([0, 0, 10]), -d, u, fovy)
+    assert int(st.rays) == w * h * 2 and int(st.shadow_rays) == 0
+    # 2 frames x 2 spp of values in {0.1, 0.5}: every pixel is a multiple of 0.1 in [0.1, 0.5]
+    a = r.accum()
+    assert a.min() >= 0.1 - 1e-6 and a.max() <= 0.5 + 1e-6 and np.abs(a * 10 - np.round(a * 10)).max() < 1e-4
+    r.close()
+
+
+def test_many_samples_per_pixel(oracle, hip_lib):
+    sc = scenes.cornell(spp=64)  # BASELINE config C5's spp
+    w, h = 48, 40
+    r = RenderHIP()
+    r.initialize(w, h)
+    r.set_scene(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    st = _check(r, o, *camera_of(sc), frames=1)
+    assert int(st.closest_rays) >= w * h * 64
+    assert r.ray_counts().max() > 255  # would not fit the reference's counters if they were 8-bit; 16-bit ok
+    r.close()
+
+
+def test_resize_and_scene_replacement(oracle, hip_lib):
+    sc1, sc2 = scenes.cornell(spp=1), scenes.instanced_grove()
+    r = RenderHIP()
+    r.initialize(64, 64)
+    r.set_scene(sc1)
+    e, d, u, fovy = camera_of(sc1)
+    r.render(e, d, u, fovy, True, False)
+    r.initialize(100, 50)  # window resize: new accumulation, same scene
+    assert r.frame_id() == 0
+    o = oracle.OracleRenderer(sc1, 100, 50)
+    _check(r, o, e, d, u, fovy)
+    r.set_scene(sc2)  # new scene on the same context (two-level, textures, different spp)
+    assert r.frame_id() == 0 and r.samples_per_pixel == sc2.samples_per_pixel
+    o2 = oracle.OracleRenderer(sc2, 100, 50)
+    _check(r, o2, *camera_of(sc2))
+    r.close()
