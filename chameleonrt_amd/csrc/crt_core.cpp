@@ -165,6 +165,12 @@ struct crt_hip_ctx {
     int device = 0;
     uint32_t flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // Occlusion rays of bounce b and closest-hit rays of bounce b+1 are independent: with overlap on,
+    // the occlusion launch goes to aux_stream so that its waves fill the CUs the other launch's tail
+    // leaves idle (and vice versa). It needs its own traversal-stack spill slab.
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false;
     int n_cus = 256;
     std::string name, err;
     int rank = 0, world = 1;
@@ -205,6 +211,11 @@ struct crt_hip_ctx {
         }
         if (h_pc) {
             (void)hipHostFree(h_pc);
+        }
+        if (aux_stream) {
+            (void)hipStreamDestroy(aux_stream);
+            (void)hipEventDestroy(ev_fork);
+            (void)hipEventDestroy(ev_join);
         }
         if (own_stream) {
             (void)hipStreamDestroy(own_stream);
@@ -433,6 +444,14 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         c->n_cus = prop.multiProcessorCount;
         c->name = std::string("HIP wavefront path tracer (") + prop.name + ", " + prop.gcnArchName + ")";
         HIP_CHECK(hipStreamCreate(&c->own_stream));
+        if (const char *e = std::getenv("CRT_HIP_OVERLAP")) {
+            c->overlap = std::atoi(e) != 0;
+        }
+        if (c->overlap) {
+            HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
         c->stream = c->own_stream;
     } catch (const HipError &err) {
         g_create_error = err.msg;
@@ -818,7 +837,8 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         sv.n_lights = s->n_lights;
         sv.n_instances = s->n_instances;
         sv.spill_stride = traversal_grid_threads(ctx->n_cus);
-        ctx->d_spill.alloc((size_t)sv.spill_stride * traversal_spill_depth() * sizeof(int32_t));
+        const size_t spill_words = (size_t)sv.spill_stride * traversal_spill_depth();
+        ctx->d_spill.alloc((ctx->overlap ? 2 : 1) * spill_words * sizeof(int32_t));
         sv.stack_spill = ctx->d_spill.as<int32_t>();
         sv.root = root;
         sv.two_level = two_level ? 1u : 0u;
@@ -895,6 +915,14 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             }
         };
 
+        // per-kernel-kind event spans need the serial schedule
+        const bool overlap = ctx->overlap && !timing;
+        LaunchCfg aux_cfg = cfg;
+        aux_cfg.stream = ctx->aux_stream;
+        SceneView aux_sv = ctx->sv;
+        if (overlap) {
+            aux_sv.stack_spill += (size_t)aux_sv.spill_stride * traversal_spill_depth();
+        }
         const auto t0 = std::chrono::high_resolution_clock::now();
         uint32_t pass = 0;
         for (uint64_t slot0 = 0; slot0 < total_slots; slot0 += slots_per_pass, ++pass) {
@@ -902,20 +930,37 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             const uint32_t n_paths = n_slots * ctx->spp;
             PassCounters *d_pc = ctx->d_pc.as<PassCounters>();
             HIP_CHECK(hipMemsetAsync(d_pc, 0, sizeof(PassCounters), ctx->stream));
+            if (cfg.counters) { // atomicMin targets start at all-ones
+                HIP_CHECK(hipMemsetAsync(d_pc->t_start, 0xff, 2 * MAX_PATH_DEPTH * sizeof(unsigned long long), ctx->stream));
+            }
             mark(2);
             launch_raygen(cfg, vp, d_tiles, (uint32_t)slot0, n_paths, ctx->q[0], ctx->radiance, d_pc);
             mark_end();
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
-                mark(0);
-                launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
-                mark_end();
+                if (!overlap || b == 0) {
+                    mark(0);
+                    launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
+                    mark_end();
+                }
                 mark(2);
                 launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
                              ctx->radiance, d_pc, b);
                 mark_end();
-                mark(1);
-                launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
-                mark_end();
+                if (overlap) {
+                    // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the main stream } -> shade(b+1)
+                    HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+                    HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+                    launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
+                    HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+                    if (b + 1 < MAX_PATH_DEPTH) {
+                        launch_trace_closest(cfg, ctx->sv, ctx->q[(b + 1) & 1], ctx->hits, d_pc, b + 1);
+                    }
+                    HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                } else {
+                    mark(1);
+                    launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
+                    mark_end();
+                }
             }
             mark(2);
             launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
@@ -952,6 +997,11 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             std::fprintf(stderr, "[crt_hip] frame %u worst closest ray: %u nodes, o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) t %.9g\n",
                          ctx->frame_id, pc.max_ray_nodes, pc.worst_ray[0], pc.worst_ray[1], pc.worst_ray[2], pc.worst_ray[3],
                          pc.worst_ray[4], pc.worst_ray[5], pc.worst_ray[6]);
+            for (int b = 0; b < MAX_PATH_DEPTH && (ctx->flags & CRT_HIP_FLAG_COUNTERS); ++b) {
+                std::fprintf(stderr, "[crt_hip] frame %u closest launch %d: %.1f us total, queue drained after %.1f us (tail %.0f%%)\n",
+                             ctx->frame_id, b, (pc.t_end[b] - pc.t_start[b]) / 100.0, (pc.t_drained[b] - pc.t_start[b]) / 100.0,
+                             100.0 * (double)(pc.t_end[b] - pc.t_drained[b]) / (double)(pc.t_end[b] - pc.t_start[b]));
+            }
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", ctx->frame_id,
                              b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     uint32_t n_nodes = 0, n_tris = 0;
     const ClosestSource src{q, hits, sc.tris, sc.instances, sc.material_ids};
     trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
-                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray);
+                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray, &pc->t_start[bounce]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);

@@ -149,8 +149,12 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
 CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
-                             uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr)
+                             uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
+                             unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */)
 {
+    if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
+        atomicMin(&t_marks[0], (unsigned long long)wall_clock64());
+    }
     uint32_t ray_nodes = 0;
     // per-lane ray state
     int32_t ray = -1;
@@ -238,6 +242,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     }
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n) {
+                        if (COUNTERS && t_marks != nullptr && !exhausted && tv_lane_id() == 0) {
+                            atomicMin(&t_marks[MAX_PATH_DEPTH], (unsigned long long)wall_clock64());
+                        }
                         exhausted = true;
                         pool_next = pool_end = 0;
                     } else {
@@ -261,6 +268,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         const uint64_t active_mask = __ballot(ray >= 0);
         if (active_mask == 0) {
             if (exhausted) {
+                if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
+                    atomicMax(&t_marks[2 * MAX_PATH_DEPTH], (unsigned long long)wall_clock64());
+                }
                 break;
             }
             continue;

@@ -70,6 +70,9 @@ struct PassCounters {
     uint32_t max_ray_nodes; // CRT_HIP_FLAG_COUNTERS: most node fetches spent on one ray, and that ray
     unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow; // CRT_HIP_FLAG_COUNTERS
     float worst_ray[8];
+    // CRT_HIP_FLAG_COUNTERS: wall-clock ticks (100 MHz) of the closest-hit launches: first wave start,
+    // first wave that found the queue empty, last wave end -- how much of a launch is tail
+    unsigned long long t_start[MAX_PATH_DEPTH], t_drained[MAX_PATH_DEPTH], t_end[MAX_PATH_DEPTH];
 };
 
 } // namespace crt
