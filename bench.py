@@ -25,7 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-NODE_BYTES, TRI_BYTES = 32, 48  # quantised BVH2 node / triangle record
+NODE_BYTES, TRI_BYTES = 64, 48  # quantised BVH4 node / triangle record
 QUEUE_BYTES_CLOSEST = 24 + 36   # o,d read + t,u,v,tri,inst,Ng,geomID written per ray
 QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
 

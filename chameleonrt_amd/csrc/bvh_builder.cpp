@@ -1,4 +1,4 @@
-// bvh_builder.cpp — parallel top-down binned-SAH BVH2 build + cache-aware node layout.
+// bvh_builder.cpp — parallel top-down binned-SAH build, collapse to 4-wide nodes, cache-aware node layout.
 #include "bvh_builder.h"
 
 #include <algorithm>
@@ -401,46 +401,84 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         out.order[i] = b.prims[i].id;
     }
     const int32_t n_tn = b.next.load();
-    // final index of every inner temp node: BFS for the first max_top_nodes, then DFS pre-order
-    // per remaining subtree (children of a node end up close to it in memory)
-    std::vector<int32_t> final_idx(n_tn, -1);
-    std::vector<int32_t> order; // temp node ids in final order
-    order.reserve(n_tn / 2 + 1);
     auto is_inner = [&](int32_t t) { return b.tn[t].left >= 0; };
-    std::vector<int32_t> pending;
+    auto half_area = [&](int32_t t) {
+        const Aabb &x = b.tn[t].box;
+        const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // Collapse the binary tree to BVH_WIDTH-wide nodes: the children of a wide node rooted at temp
+    // node t are t's two children, with the inner child of largest surface area (the one a ray is
+    // most likely to enter) replaced by its own two children until BVH_WIDTH slots are used.
+    struct Wide {
+        int32_t kid[BVH_WIDTH];
+        int n;
+    };
+    auto wide_children = [&](int32_t t) {
+        Wide w;
+        w.kid[0] = b.tn[t].left;
+        w.kid[1] = b.tn[t].right;
+        w.n = 2;
+        while (w.n < BVH_WIDTH) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int k = 0; k < w.n; ++k) {
+                if (is_inner(w.kid[k])) {
+                    const double a = half_area(w.kid[k]);
+                    if (a > best_area) {
+                        best_area = a;
+                        best = k;
+                    }
+                }
+            }
+            if (best < 0) {
+                break;
+            }
+            const int32_t x = w.kid[best];
+            w.kid[best] = b.tn[x].left; // keeps the expanded child's position, sibling goes last
+            w.kid[w.n++] = b.tn[x].right;
+        }
+        return w;
+    };
+    // final index of every wide node (keyed by the temp node it is rooted at): BFS for the first
+    // max_top_nodes, then DFS pre-order per remaining subtree (children of a node end up close to
+    // it in memory)
+    std::vector<int32_t> final_idx(n_tn, -1);
+    std::vector<int32_t> order;  // root temp node of every wide node, in final order
+    order.reserve(n_tn / 3 + 1);
+    uint32_t max_depth = 1;
     if (is_inner(root)) {
-        std::queue<int32_t> q;
-        q.push(root);
+        std::queue<std::pair<int32_t, uint32_t>> q;
+        q.push({root, 1u});
         while (!q.empty() && order.size() < max_top_nodes) {
-            const int32_t t = q.front();
+            const auto [t, dep] = q.front();
             q.pop();
             final_idx[t] = (int32_t)order.size();
             order.push_back(t);
-            if (is_inner(b.tn[t].left)) {
-                q.push(b.tn[t].left);
-            }
-            if (is_inner(b.tn[t].right)) {
-                q.push(b.tn[t].right);
+            max_depth = std::max(max_depth, dep);
+            const Wide w = wide_children(t);
+            for (int k = 0; k < w.n; ++k) {
+                if (is_inner(w.kid[k])) {
+                    q.push({w.kid[k], dep + 1});
+                }
             }
         }
         out.n_top = (uint32_t)order.size();
+        std::vector<std::pair<int32_t, uint32_t>> stack;
         while (!q.empty()) {
-            pending.push_back(q.front());
+            stack.push_back(q.front());
             q.pop();
-        }
-        std::vector<int32_t> stack;
-        for (int32_t sub : pending) {
-            stack.push_back(sub);
             while (!stack.empty()) {
-                const int32_t t = stack.back();
+                const auto [t, dep] = stack.back();
                 stack.pop_back();
                 final_idx[t] = (int32_t)order.size();
                 order.push_back(t);
-                if (is_inner(b.tn[t].right)) {
-                    stack.push_back(b.tn[t].right);
-                }
-                if (is_inner(b.tn[t].left)) {
-                    stack.push_back(b.tn[t].left);
+                max_depth = std::max(max_depth, dep);
+                const Wide w = wide_children(t);
+                for (int k = w.n - 1; k >= 0; --k) {
+                    if (is_inner(w.kid[k])) {
+                        stack.push_back({w.kid[k], dep + 1});
+                    }
                 }
             }
         }
@@ -455,39 +493,38 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         }
         return leaf_ref(c.first + item_base, c.count);
     };
-    auto set_box = [](float *lo, float *hi, const Aabb &bx) {
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = bx.lo[k];
-            hi[k] = bx.hi[k];
+    auto set_child = [&](BvhNode &nd, int k, int32_t t) {
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[k][a] = b.tn[t].box.lo[a];
+            nd.hi[k][a] = b.tn[t].box.hi[a];
         }
+        nd.c[k] = child_ref(t);
     };
-    uint32_t max_depth = 0;
-    for (int32_t t = 0; t < n_tn; ++t) {
-        max_depth = std::max(max_depth, b.tn[t].depth);
-    }
-    out.max_depth = max_depth;
-    phase("node order");
-    if (!is_inner(root)) {
-        // a single leaf: wrap it in one node listing it twice (the repeat loses every tie, so
-        // results are unchanged; far-away dummy boxes would not survive box quantisation)
+    auto empty_node = [] {
         BvhNode nd;
         std::memset(&nd, 0, sizeof(nd));
-        set_box(nd.lo0, nd.hi0, b.tn[root].box);
-        set_box(nd.lo1, nd.hi1, b.tn[root].box);
-        nd.c0 = nd.c1 = child_ref(root);
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            nd.c[k] = EMPTY_CHILD;
+        }
+        return nd;
+    };
+    out.max_depth = max_depth; // of the WIDE tree: a traversal stack holds < BVH_WIDTH entries per level
+    phase("node order");
+    if (!is_inner(root)) {
+        // a single leaf: one node with one used slot
+        BvhNode nd = empty_node();
+        set_child(nd, 0, root);
         out.nodes.push_back(nd);
         out.n_top = 1;
         return out;
     }
     out.nodes.resize(order.size());
     for (size_t i = 0; i < order.size(); ++i) {
-        const TNode &t = b.tn[order[i]];
-        BvhNode nd;
-        std::memset(&nd, 0, sizeof(nd));
-        set_box(nd.lo0, nd.hi0, b.tn[t.left].box);
-        set_box(nd.lo1, nd.hi1, b.tn[t.right].box);
-        nd.c0 = child_ref(t.left);
-        nd.c1 = child_ref(t.right);
+        const Wide w = wide_children(order[i]);
+        BvhNode nd = empty_node();
+        for (int k = 0; k < w.n; ++k) {
+            set_child(nd, k, w.kid[k]);
+        }
         out.nodes[i] = nd;
     }
     phase("emit nodes");
@@ -521,14 +558,14 @@ QNode quantise(const BvhNode &n, const QFrame &f)
         const double x = std::ceil(((double)v - (double)f.base[a]) / (double)f.step[a]) + 1.0;
         return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
     };
-    for (int a = 0; a < 3; ++a) {
-        q.lo0[a] = lo(n.lo0[a], a);
-        q.hi0[a] = hi(n.hi0[a], a);
-        q.lo1[a] = lo(n.lo1[a], a);
-        q.hi1[a] = hi(n.hi1[a], a);
+    for (int k = 0; k < BVH_WIDTH; ++k) {
+        for (int a = 0; a < 3; ++a) {
+            const bool used = n.c[k] != EMPTY_CHILD;
+            q.child[k].lo[a] = used ? lo(n.lo[k][a], a) : 0;
+            q.child[k].hi[a] = used ? hi(n.hi[k][a], a) : 0;
+        }
+        q.child[k].ref = n.c[k];
     }
-    q.c0 = n.c0;
-    q.c1 = n.c1;
     return q;
 }
 

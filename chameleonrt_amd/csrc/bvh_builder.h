@@ -1,4 +1,4 @@
-// bvh_builder.h — host-side binned-SAH BVH2 builder producing the 64-byte node layout the
+// bvh_builder.h — host-side binned-SAH builder: a binary SAH tree collapsed to the 4-wide nodes the
 // traversal kernels read (crt_types.h). Stands in for Embree's rtcCommitScene
 // (reference backends/embree/embree_utils.cpp:63-76, 121-129); static scenes only, so the build
 // runs once per set_scene on the host cores and the result is uploaded to HBM.
@@ -20,7 +20,7 @@ struct BuiltBvh {
     std::vector<uint32_t> order; // item ids in leaf order (leaf `first` indexes this array)
     uint32_t n_top = 0;
     Aabb bounds;
-    uint32_t max_depth = 0;
+    uint32_t max_depth = 0;      // levels of the wide tree (a single node = 1)
 };
 
 // boxes: one per item. Leaves hold at most max_leaf (<= 8) items.
@@ -30,7 +30,7 @@ struct BuiltBvh {
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
                    bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads);
 
-// Fixed-point frame of a BVH with bounds b, and the outward-rounded 32-byte form of a node in it
+// Fixed-point frame of a BVH with bounds b, and the outward-rounded 64-byte form of a node in it
 // (crt_types.h QFrame / QNode): what the traversal kernels actually read.
 QFrame make_frame(const Aabb &b);
 QNode quantise(const BvhNode &n, const QFrame &f);

@@ -153,11 +153,7 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
     return Vec3{v.x * c, v.y * c, v.z * c};
 }
 
-#ifndef CRT_MAX_TOP_NODES
-#define CRT_MAX_TOP_NODES 127
-#endif
-constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // same macro as kernels.hip
-constexpr uint32_t MAX_TRAVERSAL_DEPTH = 60;
+constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // kernels.h
 
 } // namespace
 
@@ -601,6 +597,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         std::vector<uint32_t> blas_top(s->n_meshes);
         // node 0.. are reserved for the TLAS when two_level so that the staged top levels are the TLAS's
         std::vector<BuiltBvh> built(s->n_meshes);
+        uint32_t blas_depth = 0, tlas_depth = 0; // levels of the wide trees
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
             const crt_mesh_desc &md = s->meshes[m];
             std::vector<TriRec> recs;
@@ -641,9 +638,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 4;
             built[m] = build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
                                  n_threads);
-            if (built[m].max_depth > MAX_TRAVERSAL_DEPTH - 8) {
-                throw std::runtime_error("BVH too deep for the traversal stack");
-            }
+            blas_depth = std::max(blas_depth, built[m].max_depth);
             // triangles in leaf order
             const size_t tri_base = tris.size();
             tris.resize(tri_base + recs.size());
@@ -715,9 +710,7 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         QFrame root_frame{};
         if (two_level) {
             BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, MAX_TOP_NODES_HOST, 1);
-            if (tlas.max_depth + 8 > MAX_TRAVERSAL_DEPTH / 2) {
-                throw std::runtime_error("TLAS too deep for the traversal stack");
-            }
+            tlas_depth = tlas.max_depth;
             root_frame = make_frame(tlas.bounds);
             for (const BvhNode &nd : tlas.nodes) {
                 nodes.push_back(quantise(nd, root_frame));
@@ -735,13 +728,21 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
                     const uint32_t x = ~(uint32_t)c;
                     return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
                 };
-                nd.c0 = rebase(nd.c0);
-                nd.c1 = rebase(nd.c1);
+                for (int k = 0; k < BVH_WIDTH; ++k) {
+                    if (nd.c[k] != EMPTY_CHILD) {
+                        nd.c[k] = rebase(nd.c[k]);
+                    }
+                }
                 nodes.push_back(quantise(nd, blas_frame[m]));
             }
             blas_root[m] = node_base;
             blas_top[m] = built[m].n_top;
             built[m] = BuiltBvh();
+        }
+        // a ray's stack holds at most BVH_WIDTH-1 pending siblings per level of the path it is on,
+        // plus the instance-exit sentinel
+        if ((BVH_WIDTH - 1) * (blas_depth + tlas_depth) + 1 > traversal_stack_capacity()) {
+            throw std::runtime_error("BVH too deep for the traversal stack");
         }
         if (tris.size() >= (1u << 28)) {
             throw std::runtime_error("too many triangles for the 28-bit leaf reference");

@@ -10,15 +10,18 @@ namespace crt {
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
 //                              BLAS: triangles [first, first+count) of Scene::tris
 //                              TLAS: instance `first` (count is 1)
-// BvhNode is what the host builder produces (full-precision boxes of BOTH children); the
-// traversal kernels read the 32-byte quantised form below.
+//                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children
+// The BVH is 4-wide: traversal is a chain of dependent node fetches whose latency, not bytes or
+// box-test ALU, bounds incoherent rays on MI355X (DESIGN.md "Traversal"), and a 4-wide node about
+// halves the length of that chain. BvhNode is what the host builder produces (full-precision
+// boxes of all children); the traversal kernels read the 64-byte quantised form below.
+constexpr int BVH_WIDTH = 4;
+constexpr int32_t EMPTY_CHILD = (int32_t)0x80000002;
 struct alignas(16) BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t c0, c1;
-    int32_t pad0, pad1;
+    float lo[BVH_WIDTH][3], hi[BVH_WIDTH][3];
+    int32_t c[BVH_WIDTH];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 112, "BvhNode must be 112 bytes");
 
 // Fixed-point frame of one BVH: world/object coordinate = base + q * step, q in [0, 65535].
 struct QFrame {
@@ -26,17 +29,19 @@ struct QFrame {
     float step[3];
 };
 
-// One BVH2 node as the kernels see it: 32 B = 2 x dwordx4 per lane. Both children's AABBs as
-// 16-bit fixed point in the BVH's QFrame, rounded OUTWARD by at least one quantum (conservative:
-// a box may only grow, so no hit can be missed; which triangle wins never depends on the boxes).
-// Halving the node halves the traffic through the per-CU vector-memory pipeline, which is what
-// bounds incoherent traversal on MI355X (TA busy ~85 % with 64-byte nodes, profiles/).
-struct alignas(16) QNode {
-    uint16_t lo0[3], hi0[3];
-    uint16_t lo1[3], hi1[3];
-    int32_t c0, c1;
+// One BVH4 node as the kernels see it: 64 B = 4 x dwordx4 per lane, one 16-byte quarter per child:
+// its AABB as 16-bit fixed point in the BVH's QFrame, rounded OUTWARD by at least one quantum
+// (conservative: a box may only grow, so no hit can be missed; which triangle wins never depends
+// on the boxes), and its reference. 64 B per 4 children is 2/3 of the bytes the same tree took as
+// 32-byte binary nodes.
+struct alignas(16) QChild {
+    uint16_t lo[3], hi[3];
+    int32_t ref;
 };
-static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
+struct alignas(16) QNode {
+    QChild child[BVH_WIDTH];
+};
+static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 
 // One triangle = 48 B; 3 x dwordx4. Embree-style precomputed edges:
 // e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1). geom = Embree geomID (position of the

@@ -7,6 +7,12 @@
 
 namespace crt {
 
+// BFS-ordered top BVH levels the traversal kernels stage in LDS (64 B each; 85 = 4 full levels of
+// the 4-wide tree). The builder is asked for this many nodes in BFS order.
+#ifndef CRT_MAX_TOP_NODES
+#define CRT_MAX_TOP_NODES 85
+#endif
+
 struct LaunchCfg {
     hipStream_t stream;
     int n_cus;      // compute units of the device (grid sizing)
@@ -16,6 +22,7 @@ struct LaunchCfg {
 // Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).
 uint32_t traversal_grid_threads(int n_cus);
 uint32_t traversal_spill_depth();
+uint32_t traversal_stack_capacity(); // entries a ray may have pending (LDS part + slab part)
 
 // K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.
 void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,

@@ -5,7 +5,7 @@
 // executes ONE stage for 64 different paths:
 //
 //   K1 raygen         pixel-sample -> primary ray                       (ispc:213-232)
-//   K2 trace_closest  BVH2 traversal + triangle test, closest hit       (rtcIntersectV, ispc:245)
+//   K2 trace_closest  BVH4 traversal + triangle test, closest hit       (rtcIntersectV, ispc:245)
 //   K3 shade          hit -> material, NEE set-up, BSDF sample, RR      (ispc:251-335)
 //   K4 trace_shadow   any-hit traversal of NEE rays                     (rtcOccludedV, ispc:144,170)
 //   K5 accumulate     sample sum, running mean, sRGB8                   (ispc:339-353, 358-370)
@@ -30,9 +30,6 @@ namespace crt {
 #ifndef CRT_TRACE_BLOCK
 #define CRT_TRACE_BLOCK 256
 #endif
-#ifndef CRT_MAX_TOP_NODES
-#define CRT_MAX_TOP_NODES 127
-#endif
 #ifndef CRT_FETCH
 #define CRT_FETCH 64
 #endif
@@ -40,7 +37,7 @@ namespace crt {
 #define CRT_TRACE_BLOCKS_PER_CU 7
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
-constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (32 B each)
+constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each; 85 = 4 full levels)
 constexpr int SHADE_BLOCK = 256;
 
 // ---- wave-level helpers (wave64) -------------------------------------------------------------
@@ -212,7 +209,7 @@ CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
     const uint32_t n = min(sc.n_top_nodes, (uint32_t)MAX_TOP_NODES);
     const float4 *src = reinterpret_cast<const float4 *>(sc.nodes + sc.root);
     float4 *dst = reinterpret_cast<float4 *>(lds.top);
-    for (uint32_t i = threadIdx.x; i < n * 2; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x) {
         dst[i] = src[i];
     }
     __syncthreads();
@@ -856,6 +853,7 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 // ---- launchers ---------------------------------------------------------------------------------
 uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
 uint32_t traversal_spill_depth() { return (uint32_t)SPILL_STACK; }
+uint32_t traversal_stack_capacity() { return (uint32_t)(LDS_STACK + SPILL_STACK); }
 
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
 static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)

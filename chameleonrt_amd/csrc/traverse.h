@@ -1,4 +1,4 @@
-// traverse.h — BVH2 traversal + ray/triangle intersection for gfx950 (the Embree stand-in).
+// traverse.h — BVH4 traversal + ray/triangle intersection for gfx950 (the Embree stand-in).
 //
 // Replaces what the reference gets from rtcIntersectV / rtcOccludedV (call sites
 // backends/embree/render_embree.ispc:245, :144, :170). Semantics (DESIGN.md
@@ -9,9 +9,9 @@
 //   * closest hit = lexicographic min of (t, inst, geom, prim) -> independent of visit order
 //   * occluded = any valid hit
 // Boxes are tested with a conservative slab test (exit widened by 2 ulp, NaN-ignoring
-// min/max), children visited nearest-entry first, far child pushed on a per-lane stack whose
-// first LDS_STACK entries live in LDS ([depth][lane] so a wave's accesses are conflict-free)
-// and the rest in an HBM slab.
+// min/max), the children of a 4-wide node visited nearest-entry first, the others pushed
+// farthest first on a per-lane stack whose first LDS_STACK entries live in LDS ([depth][lane] so
+// a wave's accesses are conflict-free) and the rest in an HBM slab.
 #pragma once
 #include "pt_device.h"
 
@@ -22,10 +22,10 @@ namespace crt {
 #endif
 constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
-// and compact per wave (14 KB), so deep traversals stay within a few pages.
+// and compact per wave (22 KB), so deep traversals stay within a few pages.
 // Not a private array: scratch-backed kernels get their wave occupancy throttled by the
 // runtime's scratch ring, which cost this kernel most of its latency hiding.
-constexpr int SPILL_STACK = 64 - CRT_LDS_STACK;
+constexpr int SPILL_STACK = 96 - CRT_LDS_STACK;
 constexpr int32_t STACK_SENTINEL = (int32_t)0x80000000; // marks "leave instance" (two-level)
 
 struct RayHit {
@@ -81,6 +81,15 @@ CRT_DEV bool slab_q(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint
     tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
     return tn <= tf * 1.0000004f;
+}
+
+// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront).
+CRT_DEV uint32_t child_key(const uint4 k, uint32_t slot, V3 qa, V3 qb, float tmin, float tmax)
+{
+    float tn;
+    const bool hit = slab_q(k.x & 0xffffu, k.x >> 16, k.y & 0xffffu, k.y >> 16, k.z & 0xffffu, k.z >> 16, qa, qb, tmin,
+                            tmax, tn);
+    return hit && (int32_t)k.w != EMPTY_CHILD ? ((__float_as_uint(tn) & 0x7ffffffcu) | slot) : 0xffffffffu;
 }
 
 CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D, float tnear, float tfar,
@@ -285,37 +294,51 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 break;
             }
             if (inner) {
-                uint4 q0, q1;
-                if (top != nullptr && cur >= top_lo && cur < top_hi) {
-                    const uint4 *p = reinterpret_cast<const uint4 *>(top + (cur - top_lo));
-                    q0 = p[0];
-                    q1 = p[1];
-                } else {
-                    const uint4 *p = reinterpret_cast<const uint4 *>(sc.nodes + cur);
-                    q0 = p[0];
-                    q1 = p[1];
+                // one 16-byte quarter per child: {lox|loy, loz|hix, hiy|hiz, ref}
+                uint4 k0, k1, k2, k3;
+                {
+                    const uint4 *p = (top != nullptr && cur >= top_lo && cur < top_hi)
+                                         ? reinterpret_cast<const uint4 *>(top + (cur - top_lo))
+                                         : reinterpret_cast<const uint4 *>(sc.nodes + cur);
+                    k0 = p[0];
+                    k1 = p[1];
+                    k2 = p[2];
+                    k3 = p[3];
                 }
                 if (COUNTERS) {
                     ++n_nodes;
                     ++ray_nodes;
                 }
-                // dwords: {lo0x|lo0y, lo0z|hi0x, hi0y|hi0z, lo1x|lo1y} {lo1z|hi1x, hi1y|hi1z, c0, c1}
-                float t0, t1;
-                const bool h0 = slab_q(q0.x & 0xffffu, q0.x >> 16, q0.y & 0xffffu, q0.y >> 16, q0.z & 0xffffu,
-                                       q0.z >> 16, qa, qb, tnear, hit.t, t0);
-                const bool h1 = slab_q(q0.w & 0xffffu, q0.w >> 16, q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu,
-                                       q1.y >> 16, qa, qb, tnear, hit.t, t1);
-                const int32_t c0 = (int32_t)q1.z, c1 = (int32_t)q1.w;
-                if (h0 && h1) {
-                    const bool first0 = t0 <= t1;
-                    st.push(first0 ? c1 : c0);
-                    cur = first0 ? c0 : c1;
-                } else if (h0) {
-                    cur = c0;
-                } else if (h1) {
-                    cur = c1;
-                } else {
+                // Visit order: children whose box the ray enters, nearest entry first. The sort key
+                // is the entry distance with its two lowest mantissa bits replaced by the child
+                // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
+                // the slot makes keys distinct and breaks ties towards the lower slot); children
+                // that are missed, or unused slots, get the all-ones key.
+                const uint32_t s0 = child_key(k0, 0u, qa, qb, tnear, hit.t);
+                const uint32_t s1 = child_key(k1, 1u, qa, qb, tnear, hit.t);
+                const uint32_t s2 = child_key(k2, 2u, qa, qb, tnear, hit.t);
+                const uint32_t s3 = child_key(k3, 3u, qa, qb, tnear, hit.t);
+                // 5-comparator sorting network
+                const uint32_t a0 = min(s0, s1), a1 = max(s0, s1), a2 = min(s2, s3), a3 = max(s2, s3);
+                const uint32_t b0 = min(a0, a2), b2 = max(a0, a2), b1 = min(a1, a3), b3 = max(a1, a3);
+                const uint32_t c1 = min(b1, b2), c2 = max(b1, b2);
+                auto ref_of = [&](uint32_t key) -> int32_t {
+                    const uint32_t slot = key & 3u;
+                    return (int32_t)(slot == 0u ? k0.w : slot == 1u ? k1.w : slot == 2u ? k2.w : k3.w);
+                };
+                if (b0 == 0xffffffffu) {
                     pop_next();
+                } else {
+                    if (b3 != 0xffffffffu) {
+                        st.push(ref_of(b3));
+                    }
+                    if (c2 != 0xffffffffu) {
+                        st.push(ref_of(c2));
+                    }
+                    if (c1 != 0xffffffffu) {
+                        st.push(ref_of(c1));
+                    }
+                    cur = ref_of(b0);
                 }
             }
         }

@@ -111,7 +111,7 @@ class RenderHIP:
         frame = np.zeros(6, np.float32)
         core.check(self._ctx, self._lib.crt_hip_bvh_info(self._ctx, C.byref(nn), C.byref(nt), C.byref(ni),
                                                          C.byref(tl), core.fptr(frame)), "bvh_info")
-        nodes = np.zeros((nn.value, 8), np.uint32)
+        nodes = np.zeros((nn.value, 16), np.uint32)  # 64-byte 4-wide nodes
         tris = np.zeros((nt.value, 12), np.float32)
         core.check(self._ctx, self._lib.crt_hip_bvh_copy(self._ctx, nodes.ctypes.data_as(C.c_void_p),
                                                          tris.ctypes.data_as(C.c_void_p)), "bvh_copy")

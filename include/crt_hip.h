@@ -200,7 +200,7 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
                 float *out, int out_stride);
 
 /* BVH introspection for tests: copy out the traversal arrays the kernels use. Nodes are
- * 32-byte quantised records, triangles 48-byte records (DESIGN.md "Data layout in HBM");
+ * 64-byte quantised 4-wide records, triangles 48-byte records (DESIGN.md "Data layout in HBM");
  * root_frame receives the 6 floats {base.xyz, step.xyz} of the root BVH's fixed-point frame. */
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,
                      uint64_t *n_instances, int32_t *two_level, float *root_frame);

@@ -1761,19 +1761,26 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 }
 
 // Foreign (product) BVH walk with the product's documented visit rule (DESIGN.md "Traversal
-// rule"): 32-byte nodes {lo0[3] hi0[3] lo1[3] hi1[3] as uint16 fixed point, c0, c1}; a plane at
-// fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv); c >= 0 inner node
-// index; c < 0 leaf with x = ~c, first = x >> 3, count = (x & 7) + 1; 48-byte triangle records.
+// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {lo[3] hi[3] as uint16 fixed point,
+// ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
+// ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
+// ref == 0x80000002 unused slot; 48-byte triangle records. Children whose box is entered are
+// visited in ascending order of the key (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked
+// farthest first.
 namespace {
-struct FNode {
-    uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
-    int32_t c0, c1;
+struct FChild {
+    uint16_t lo[3], hi[3];
+    int32_t ref;
 };
+struct FNode {
+    FChild child[4];
+};
+constexpr int32_t F_EMPTY = (int32_t)0x80000002;
 struct FTri {
     f3 v0, e1, e2;
     uint32_t geom, prim, pad;
 };
-static_assert(sizeof(FNode) == 32 && sizeof(FTri) == 48, "product BVH record sizes");
+static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48, "product BVH record sizes");
 inline bool fbox(const uint16_t lo[3], const uint16_t hi[3], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
     const float t0x = std::fma((float)lo[0], qa.x, qb.x), t1x = std::fma((float)hi[0], qa.x, qb.x);
@@ -1805,7 +1812,7 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
         const f3 qa = mk3(frame[3] * inv.x, frame[4] * inv.y, frame[5] * inv.z);
         const f3 qb = mk3((frame[0] - o.x) * inv.x, (frame[1] - o.y) * inv.y, (frame[2] - o.z) * inv.z);
         float best = tmax[i];
-        int32_t stack[128];
+        int32_t stack[256];
         int sp = 0;
         int32_t cur = 0;
         bool done = false;
@@ -1813,21 +1820,22 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
             if (cur >= 0) {
                 const FNode &nd = nodes[cur];
                 ++nv;
-                float t0, t1;
-                const bool h0 = fbox(nd.lo0, nd.hi0, qa, qb, tmin[i], best, t0);
-                const bool h1 = fbox(nd.lo1, nd.hi1, qa, qb, tmin[i], best, t1);
-                if (h0 && h1) {
-                    const bool first0 = t0 <= t1;
-                    stack[sp++] = first0 ? nd.c1 : nd.c0;
-                    cur = first0 ? nd.c0 : nd.c1;
-                    continue;
+                uint32_t keys[4];
+                int n_hit = 0;
+                for (uint32_t k = 0; k < 4; ++k) {
+                    float tn;
+                    uint32_t tb;
+                    if (nd.child[k].ref != F_EMPTY && fbox(nd.child[k].lo, nd.child[k].hi, qa, qb, tmin[i], best, tn)) {
+                        std::memcpy(&tb, &tn, 4);
+                        keys[n_hit++] = (tb & 0x7ffffffcu) | k;
+                    }
                 }
-                if (h0) {
-                    cur = nd.c0;
-                    continue;
-                }
-                if (h1) {
-                    cur = nd.c1;
+                if (n_hit > 0) {
+                    std::sort(keys, keys + n_hit);
+                    for (int k = n_hit - 1; k >= 1; --k) {
+                        stack[sp++] = nd.child[keys[k] & 3u].ref;
+                    }
+                    cur = nd.child[keys[0] & 3u].ref;
                     continue;
                 }
             } else {

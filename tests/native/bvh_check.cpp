@@ -4,7 +4,8 @@
 //   bvh_check <n_items> <threads> <seed> <mode>      mode: 0 scattered boxes, 1 axis-aligned flat
 //                                                    quads far from the origin, 2 duplicates
 // Verifies: every item is in exactly one leaf; every child box contains its subtree's items;
-// leaves hold <= max_leaf items; depth fits the traversal stack; and for every node the
+// leaves hold <= max_leaf items; used child slots come first; the reported wide-tree depth is the
+// real one and fits the traversal stack; and for every node the
 // DEQUANTISED child boxes -- base + q*step evaluated in fp32 exactly like the kernels' planes --
 // contain the full-precision boxes (quantisation may only grow a box).
 #include <cmath>
@@ -45,7 +46,7 @@ int main(int argc, char **argv)
         }
     }
     const int max_leaf = 4;
-    const BuiltBvh b = build_bvh(boxes.data(), n, max_leaf, 0, 0, false, 127, threads);
+    const BuiltBvh b = build_bvh(boxes.data(), n, max_leaf, 0, 0, false, 85, threads);
     const QFrame f = make_frame(b.bounds);
     std::vector<char> seen(n, 0);
     int errors = 0;
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
     // subtree bounds by recursion over the emitted nodes
     struct Rec {
         static void subtree(const BuiltBvh &b, const std::vector<Aabb> &boxes, int32_t ref, Aabb &out, std::vector<char> &seen,
-                            int &errors, int max_leaf)
+                            int &errors, int max_leaf, uint32_t depth, uint32_t &max_depth)
         {
             for (int k = 0; k < 3; ++k) {
                 out.lo[k] = INFINITY;
@@ -78,54 +79,75 @@ int main(int argc, char **argv)
                 return;
             }
             const BvhNode &nd = b.nodes[ref];
-            Aabb c0, c1;
-            subtree(b, boxes, nd.c0, c0, seen, errors, max_leaf);
-            if (nd.c1 == nd.c0) { // a one-leaf BVH lists its leaf twice (the repeat loses every tie)
-                c1 = c0;
-            } else {
-                subtree(b, boxes, nd.c1, c1, seen, errors, max_leaf);
-            }
-            for (int k = 0; k < 3; ++k) {
-                if (c0.lo[k] < nd.lo0[k] || c0.hi[k] > nd.hi0[k] || c1.lo[k] < nd.lo1[k] || c1.hi[k] > nd.hi1[k]) {
-                    ++errors; // a child box does not contain its subtree
+            int used = 0;
+            for (int c = 0; c < BVH_WIDTH; ++c) {
+                if (nd.c[c] == EMPTY_CHILD) {
+                    continue;
                 }
-                out.lo[k] = std::fmin(c0.lo[k], c1.lo[k]);
-                out.hi[k] = std::fmax(c0.hi[k], c1.hi[k]);
+                if (c != used) {
+                    ++errors; // used slots come first
+                }
+                ++used;
+                Aabb cb;
+                subtree(b, boxes, nd.c[c], cb, seen, errors, max_leaf, depth + 1, max_depth);
+                for (int k = 0; k < 3; ++k) {
+                    if (cb.lo[k] < nd.lo[c][k] || cb.hi[k] > nd.hi[c][k]) {
+                        ++errors; // a child box does not contain its subtree
+                    }
+                    out.lo[k] = std::fmin(out.lo[k], cb.lo[k]);
+                    out.hi[k] = std::fmax(out.hi[k], cb.hi[k]);
+                }
             }
+            if (used == 0 || (used == 1 && b.nodes.size() > 1)) {
+                ++errors; // only the one-leaf BVH has a node with a single child
+            }
+            max_depth = std::max(max_depth, depth);
         }
     };
     Aabb all;
-    Rec::subtree(b, boxes, 0, all, seen, errors, max_leaf);
+    uint32_t walked_depth = 0;
+    Rec::subtree(b, boxes, 0, all, seen, errors, max_leaf, 1, walked_depth);
+    if (walked_depth != b.max_depth) {
+        ++errors; // the builder reports the levels of the wide tree (sizes the traversal stack)
+    }
     for (size_t i = 0; i < n; ++i) {
         if (seen[i] != 1) {
             ++errors;
         }
     }
-    if (b.max_depth > 52) {
+    if (3 * b.max_depth + 1 > 96) { // traversal stack: BVH_WIDTH-1 pending siblings per level (traverse.h)
         ++errors;
+    }
+    size_t slots = 0;
+    for (const BvhNode &nd : b.nodes) {
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            slots += nd.c[c] != EMPTY_CHILD;
+        }
     }
     for (const BvhNode &nd : b.nodes) {
         const QNode q = quantise(nd, f);
-        const float *lo[2] = {nd.lo0, nd.lo1}, *hi[2] = {nd.hi0, nd.hi1};
-        const uint16_t *qlo[2] = {q.lo0, q.lo1}, *qhi[2] = {q.hi0, q.hi1};
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            if (q.child[c].ref != nd.c[c]) {
+                ++errors;
+            }
+            if (nd.c[c] == EMPTY_CHILD) {
+                continue;
+            }
             for (int k = 0; k < 3; ++k) {
                 // the kernels place the plane at base + q*step (as fma(q, step/d, (base-o)/d)); in fp32:
-                const float dl = f.base[k] + (float)qlo[c][k] * f.step[k];
-                const float dh = f.base[k] + (float)qhi[c][k] * f.step[k];
-                if (!(dl <= lo[c][k]) || !(dh >= hi[c][k])) {
+                const float dl = f.base[k] + (float)q.child[c].lo[k] * f.step[k];
+                const float dh = f.base[k] + (float)q.child[c].hi[k] * f.step[k];
+                if (!(dl <= nd.lo[c][k]) || !(dh >= nd.hi[c][k])) {
                     ++errors;
                 }
-                slack += (lo[c][k] - dl) + (dh - hi[c][k]);
+                slack += (nd.lo[c][k] - dl) + (dh - nd.hi[c][k]);
                 planes += 2;
-                inflated += (lo[c][k] - dl > 3.f * f.step[k]) + (dh - hi[c][k] > 3.f * f.step[k]);
+                inflated += (nd.lo[c][k] - dl > 3.f * f.step[k]) + (dh - nd.hi[c][k] > 3.f * f.step[k]);
             }
         }
-        if (q.c0 != nd.c0 || q.c1 != nd.c1) {
-            ++errors;
-        }
     }
-    std::printf("items %zu nodes %zu depth %u top %u errors %d mean_slack_quanta %.3f over_3_quanta %zu\n", n, b.nodes.size(),
-                b.max_depth, b.n_top, errors, planes ? slack / planes / f.step[0] : 0.0, inflated);
+    std::printf("items %zu nodes %zu fill %.2f depth %u top %u errors %d mean_slack_quanta %.3f over_3_quanta %zu\n", n,
+                b.nodes.size(), b.nodes.empty() ? 0.0 : (double)slots / (BVH_WIDTH * b.nodes.size()), b.max_depth, b.n_top,
+                errors, planes ? slack / planes / f.step[0] : 0.0, inflated);
     return errors == 0 && inflated == 0 ? 0 : 1;
 }

@@ -1,4 +1,4 @@
-"""GPU parity: BVH2 traversal + triangle intersection (kernels K2/K4).
+"""GPU parity: BVH4 traversal + triangle intersection (kernels K2/K4).
 
 The closest hit is defined as the lexicographic minimum of (t, inst, geom, prim) over all
 valid triangle hits, so the HIP kernel walking its own SAH BVH must return EXACTLY what the
