@@ -1003,6 +1003,20 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                              ctx->frame_id, b, (pc.t_end[b] - pc.t_start[b]) / 100.0, (pc.t_drained[b] - pc.t_start[b]) / 100.0,
                              100.0 * (double)(pc.t_end[b] - pc.t_drained[b]) / (double)(pc.t_end[b] - pc.t_start[b]));
             }
+            for (int k = 0; k < 2 && (ctx->flags & CRT_HIP_FLAG_COUNTERS); ++k) {
+                static const char *names[4] = {"refill", "inner", "leaf", "retire"};
+                double total = 0.0;
+                for (int ph = 0; ph < 4; ++ph) {
+                    total += (double)pc.prof_cycles[k][ph];
+                }
+                for (int ph = 0; ph < 4; ++ph) {
+                    const double it = (double)std::max<unsigned long long>(1ull, pc.prof_iters[k][ph]);
+                    std::fprintf(stderr, "[crt_hip] frame %u %s waves, %-6s: %5.1f%% of wave cycles, %.0f cycles/iteration, %.1f lanes/iteration\n",
+                                 ctx->frame_id, k == 0 ? "closest" : "shadow ", names[ph],
+                                 100.0 * (double)pc.prof_cycles[k][ph] / std::max(1.0, total),
+                                 (double)pc.prof_cycles[k][ph] / it, (double)pc.prof_lanes[k][ph] / it);
+                }
+            }
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", ctx->frame_id,
                              b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);

@@ -213,7 +213,7 @@ CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
         dst[i] = src[i];
     }
     __syncthreads();
-    return n > 0 ? lds.top : nullptr;
+    return lds.top; // always the LDS array (so loads through it stay ds_read); holds min(n_top_nodes, MAX_TOP_NODES) nodes
 }
 
 // ---- K2 trace_closest ----------------------------------------------------------------------------
@@ -260,16 +260,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     __shared__ TraceLds lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
-    st.lds = &lds.stack[0][threadIdx.x];
+    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
-               (threadIdx.x & 63);
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+                                  (threadIdx.x & 63));
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
     const ClosestSource src{q, hits, sc.tris, sc.instances, sc.material_ids};
     trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
-                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray, &pc->t_start[bounce]);
+                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray, &pc->t_start[bounce],
+                                                &pc->prof_cycles[0][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
@@ -341,14 +342,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(SceneView sc, Shad
     __shared__ TraceLds lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
-    st.lds = &lds.stack[0][threadIdx.x];
+    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
-               (threadIdx.x & 63);
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+                                  (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const ShadowSource src{sa, sb, radiance};
     trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
-                                               src, n_nodes, n_tris);
+                                               src, n_nodes, n_tris, nullptr, nullptr, nullptr, &pc->prof_cycles[1][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
@@ -715,10 +716,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     __shared__ TraceLds lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
-    st.lds = &lds.stack[0][threadIdx.x];
+    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
-               (threadIdx.x & 63);
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+                                  (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
     trace_wavefront<ANY_HIT, TWO_LEVEL, true>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]), tmin, src,

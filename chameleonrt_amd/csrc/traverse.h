@@ -34,10 +34,16 @@ struct RayHit {
     int32_t inst; // instance index
 };
 
+// Pointers into LDS and HBM carry their address space in the type: through generic pointers the
+// compiler merges the two arms of "LDS or HBM?" into one flat_load, which is slower than either
+// ds_read or global_load and sends even LDS-resident data through the vector-memory front end.
+#define TV_LDS __attribute__((address_space(3)))
+#define TV_HBM __attribute__((address_space(1)))
+
 struct TraversalStack {
-    int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
+    TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
-    int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
+    TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
     int sp;
     CRT_DEV void push(int32_t x)
     {
@@ -83,12 +89,31 @@ CRT_DEV bool slab_q(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint
     return tn <= tf * 1.0000004f;
 }
 
-// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront).
-CRT_DEV uint32_t child_key(const uint4 k, uint32_t slot, V3 qa, V3 qb, float tmin, float tmax)
+// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront). The two
+// planes of an axis go through one packed FMA (v_pk_fma_f32: two fp32 FMAs per issue slot, each
+// rounded like the scalar one): traversal is bound by VALU issue, not by memory.
+#ifndef CRT_PK_FMA
+#define CRT_PK_FMA 1
+#endif
+typedef float tv_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t tv_u4 __attribute__((ext_vector_type(4))); // plain vector: loadable from any address space
+CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, V3 qa, V3 qb, float tmin, float tmax)
 {
+#if CRT_PK_FMA
+    const tv_f2 px = {(float)(k.x & 0xffffu), (float)(k.y >> 16)};
+    const tv_f2 py = {(float)(k.x >> 16), (float)(k.z & 0xffffu)};
+    const tv_f2 pz = {(float)(k.y & 0xffffu), (float)(k.z >> 16)};
+    const tv_f2 tx = __builtin_elementwise_fma(px, (tv_f2){qa.x, qa.x}, (tv_f2){qb.x, qb.x});
+    const tv_f2 ty = __builtin_elementwise_fma(py, (tv_f2){qa.y, qa.y}, (tv_f2){qb.y, qb.y});
+    const tv_f2 tz = __builtin_elementwise_fma(pz, (tv_f2){qa.z, qa.z}, (tv_f2){qb.z, qb.z});
+    const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
+    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmax));
+    const bool hit = tn <= tf * 1.0000004f;
+#else
     float tn;
     const bool hit = slab_q(k.x & 0xffffu, k.x >> 16, k.y & 0xffffu, k.y >> 16, k.z & 0xffffu, k.z >> 16, qa, qb, tmin,
                             tmax, tn);
+#endif
     return hit && (int32_t)k.w != EMPTY_CHILD ? ((__float_as_uint(tn) & 0x7ffffffcu) | slot) : 0xffffffffu;
 }
 
@@ -137,6 +162,9 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 #ifndef CRT_REFILL_MIN
 #define CRT_REFILL_MIN 16
 #endif
+#ifndef CRT_DEFER_RETIRE
+#define CRT_DEFER_RETIRE 1
+#endif
 #ifndef CRT_POOL_CHUNK
 #define CRT_POOL_CHUNK 128
 #endif
@@ -159,8 +187,21 @@ template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
 CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
-                             unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */)
+                             unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
+                             unsigned long long *prof = nullptr /* PassCounters::prof_cycles[kind], iters, lanes 8 and 16 on */)
 {
+    unsigned long long pf_cyc[4] = {0, 0, 0, 0};
+    uint32_t pf_it[4] = {0, 0, 0, 0}, pf_ln[4] = {0, 0, 0, 0};
+    unsigned long long pf_t = COUNTERS ? (unsigned long long)clock64() : 0ull;
+    auto pf_mark = [&](int phase, uint32_t lanes) {
+        if (COUNTERS) {
+            const unsigned long long now = (unsigned long long)clock64();
+            pf_cyc[phase] += now - pf_t;
+            pf_t = now;
+            pf_it[phase] += 1u;
+            pf_ln[phase] += lanes;
+        }
+    };
     if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
         atomicMin(&t_marks[0], (unsigned long long)wall_clock64());
     }
@@ -184,7 +225,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     // wave-uniform pool of ray indices
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
-    const int32_t top_lo = sc.root, top_hi = sc.root + (int32_t)sc.n_top_nodes;
+    const int32_t top_lo = sc.root, top_hi = sc.root + (int32_t)sc.n_top_nodes; // host: n_top_nodes <= CRT_MAX_TOP_NODES
 
     // Box tests use 1/d with |d| clamped to >= 1e-18 (sign kept): with an exactly zero component
     // q*inf + (-inf) would be NaN for every plane of that axis and switch its culling off (one such
@@ -275,6 +316,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
         }
         const uint64_t active_mask = __ballot(ray >= 0);
+        pf_mark(0, 0u);
         if (active_mask == 0) {
             if (exhausted) {
                 if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
@@ -284,7 +326,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
             continue;
         }
-        const uint32_t n_active = (uint32_t)__popcll(active_mask);
+        // lanes with a ray still being traversed (a finished ray may wait for its batch to retire)
+        const uint32_t n_active = (uint32_t)__popcll(__ballot(ray >= 0 && cur != CUR_DONE));
 
         // ---- inner-node phase: step while at least half of the active lanes are on an inner node
         for (;;) {
@@ -295,11 +338,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
             if (inner) {
                 // one 16-byte quarter per child: {lox|loy, loz|hix, hiy|hiz, ref}
-                uint4 k0, k1, k2, k3;
-                {
-                    const uint4 *p = (top != nullptr && cur >= top_lo && cur < top_hi)
-                                         ? reinterpret_cast<const uint4 *>(top + (cur - top_lo))
-                                         : reinterpret_cast<const uint4 *>(sc.nodes + cur);
+                tv_u4 k0, k1, k2, k3;
+                if (cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
+                    const TV_LDS tv_u4 *p = (const TV_LDS tv_u4 *)(top + (cur - top_lo));
+                    k0 = p[0];
+                    k1 = p[1];
+                    k2 = p[2];
+                    k3 = p[3];
+                } else {
+                    const TV_HBM tv_u4 *p = (const TV_HBM tv_u4 *)(sc.nodes + cur);
                     k0 = p[0];
                     k1 = p[1];
                     k2 = p[2];
@@ -341,9 +388,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     cur = ref_of(b0);
                 }
             }
+            pf_mark(1, n_inner);
         }
 
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
+        const uint32_t pf_leaf_lanes = COUNTERS ? (uint32_t)__popcll(__ballot(ray >= 0 && cur < 0 && cur != CUR_DONE)) : 0u;
         if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
             const uint32_t x = ~(uint32_t)cur;
             const uint32_t first = x >> 3;
@@ -403,8 +452,22 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
         }
 
+        if (COUNTERS) {
+            pf_mark(2, pf_leaf_lanes);
+        }
         // ---- retire finished rays -------------------------------------------------------------
-        if (ray >= 0 && cur == CUR_DONE) {
+        // Retiring costs a few dozen instructions and a chain of dependent loads whatever the number
+        // of lanes that take part, and a finished lane has nothing to do before the next refill
+        // anyway: so rays are retired in batches, when finished + idle lanes reach the refill
+        // threshold (or nothing else is left to do in this wave), not one or two per iteration.
+        bool do_retire = true;
+        if (CRT_DEFER_RETIRE) {
+            const uint32_t n_done = (uint32_t)__popcll(__ballot(ray >= 0 && cur == CUR_DONE));
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(ray < 0));
+            const uint32_t n_wait = exhausted ? n_done : n_done + n_idle;
+            do_retire = n_wait >= CRT_REFILL_MIN || n_done + n_idle == 64u;
+        }
+        if (do_retire && ray >= 0 && cur == CUR_DONE) {
             if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
                 if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
                     worst_ray[0] = org.x;
@@ -423,6 +486,16 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             } else {
                 ray = -1;
             }
+        }
+        if (COUNTERS) {
+            pf_mark(3, 0u);
+        }
+    }
+    if (COUNTERS && prof != nullptr && tv_lane_id() == 0) {
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&prof[k], pf_cyc[k]);
+            atomicAdd(&prof[8 + k], (unsigned long long)pf_it[k]);
+            atomicAdd(&prof[16 + k], (unsigned long long)pf_ln[k]);
         }
     }
 }

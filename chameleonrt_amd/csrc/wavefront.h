@@ -73,6 +73,10 @@ struct PassCounters {
     // CRT_HIP_FLAG_COUNTERS: wall-clock ticks (100 MHz) of the closest-hit launches: first wave start,
     // first wave that found the queue empty, last wave end -- how much of a launch is tail
     unsigned long long t_start[MAX_PATH_DEPTH], t_drained[MAX_PATH_DEPTH], t_end[MAX_PATH_DEPTH];
+    // CRT_HIP_FLAG_COUNTERS: where the persistent traversal waves spend their time, summed over waves:
+    // [phase] = refill, inner-node steps, leaf steps, retire; shader-clock cycles, loop iterations
+    // that ran the phase, and lanes that took part in them. [0] closest-hit launches, [1] occlusion.
+    unsigned long long prof_cycles[2][4], prof_iters[2][4], prof_lanes[2][4];
 };
 
 } // namespace crt
