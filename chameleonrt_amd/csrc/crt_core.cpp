@@ -635,7 +635,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             if (recs.empty()) {
                 throw std::runtime_error("mesh without triangles");
             }
-            static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 4;
+            // leaves of at most 2 triangles: with 4-wide nodes a leaf is one of four boxes tested per node
+            // fetch, so small leaves are cheap to reach, and every triangle test saved is 3 lane requests
+            static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
             built[m] = build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
                                  n_threads);
             blas_depth = std::max(blas_depth, built[m].max_depth);

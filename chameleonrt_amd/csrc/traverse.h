@@ -89,31 +89,15 @@ CRT_DEV bool slab_q(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint
     return tn <= tf * 1.0000004f;
 }
 
-// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront). The two
-// planes of an axis go through one packed FMA (v_pk_fma_f32: two fp32 FMAs per issue slot, each
-// rounded like the scalar one): traversal is bound by VALU issue, not by memory.
-#ifndef CRT_PK_FMA
-#define CRT_PK_FMA 1
-#endif
-typedef float tv_f2 __attribute__((ext_vector_type(2)));
+// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront).
+// (Packed v_pk_fma_f32 for the two planes of an axis was measured: +1.6 % on C2, -1.5 % on C4,
+// where the kernel is VALU-issue bound; the scalar form stays.)
 typedef uint32_t tv_u4 __attribute__((ext_vector_type(4))); // plain vector: loadable from any address space
 CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, V3 qa, V3 qb, float tmin, float tmax)
 {
-#if CRT_PK_FMA
-    const tv_f2 px = {(float)(k.x & 0xffffu), (float)(k.y >> 16)};
-    const tv_f2 py = {(float)(k.x >> 16), (float)(k.z & 0xffffu)};
-    const tv_f2 pz = {(float)(k.y & 0xffffu), (float)(k.z >> 16)};
-    const tv_f2 tx = __builtin_elementwise_fma(px, (tv_f2){qa.x, qa.x}, (tv_f2){qb.x, qb.x});
-    const tv_f2 ty = __builtin_elementwise_fma(py, (tv_f2){qa.y, qa.y}, (tv_f2){qb.y, qb.y});
-    const tv_f2 tz = __builtin_elementwise_fma(pz, (tv_f2){qa.z, qa.z}, (tv_f2){qb.z, qb.z});
-    const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
-    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmax));
-    const bool hit = tn <= tf * 1.0000004f;
-#else
     float tn;
     const bool hit = slab_q(k.x & 0xffffu, k.x >> 16, k.y & 0xffffu, k.y >> 16, k.z & 0xffffu, k.z >> 16, qa, qb, tmin,
                             tmax, tn);
-#endif
     return hit && (int32_t)k.w != EMPTY_CHILD ? ((__float_as_uint(tn) & 0x7ffffffcu) | slot) : 0xffffffffu;
 }
 
