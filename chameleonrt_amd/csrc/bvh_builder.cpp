@@ -407,36 +407,123 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
-    // Collapse the binary tree to BVH_WIDTH-wide nodes: the children of a wide node rooted at temp
-    // node t are t's two children, with the inner child of largest surface area (the one a ray is
-    // most likely to enter) replaced by its own two children until BVH_WIDTH slots are used.
+    // Collapse the binary tree to BVH_WIDTH-wide nodes. A traversal step costs the same whatever the
+    // number of used child slots, so the expected cost of a ray is proportional to the summed
+    // surface area of the binary nodes that become roots of wide nodes; every other inner node is
+    // absorbed into its parent's wide node. That sum is minimised exactly by dynamic programming
+    // over the binary tree (Ylitie, Karras, Laine 2017, section 3.1, for width 4):
+    //   root_cost[n] = area(n) + min over a + b = 4 of slots(left, a) + slots(right, b)
+    //   slots(n, j)  = cheapest way to hand subtree n at most j child slots of its parent's node:
+    //                  a leaf costs 0; an inner node either takes one slot as the root of its own
+    //                  wide node (root_cost[n]) or, if j >= 2, is absorbed and splits its j slots
+    //                  between its children.
+    // CRT_BVH_COLLAPSE=greedy selects the earlier heuristic (expand the inner child of largest
+    // surface area until the node is full) for comparison.
     struct Wide {
         int32_t kid[BVH_WIDTH];
         int n;
     };
+    static const bool greedy_collapse = [] {
+        const char *e = std::getenv("CRT_BVH_COLLAPSE");
+        return e != nullptr && std::strcmp(e, "greedy") == 0;
+    }();
+    static_assert(BVH_WIDTH == 4, "the collapse below is written for 4-wide nodes");
+    // slot_cost[3*n + (j-1)] = slots(n, j) for j = 1..3 (inner nodes; j = 1 is root_cost)
+    std::vector<float> slot_cost;
+    auto slots = [&](int32_t t, int j) -> double { return is_inner(t) ? (double)slot_cost[3 * (size_t)t + (j - 1)] : 0.0; };
+    // the split of j >= 2 slots between the children of an absorbed (or root, j = 4) node
+    auto best_split = [&](int32_t t, int j, int &a_out) {
+        const int32_t l = b.tn[t].left, r = b.tn[t].right;
+        double best = std::numeric_limits<double>::infinity();
+        for (int a = 1; a < j; ++a) {
+            const double c = slots(l, std::min(a, 3)) + slots(r, std::min(j - a, 3));
+            if (c < best) {
+                best = c;
+                a_out = a;
+            }
+        }
+        return best;
+    };
+    if (!greedy_collapse && is_inner(root)) {
+        slot_cost.assign(3 * (size_t)n_tn, 0.f);
+        // children before parents: reverse of a pre-order walk
+        std::vector<int32_t> pre;
+        pre.reserve(n_tn);
+        std::vector<int32_t> st{root};
+        while (!st.empty()) {
+            const int32_t t = st.back();
+            st.pop_back();
+            if (!is_inner(t)) {
+                continue;
+            }
+            pre.push_back(t);
+            st.push_back(b.tn[t].left);
+            st.push_back(b.tn[t].right);
+        }
+        const double norm = 1.0 / std::max(half_area(root), 1e-300);
+        for (size_t i = pre.size(); i-- > 0;) {
+            const int32_t t = pre[i];
+            int a;
+            const double as_root = half_area(t) * norm + best_split(t, 4, a);
+            slot_cost[3 * (size_t)t + 0] = (float)as_root;
+            slot_cost[3 * (size_t)t + 1] = (float)std::min(as_root, best_split(t, 2, a));
+            slot_cost[3 * (size_t)t + 2] = (float)std::min(as_root, best_split(t, 3, a));
+        }
+        out.collapse_cost = slot_cost[3 * (size_t)root];
+    }
     auto wide_children = [&](int32_t t) {
         Wide w;
-        w.kid[0] = b.tn[t].left;
-        w.kid[1] = b.tn[t].right;
-        w.n = 2;
-        while (w.n < BVH_WIDTH) {
-            int best = -1;
-            double best_area = -1.0;
-            for (int k = 0; k < w.n; ++k) {
-                if (is_inner(w.kid[k])) {
-                    const double a = half_area(w.kid[k]);
-                    if (a > best_area) {
-                        best_area = a;
-                        best = k;
+        w.n = 0;
+        if (greedy_collapse) {
+            w.kid[0] = b.tn[t].left;
+            w.kid[1] = b.tn[t].right;
+            w.n = 2;
+            while (w.n < BVH_WIDTH) {
+                int best = -1;
+                double best_area = -1.0;
+                for (int k = 0; k < w.n; ++k) {
+                    if (is_inner(w.kid[k])) {
+                        const double a = half_area(w.kid[k]);
+                        if (a > best_area) {
+                            best_area = a;
+                            best = k;
+                        }
                     }
                 }
+                if (best < 0) {
+                    break;
+                }
+                const int32_t x = w.kid[best];
+                w.kid[best] = b.tn[x].left; // keeps the expanded child's position, sibling goes last
+                w.kid[w.n++] = b.tn[x].right;
             }
-            if (best < 0) {
-                break;
+            return w;
+        }
+        // hand `j` slots to subtree x: explicit stack instead of recursion (at most 3 absorbed nodes)
+        struct Item {
+            int32_t x;
+            int j;
+        };
+        Item work[8];
+        int nw = 0;
+        int a = 2;
+        best_split(t, 4, a);
+        work[nw++] = Item{b.tn[t].right, 4 - a};
+        work[nw++] = Item{b.tn[t].left, a};
+        while (nw > 0) {
+            const Item it = work[--nw];
+            bool own_slot = !is_inner(it.x) || it.j == 1;
+            int sa = 1;
+            if (!own_slot) {
+                const double split = best_split(it.x, it.j, sa);
+                own_slot = slots(it.x, 1) <= split; // on a tie the subtree keeps its own node (fewer, fuller parents)
             }
-            const int32_t x = w.kid[best];
-            w.kid[best] = b.tn[x].left; // keeps the expanded child's position, sibling goes last
-            w.kid[w.n++] = b.tn[x].right;
+            if (own_slot) {
+                w.kid[w.n++] = it.x;
+            } else {
+                work[nw++] = Item{b.tn[it.x].right, it.j - sa};
+                work[nw++] = Item{b.tn[it.x].left, sa};
+            }
         }
         return w;
     };

@@ -21,6 +21,8 @@ struct BuiltBvh {
     uint32_t n_top = 0;
     Aabb bounds;
     uint32_t max_depth = 0;      // levels of the wide tree (a single node = 1)
+    float collapse_cost = 0.f;   // summed surface area of the wide nodes / area of the root (expected node visits
+                                 // of a random ray that hits the root box); 0 if not computed
 };
 
 // boxes: one per item. Leaves hold at most max_leaf (<= 8) items.

@@ -1,8 +1,9 @@
 // bvh_check.cpp — host-only check of the product's BVH builder and node quantiser
 // (chameleonrt_amd/csrc/bvh_builder.{h,cpp}); built with g++ by tests/test_bvh_builder.py.
 //
-//   bvh_check <n_items> <threads> <seed> <mode>      mode: 0 scattered boxes, 1 axis-aligned flat
-//                                                    quads far from the origin, 2 duplicates
+//   bvh_check <n_items> <threads> <seed> <mode> [file]   mode: 0 scattered boxes, 1 axis-aligned flat
+//                                                        quads far from the origin, 2 duplicates,
+//                                                        3 boxes from `file` (n x 6 float32: lo, hi)
 // Verifies: every item is in exactly one leaf; every child box contains its subtree's items;
 // leaves hold <= max_leaf items; used child slots come first; the reported wide-tree depth is the
 // real one and fits the traversal stack; and for every node the
@@ -27,7 +28,15 @@ int main(int argc, char **argv)
     std::mt19937 rng(seed);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     std::vector<Aabb> boxes(n);
-    for (size_t i = 0; i < n; ++i) {
+    if (mode == 3) {
+        FILE *f = argc > 5 ? std::fopen(argv[5], "rb") : nullptr;
+        if (f == nullptr || std::fread(boxes.data(), sizeof(Aabb), n, f) != n) {
+            std::fprintf(stderr, "cannot read %zu boxes\n", n);
+            return 2;
+        }
+        std::fclose(f);
+    }
+    for (size_t i = 0; i < n && mode != 3; ++i) {
         float c[3] = {U(rng) * 40.f - 20.f, U(rng) * 6.f, U(rng) * 40.f - 20.f};
         float h[3] = {0.01f + 0.1f * U(rng), 0.01f + 0.1f * U(rng), 0.01f + 0.1f * U(rng)};
         if (mode == 1) { // voxel-city like: flat, axis-aligned, offset 1000 units from the origin
@@ -45,7 +54,7 @@ int main(int argc, char **argv)
             boxes[i].hi[k] = c[k] + h[k];
         }
     }
-    const int max_leaf = 4;
+    const int max_leaf = getenv("BVH_CHECK_MAX_LEAF") ? atoi(getenv("BVH_CHECK_MAX_LEAF")) : 2; // the product default (crt_core.cpp)
     const BuiltBvh b = build_bvh(boxes.data(), n, max_leaf, 0, 0, false, 85, threads);
     const QFrame f = make_frame(b.bounds);
     std::vector<char> seen(n, 0);
@@ -146,6 +155,24 @@ int main(int argc, char **argv)
             }
         }
     }
+    // expected node visits of a random ray that hits the root box: sum of the nodes' surface areas over the root's
+    double sah_nodes = 0.0, root_area = 0.0;
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            for (int k = 0; k < 3 && b.nodes[i].c[c] != EMPTY_CHILD; ++k) {
+                lo[k] = std::fmin(lo[k], b.nodes[i].lo[c][k]);
+                hi[k] = std::fmax(hi[k], b.nodes[i].hi[c][k]);
+            }
+        }
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        const double area = dx * dy + dy * dz + dz * dx;
+        if (i == 0) {
+            root_area = area;
+        }
+        sah_nodes += area;
+    }
+    std::printf("sah_nodes %.3f (builder: %.3f) ", root_area > 0 ? sah_nodes / root_area : 0.0, b.collapse_cost);
     std::printf("items %zu nodes %zu fill %.2f depth %u top %u errors %d mean_slack_quanta %.3f over_3_quanta %zu\n", n,
                 b.nodes.size(), b.nodes.empty() ? 0.0 : (double)slots / (BVH_WIDTH * b.nodes.size()), b.max_depth, b.n_top,
                 errors, planes ? slack / planes / f.step[0] : 0.0, inflated);

@@ -32,3 +32,21 @@ def test_thread_count_does_not_change_the_tree(exe):
     outs = [subprocess.run([exe, "50000", str(t), "7", "0"], capture_output=True, text=True, timeout=600).stdout
             for t in (1, 3, 8)]
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_optimal_collapse_is_not_worse_than_the_greedy_one(exe):
+    """The 4-wide nodes come from a dynamic program that minimises the summed surface area of the
+    wide nodes (= expected node visits of a random ray); the earlier greedy collapse of the same
+    binary tree must never beat it, and both must be valid trees."""
+    import os
+    import re
+    cost = {}
+    for mode in ("dp", "greedy"):
+        env = dict(os.environ, CRT_BVH_COLLAPSE=mode)
+        p = subprocess.run([exe, "60000", "4", "11", "0"], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0 and "errors 0" in p.stdout, p.stdout + p.stderr
+        cost[mode] = float(re.search(r"sah_nodes ([0-9.]+)", p.stdout).group(1))
+        nodes = int(re.search(r"nodes (\d+) fill", p.stdout).group(1))
+        cost[mode + "_nodes"] = nodes
+    assert cost["dp"] <= cost["greedy"] * (1 + 1e-6)
+    assert cost["dp_nodes"] <= cost["greedy_nodes"]

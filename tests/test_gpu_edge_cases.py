@@ -81,3 +81,26 @@ def test_resize_and_scene_replacement(oracle, hip_lib):
     o2 = oracle.OracleRenderer(sc2, 100, 50)
     _check(r, o2, *camera_of(sc2))
     r.close()
+
+
+def test_overlapped_launch_schedule_is_bit_identical(hip_lib, monkeypatch):
+    """CRT_HIP_OVERLAP=1 puts the occlusion launch of bounce b on a second stream next to the
+    closest-hit launch of bounce b+1 (they are independent). Same kernels, same order of the
+    radiance updates per path: accumulated radiance, ray counts and the 8-bit image must not change
+    by a single bit. Two-level scene, so both traversal stacks (and both spill slabs) are in use."""
+    sc = scenes.instanced_grove()
+    w, h = 160, 96
+    e, d, u, fovy = camera_of(sc)
+    out = []
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("CRT_HIP_OVERLAP", overlap)  # read when the context is created
+        r = RenderHIP()
+        r.initialize(w, h)
+        r.set_scene(sc)
+        for f in range(3):
+            st = r.render(e, d, u, fovy, f == 0, True)
+        out.append((r.accum().copy(), r.ray_counts().copy(), r.img.copy(), int(st.rays)))
+        r.close()
+    a, b = out
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
