@@ -49,6 +49,10 @@ struct TNode {
     int32_t left = -1, right = -1; // temp-node indices; -1 = leaf
     uint32_t first = 0, count = 0;
     uint32_t depth = 0;
+    // Collapse to 4-wide nodes (see build_bvh): cheapest summed surface area of the wide nodes below
+    // this node if it may use 1 (= it is the root of a wide node), 2 or 3 child slots of its
+    // parent's wide node. Filled when both children are complete, i.e. inside the parallel build.
+    double slot_cost[3] = {0.0, 0.0, 0.0};
 };
 
 // One item as the builder moves it around: 32 B, partitioned IN PLACE so every pass streams
@@ -345,7 +349,32 @@ struct Builder {
         }
         tn[me].left = l;
         tn[me].right = r;
+        {
+            const Aabb &x = tn[me].box;
+            const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
+            int a;
+            const double as_root = (dx * dy + dy * dz + dz * dx) + best_split(me, 4, a);
+            tn[me].slot_cost[0] = as_root;
+            tn[me].slot_cost[1] = std::min(as_root, best_split(me, 2, a));
+            tn[me].slot_cost[2] = std::min(as_root, best_split(me, 3, a));
+        }
         return me;
+    }
+    // slots(t, j): see TNode::slot_cost; a leaf costs nothing here (its triangles are tested either way)
+    double slots(int32_t t, int j) const { return tn[t].left >= 0 ? tn[t].slot_cost[j - 1] : 0.0; }
+    // the cheapest split of j >= 2 slots between the children of node t: cost, and the left child's share
+    double best_split(int32_t t, int j, int &a_out) const
+    {
+        const int32_t l = tn[t].left, r = tn[t].right;
+        double best = std::numeric_limits<double>::infinity();
+        for (int a = 1; a < j; ++a) {
+            const double c = slots(l, std::min(a, 3)) + slots(r, std::min(j - a, 3));
+            if (c < best) {
+                best = c;
+                a_out = a;
+            }
+        }
+        return best;
     }
 };
 
@@ -428,48 +457,11 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         return e != nullptr && std::strcmp(e, "greedy") == 0;
     }();
     static_assert(BVH_WIDTH == 4, "the collapse below is written for 4-wide nodes");
-    // slot_cost[3*n + (j-1)] = slots(n, j) for j = 1..3 (inner nodes; j = 1 is root_cost)
-    std::vector<float> slot_cost;
-    auto slots = [&](int32_t t, int j) -> double { return is_inner(t) ? (double)slot_cost[3 * (size_t)t + (j - 1)] : 0.0; };
-    // the split of j >= 2 slots between the children of an absorbed (or root, j = 4) node
-    auto best_split = [&](int32_t t, int j, int &a_out) {
-        const int32_t l = b.tn[t].left, r = b.tn[t].right;
-        double best = std::numeric_limits<double>::infinity();
-        for (int a = 1; a < j; ++a) {
-            const double c = slots(l, std::min(a, 3)) + slots(r, std::min(j - a, 3));
-            if (c < best) {
-                best = c;
-                a_out = a;
-            }
-        }
-        return best;
-    };
-    if (!greedy_collapse && is_inner(root)) {
-        slot_cost.assign(3 * (size_t)n_tn, 0.f);
-        // children before parents: reverse of a pre-order walk
-        std::vector<int32_t> pre;
-        pre.reserve(n_tn);
-        std::vector<int32_t> st{root};
-        while (!st.empty()) {
-            const int32_t t = st.back();
-            st.pop_back();
-            if (!is_inner(t)) {
-                continue;
-            }
-            pre.push_back(t);
-            st.push_back(b.tn[t].left);
-            st.push_back(b.tn[t].right);
-        }
-        const double norm = 1.0 / std::max(half_area(root), 1e-300);
-        for (size_t i = pre.size(); i-- > 0;) {
-            const int32_t t = pre[i];
-            int a;
-            const double as_root = half_area(t) * norm + best_split(t, 4, a);
-            slot_cost[3 * (size_t)t + 0] = (float)as_root;
-            slot_cost[3 * (size_t)t + 1] = (float)std::min(as_root, best_split(t, 2, a));
-            slot_cost[3 * (size_t)t + 2] = (float)std::min(as_root, best_split(t, 3, a));
-        }
-        out.collapse_cost = slot_cost[3 * (size_t)root];
+    // The table slots(n, j) is TNode::slot_cost, filled bottom-up inside the (parallel) build.
+    auto slots = [&](int32_t t, int j) { return b.slots(t, j); };
+    auto best_split = [&](int32_t t, int j, int &a_out) { return b.best_split(t, j, a_out); };
+    if (is_inner(root)) {
+        out.collapse_cost = (float)(b.tn[root].slot_cost[0] / std::max(half_area(root), 1e-300));
     }
     auto wide_children = [&](int32_t t) {
         Wide w;
