@@ -1695,6 +1695,34 @@ extern "C" int orc_read_ray_counts(const orc_renderer *r, uint32_t *counts)
     return 0;
 }
 
+// The glm::inverse stand-in (GLM is third-party, like Embree): exported so that oracle/ref_driver.cpp hands
+// the reference kernel the same world_to_object matrices the oracle uses.
+extern "C" int orc_invert4x4(const float m[16], float out[16]) { return invert4x4(m, out) ? 1 : 0; }
+
+// Single-ray forms of the stand-in (no thread pool): what oracle/ref_driver.cpp plugs in where the
+// reference kernel calls rtcIntersect1 / rtcOccluded1.
+extern "C" int orc_intersect1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar,
+                              float *t, float *u, float *v, int32_t *inst, int32_t *geom, int32_t *prim)
+{
+    TraceCounters ctr;
+    Hit h;
+    if (!scene_intersect(*s, mk3(org[0], org[1], org[2]), mk3(dir[0], dir[1], dir[2]), tnear, tfar, false, h, ctr)) {
+        return 0;
+    }
+    *t = h.t;
+    *u = h.u;
+    *v = h.v;
+    *inst = h.inst;
+    *geom = h.geom;
+    *prim = h.prim;
+    return 1;
+}
+extern "C" int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar)
+{
+    TraceCounters ctr;
+    return scene_occluded(*s, mk3(org[0], org[1], org[2]), mk3(dir[0], dir[1], dir[2]), tnear, tfar, false, ctr) ? 1 : 0;
+}
+
 extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, const float *dir,
                               const float *tmin, const float *tmax, int closest, int brute_force,
                               float *out_t, float *out_u, float *out_v, int32_t *out_inst,

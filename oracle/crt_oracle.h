@@ -5,14 +5,24 @@
  * cpu_baseline leg may load it, and only as the checker. Nothing under chameleonrt_amd/
  * or backends/hip/ may include, link or call it.
  *
- * PARITY STATUS: "parity unpinned" at the ray/triangle boundary. The reference delegates
- * BVH build, traversal and triangle intersection to Embree 4 (pinned 4.0.1 in
- * .github/workflows/cmake.yml:12; call sites backends/embree/render_embree.ispc:144,170,245),
- * which is not in /root/reference and not installable here, and the reference ships no
- * tests, golden images or scenes. Everything the reference DOES define (RNG, camera,
- * shading, lights, textures, accumulation, sRGB) is restated line by line; the integer
- * RNG is pinned against an independent MurmurHash3/LCG implementation in
- * tests/test_oracle_rng.py.
+ * PARITY STATUS
+ *  - PINNED, bit for bit, for everything the reference defines: RNG keying, camera rays, the path
+ *    loop, material unpacking and textures, the Disney BSDF, quad lights, NEE + MIS, Russian
+ *    roulette, the running mean, sRGB8 and the ray statistics. The pin is the reference's own
+ *    kernel source (backends/embree_sycl/render_embree_kernel.inl and the headers it includes:
+ *    the C++ twin of the ISPC files this restatement follows), compiled from /root/reference by
+ *    `make -C oracle ref` and run on Cornell, a textured scene and a 64-instance scene with
+ *    glass: accumulated radiance, RGBA8 and per-pixel ray counts are identical to the last bit
+ *    (tests/test_oracle_pinned.py; tests/golden/ref_*.npz carry its frames to machines without
+ *    the reference tree). The integer RNG is also pinned against an independent
+ *    MurmurHash3/LCG implementation (tests/test_oracle_rng.py).
+ *  - "parity unpinned" at the ray/triangle boundary only. The reference delegates BVH build,
+ *    traversal and triangle intersection to Embree 4 (pinned 4.0.1 in
+ *    .github/workflows/cmake.yml:12; call sites backends/embree/render_embree.ispc:144,170,245),
+ *    which is not in /root/reference and not installable here; the pinning run above plugs the
+ *    oracle's own intersector in where the kernel calls rtcIntersect1 / rtcOccluded1, and
+ *    GLM's matrix inverse (third-party too) is the oracle's. The ISPC build's `--opt=fast-math`
+ *    and approximate transcendentals are not reproduced by any C++ build either.
  */
 #ifndef CRT_ORACLE_H
 #define CRT_ORACLE_H
@@ -62,7 +72,15 @@ int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, const float
                    float *out_t, float *out_u, float *out_v, int32_t *out_inst,
                    int32_t *out_geom, int32_t *out_prim, orc_stats *stats);
 
-/* Walk a FOREIGN BVH (the product's 32-byte quantised nodes + frame / 48-byte triangles,
+/* glm::inverse stand-in used for Instance::world_to_object (embree_utils.cpp:97). 1 = invertible. */
+int orc_invert4x4(const float m[16], float out[16]);
+
+/* The same stand-in for one ray, on the calling thread: 1 = hit / occluded, 0 = not. */
+int orc_intersect1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar,
+                   float *t, float *u, float *v, int32_t *inst, int32_t *geom, int32_t *prim);
+int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar);
+
+/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frame / 48-byte triangles,
  * DESIGN.md) with the product's documented visit rule and count nodes fetched / triangles
  * tested, to cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers. Single-level only. */
 int orc_count_foreign_bvh(const void *nodes, uint64_t n_nodes, const void *tris,

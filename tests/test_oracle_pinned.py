@@ -1,0 +1,90 @@
+"""CPU: the oracle pinned against the REFERENCE's own code.
+
+The reference's Embree backend cannot be built here (ISPC, Embree 4, TBB), but its SYCL twin
+carries the same per-pixel kernel as plain C++ (backends/embree_sycl/render_embree_kernel.inl with
+disney_bsdf.h, lights.h, lcg_rng.h, texture2d.h, util.h, float3.h, mat4.h). `make -C oracle ref`
+compiles those files from where they lie under /root/reference (oracle/ref_driver.cpp, stand-in
+headers only for SYCL math, GLM and Embree's records) and tests/golden/ref_*.npz hold frames it
+rendered. The oracle restatement must reproduce them BIT FOR BIT: accumulated radiance (including
+the non-finite pixels the reference's glass produces), the RGBA8 framebuffer and the per-pixel
+ray statistics. Tolerance: none (uint32 views are compared).
+
+What this does not pin: Embree's BVH and ray/triangle arithmetic (both sides use the oracle's
+stand-in), GLM's matrix inverse (same), and the ISPC build's fast-math (`--opt=fast-math`), which
+no C++ build reproduces."""
+import os
+
+import numpy as np
+import pytest
+
+from chameleonrt_amd import scenes
+from tests import ref_lib
+from tests.parity import camera_of
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _oracle_frames(oracle, sc, w, h, frames):
+    o = oracle.OracleRenderer(sc, w, h)
+    e, d, u, fovy = camera_of(sc)
+    for f in range(frames):
+        o.render(e, d, u, fovy, f == 0)
+    fb = o.framebuffer().view(np.uint8).reshape(h, w, 4)
+    return o.accum(), fb, o.ray_counts()
+
+
+def _assert_identical(oracle_out, ref_out, what):
+    (oa, ofb, orc), (ra, rfb, rrs) = oracle_out, ref_out
+    differing = (oa.view(np.uint32) != ra.view(np.uint32)).any(axis=2)
+    assert not differing.any(), f"{what}: {int(differing.sum())} of {differing.size} pixels differ from the reference kernel"
+    assert np.array_equal(ofb, rfb), f"{what}: RGBA8 framebuffer differs"
+    assert np.array_equal(orc.astype(np.uint16), rrs), f"{what}: per-pixel ray statistics differ"
+
+
+@pytest.mark.parametrize("frame", ref_lib.GOLDEN_FRAMES, ids=[f[0] for f in ref_lib.GOLDEN_FRAMES])
+def test_oracle_reproduces_reference_kernel_golden(frame, oracle):
+    """Cornell (plain diffuse, one light); the Sponza-like scene (UVs, sRGB and linear textures,
+    textured scalar parameters, 16 materials); the instanced grove (64 non-identity instances,
+    glass, anisotropy, sheen, clearcoat). Two accumulated frames each."""
+    name, kwargs, w, h, frames = frame
+    g = np.load(os.path.join(GOLDEN, f"ref_{name}.npz"))
+    assert (int(g["width"]), int(g["height"]), int(g["frames"])) == (w, h, frames)
+    sc = getattr(scenes, name)(**kwargs)
+    _assert_identical(_oracle_frames(oracle, sc, w, h, frames), (g["accum"], g["framebuffer"], g["ray_stats"]), name)
+
+
+needs_ref = pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref is built only where /root/reference exists")
+
+
+@needs_ref
+def test_golden_files_are_what_the_reference_kernel_renders():
+    """Guards against stale goldens: re-render one with oracle/_ref and compare with the file."""
+    name, kwargs, w, h, frames = ref_lib.GOLDEN_FRAMES[0]
+    sc = getattr(scenes, name)(**kwargs)
+    acc, fb, rs = ref_lib.render(sc, w, h, *camera_of(sc), frames)
+    g = np.load(os.path.join(GOLDEN, f"ref_{name}.npz"))
+    assert np.array_equal(acc.view(np.uint32), g["accum"].view(np.uint32))
+    assert np.array_equal(fb, g["framebuffer"]) and np.array_equal(rs, g["ray_stats"])
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["cornell_odd_size_3spp", "sponza_other_view", "grove_white_diffuse"])
+def test_oracle_matches_reference_kernel_live(case, oracle):
+    """Configurations outside the golden set: a framebuffer that is not a multiple of the 64x64
+    tile (the oracle renders tiles like the ISPC backend, the SYCL kernel renders pixels), a moved
+    camera, and the `-mat-mode white_diffuse` override."""
+    if case == "cornell_odd_size_3spp":
+        sc, w, h, frames = scenes.cornell(spp=3), 70, 45, 3
+        cam = camera_of(sc)
+    elif case == "sponza_other_view":
+        sc, w, h, frames = scenes.sponza_like(spp=2, detail=0.02, tex_size=32), 80, 48, 1
+        e, d, u, fovy = camera_of(sc)
+        cam = (e + np.float32([0.3, 0.2, -0.1]), d, u, fovy * 0.8)
+    else:
+        sc, w, h, frames = scenes.instanced_grove().white_diffuse(), 64, 40, 2
+        cam = camera_of(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    for f in range(frames):
+        o.render(*cam, f == 0)
+    ofb = o.framebuffer().view(np.uint8).reshape(h, w, 4)
+    _assert_identical((o.accum(), ofb, o.ray_counts()), ref_lib.render(sc, w, h, *cam, frames), case)
