@@ -11,10 +11,12 @@
 //   K5 accumulate     sample sum, running mean, sRGB8                   (ispc:339-353, 358-370)
 //   K8 assemble       multi-GPU tile un-permute                         (new)
 //
-// Rays that survive a bounce are compacted into the next queue with __ballot + mbcnt and one
-// atomic per wave. Traversal kernels are persistent: a fixed grid of waves pulls 64-ray
-// packets from the queue with an atomic cursor, so long rays do not stall a whole block.
-// No MFMA anywhere: the path is divergent pointer chasing bounded by memory, not a contraction.
+// Rays that survive a bounce are compacted into the next queue with __ballot + mbcnt, staged in
+// LDS and flushed with one atomic per 128-256 entries. Traversal kernels are persistent: a fixed
+// grid of waves pulls 128-ray chunks from the queue with an atomic cursor and refills lanes as
+// their rays finish, so long rays do not stall a whole block.
+// No MFMA anywhere: the path is divergent pointer chasing, bound by vector-ALU issue at half the
+// lanes, not a contraction.
 
 #include <hip/hip_runtime.h>
 
@@ -29,9 +31,6 @@ namespace crt {
 
 #ifndef CRT_TRACE_BLOCK
 #define CRT_TRACE_BLOCK 256
-#endif
-#ifndef CRT_FETCH
-#define CRT_FETCH 64
 #endif
 #ifndef CRT_TRACE_BLOCKS_PER_CU
 #define CRT_TRACE_BLOCKS_PER_CU 7
@@ -62,18 +61,6 @@ CRT_DEV uint32_t wave_append(uint32_t *counter, bool pred)
     }
     base = __shfl(base, leader);
     return base + rank;
-}
-// A wave grabs the next FETCH-element packet of a queue (FETCH/64 rounds of 64 rays). One
-// returning atomic on a single word sustains only ~88 ops/us on MI355X (MI355X_MICROARCH.md,
-// "dequeue"), so a packet must be large enough that fetching is off the critical path.
-constexpr uint32_t FETCH = CRT_FETCH;
-CRT_DEV uint32_t wave_fetch(uint32_t *cursor)
-{
-    uint32_t base = 0;
-    if (lane_id() == 0) {
-        base = atomicAdd(cursor, FETCH);
-    }
-    return __builtin_amdgcn_readfirstlane(base);
 }
 // Same compaction as wave_append but on an LDS counter (cheap, no memory-side atomic).
 CRT_DEV uint32_t wave_append_lds(uint32_t *lds_counter, bool pred)
