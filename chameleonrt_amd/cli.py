@@ -1,7 +1,7 @@
 """Headless re-statement of the reference application's command line and frame loop
 (main.cpp:19-33, 113-345) around the HIP backend:
 
-    python -m chameleonrt_amd.cli hip <scene.obj | synthetic:NAME | C1..C5> [options]
+    python -m chameleonrt_amd.cli hip <scene.obj | scene.crts | scene.gltf | scene.glb | synthetic:NAME | C1..C5> [options]
 
     -eye x y z  -center x y z  -up x y z  -fov deg  -spp n  -img w h
     -mat-mode default|white_diffuse   -benchmark-frames n   -validation prefix
@@ -79,6 +79,14 @@ def main(argv=None) -> int:
     elif scene_file.startswith("synthetic:"):
         scene = getattr(scenes, scene_file.split(":", 1)[1])()
         scene.samples_per_pixel = spp
+    elif scene_file.lower().endswith(".crts"):  # dispatch on the extension like Scene::Scene (util/scene.cpp:49-72)
+        from .crts_io import load_crts
+        scene = load_crts(scene_file, mat_mode, spp)
+        mat_mode = "default"  # already applied by the loader, the way the reference does it
+    elif scene_file.lower().endswith((".gltf", ".glb")):
+        from .gltf_io import load_gltf
+        scene = load_gltf(scene_file, mat_mode, spp)
+        mat_mode = "default"
     else:
         from .obj_io import load_obj
         scene = load_obj(scene_file, "default", spp)
