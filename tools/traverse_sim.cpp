@@ -42,6 +42,7 @@ struct Ray {
 std::vector<QNode> g_nodes;
 std::vector<Tri> g_tris;
 QFrame g_frame;
+int g_order = 0; // child ordering rule, see Lane::inner_step (TRAVERSE_SIM_ORDER)
 
 inline float box_dir(float x) { return std::fabs(x) < 1e-18f ? std::copysign(1e-18f, x) : x; }
 
@@ -157,8 +158,26 @@ struct Lane {
         (void)closest;
         if (n == 0) {
             pop();
-        } else {
+        } else if (g_order == 0) { // full sort: nearest first, the rest stacked farthest first (the kernel today)
             std::sort(keys, keys + n);
+            for (int k = n - 1; k >= 1; --k) {
+                stack.push_back(nd.child[keys[k] & 3u].ref);
+            }
+            cur = nd.child[keys[0] & 3u].ref;
+        } else if (g_order == 1) { // nearest first, the rest stacked in slot order (no sort network)
+            int best = 0;
+            for (int k = 1; k < n; ++k) {
+                if (keys[k] < keys[best]) {
+                    best = k;
+                }
+            }
+            for (int k = n - 1; k >= 0; --k) {
+                if (k != best) {
+                    stack.push_back(nd.child[keys[k] & 3u].ref);
+                }
+            }
+            cur = nd.child[keys[best] & 3u].ref;
+        } else { // slot order only
             for (int k = n - 1; k >= 1; --k) {
                 stack.push_back(nd.child[keys[k] & 3u].ref);
             }
@@ -208,6 +227,7 @@ int main(int argc, char **argv)
         return 2;
     }
     const bool closest = std::atoi(argv[3]) != 0;
+    g_order = std::getenv("TRAVERSE_SIM_ORDER") ? std::atoi(std::getenv("TRAVERSE_SIM_ORDER")) : 0;
     const int max_leaf = argc > 4 ? std::atoi(argv[4]) : 2;
     std::vector<float> tv, rv;
     for (int f = 0; f < 2; ++f) {
