@@ -71,7 +71,7 @@ def main():
     import torch
     from chameleonrt_amd import core, multi_gpu, scenes
     from chameleonrt_amd.render_hip import RenderHIP
-    from tests.parity import camera_of
+    from chameleonrt_amd.camera import camera_of
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

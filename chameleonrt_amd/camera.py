@@ -19,3 +19,10 @@ def look_at(eye, center, up):
     x = _n(np.cross(z, _n(up)))
     y = _n(np.cross(x, z))
     return eye, z, y
+
+
+def camera_of(scene):
+    """(eye, dir, up, fovy_deg) of a scene's first camera, as main.cpp:122-125,208-213 hands them to render()."""
+    cam = scene.cameras[0]
+    e, d, u = look_at(cam.position, cam.center, cam.up)
+    return e, d, u, cam.fov_y

@@ -195,7 +195,7 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
 
 /* Known-answer tests of the device shading functions: run device function `fn` on n
  * input records of in_stride floats, producing out_stride floats each (see
- * chameleonrt_amd/csrc/kat.h for the record layouts). */
+ * include/crt_kat.h for the record layouts). */
 int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_stride,
                 float *out, int out_stride);
 

@@ -1,7 +1,7 @@
 """Shared parity helpers for the GPU tests (HIP core vs CPU oracle)."""
 import numpy as np
 
-from chameleonrt_amd.camera import look_at
+from chameleonrt_amd.camera import camera_of, look_at  # noqa: F401  (camera_of re-exported for the tests)
 
 # Image tolerance (SURVEY §8c / north star "within a stated float tolerance"): the two
 # implementations evaluate the same expressions in the same order and differ only in libm
@@ -10,12 +10,6 @@ from chameleonrt_amd.camera import look_at
 # flips a discrete decision (shadow edge, Russian roulette, checker boundary) diverges
 # completely; such pixels are counted and must stay below 0.1 % of the image.
 ABS_TOL, REL_TOL, MAX_DIVERGED = 1e-4, 1e-3, 1e-3
-
-
-def camera_of(scene):
-    cam = scene.cameras[0]
-    e, d, u = look_at(cam.position, cam.center, cam.up)
-    return e, d, u, cam.fov_y
 
 
 def probe_rays(scene, n, seed=0, spread=0.3):

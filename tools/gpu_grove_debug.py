@@ -4,7 +4,7 @@ import numpy as np
 from chameleonrt_amd import scenes
 from chameleonrt_amd.render_hip import RenderHIP
 from tests.oracle_lib import OracleRenderer
-from tests.parity import camera_of
+from chameleonrt_amd.camera import camera_of
 sc = scenes.instanced_grove(); w, h = 320, 200
 r = RenderHIP(); r.initialize(w, h); r.set_scene(sc); o = OracleRenderer(sc, w, h)
 e, d, u, fovy = camera_of(sc)
