@@ -10,7 +10,7 @@ namespace crt {
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
 //                              BLAS: triangles [first, first+count) of Scene::tris
 //                              TLAS: instance `first` (count is 1)
-//                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children
+//                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children (builder output only)
 // The BVH is 4-wide: traversal is a chain of dependent node fetches whose latency, not bytes or
 // box-test ALU, bounds incoherent rays on MI355X (DESIGN.md "Traversal"), and a 4-wide node about
 // halves the length of that chain. BvhNode is what the host builder produces (full-precision
@@ -30,14 +30,19 @@ struct QFrame {
 };
 
 // One BVH4 node as the kernels see it: 64 B = 4 x dwordx4 per lane, one 16-byte quarter per child:
-// its AABB as 16-bit fixed point in the BVH's QFrame, rounded OUTWARD by at least one quantum
+// its AABB as 16-bit fixed point in the BVH's QFrame (one lo|hi dword per axis), rounded OUTWARD by at least one quantum
 // (conservative: a box may only grow, so no hit can be missed; which triangle wins never depends
 // on the boxes), and its reference. 64 B per 4 children is 2/3 of the bytes the same tree took as
 // 32-byte binary nodes.
 struct alignas(16) QChild {
-    uint16_t lo[3], hi[3];
+    uint16_t q[3][2]; // per axis: {lo, hi} -> one dword per axis, lo in the low half
     int32_t ref;
 };
+// An unused slot holds an INVERTED box (lo = 65535, hi = 0 on every axis), which the slab test
+// rejects by itself because it picks the near plane by the sign of the ray direction instead of
+// symmetrising with min/max (slab.h), and a COPY of slot 0's reference: should a degenerate ray get
+// through (origin so far away that both planes round to the same parameter), it revisits a sibling,
+// which cannot change any result. EMPTY_CHILD marks unused slots in the builder's BvhNode only.
 struct alignas(16) QNode {
     QChild child[BVH_WIDTH];
 };

@@ -1789,31 +1789,30 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 }
 
 // Foreign (product) BVH walk with the product's documented visit rule (DESIGN.md "Traversal
-// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {lo[3] hi[3] as uint16 fixed point,
-// ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
+// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
+// fixed point, ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
 // ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
-// ref == 0x80000002 unused slot; 48-byte triangle records. Children whose box is entered are
+// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; 48-byte triangle records. Children whose box is entered are
 // visited in ascending order of the key (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked
 // farthest first.
 namespace {
 struct FChild {
-    uint16_t lo[3], hi[3];
+    uint16_t q[3][2]; // per axis {lo, hi}; an unused slot is stored inverted (lo > hi)
     int32_t ref;
 };
 struct FNode {
     FChild child[4];
 };
-constexpr int32_t F_EMPTY = (int32_t)0x80000002;
 struct FTri {
     f3 v0, e1, e2;
     uint32_t geom, prim, pad;
 };
 static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48, "product BVH record sizes");
-inline bool fbox(const uint16_t lo[3], const uint16_t hi[3], f3 qa, f3 qb, float tmin, float tmax, float &tn)
+inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
-    const float t0x = std::fma((float)lo[0], qa.x, qb.x), t1x = std::fma((float)hi[0], qa.x, qb.x);
-    const float t0y = std::fma((float)lo[1], qa.y, qb.y), t1y = std::fma((float)hi[1], qa.y, qb.y);
-    const float t0z = std::fma((float)lo[2], qa.z, qb.z), t1z = std::fma((float)hi[2], qa.z, qb.z);
+    const float t0x = std::fma((float)q[0][0], qa.x, qb.x), t1x = std::fma((float)q[0][1], qa.x, qb.x);
+    const float t0y = std::fma((float)q[1][0], qa.y, qb.y), t1y = std::fma((float)q[1][1], qa.y, qb.y);
+    const float t0z = std::fma((float)q[2][0], qa.z, qb.z), t1z = std::fma((float)q[2][1], qa.z, qb.z);
     tn = std::fmax(std::fmax(std::fmin(t0x, t1x), std::fmin(t0y, t1y)), std::fmax(std::fmin(t0z, t1z), tmin));
     const float tf = std::fmin(std::fmin(std::fmax(t0x, t1x), std::fmax(t0y, t1y)),
                                std::fmin(std::fmax(t0z, t1z), tmax));
@@ -1853,7 +1852,9 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
                 for (uint32_t k = 0; k < 4; ++k) {
                     float tn;
                     uint32_t tb;
-                    if (nd.child[k].ref != F_EMPTY && fbox(nd.child[k].lo, nd.child[k].hi, qa, qb, tmin[i], best, tn)) {
+                    // (the kernel rejects inverted boxes inside its sign-ordered slab test; here, with the
+                    // symmetric min/max form, they are skipped explicitly -- same entry distances otherwise)
+                    if (nd.child[k].q[0][0] <= nd.child[k].q[0][1] && fbox(nd.child[k].q, qa, qb, tmin[i], best, tn)) {
                         std::memcpy(&tb, &tn, 4);
                         keys[n_hit++] = (tb & 0x7ffffffcu) | k;
                     }
