@@ -209,6 +209,12 @@ def main():
         dom, other = (rc, rs) if closest_ms >= shadow_ms else (rs, rc)
         out["roofline"] = dom
         out["roofline_other"] = other
+        # the contract's roofline axis for this path is HBM; what the PMC passes show to be binding is not
+        # (profiles/README.md): stated here so the line is not read as "HBM-bound"
+        out["roofline_note"] = ("achieved = algorithmic bytes (every node / triangle touch priced as an HBM access) / time; "
+                                "measured HBM-side traffic is `traffic` per launch (L2 + Infinity Cache absorb the rest). "
+                                "PMC: the traversal kernels are bound by VALU issue at ~32 of 64 lanes "
+                                "(SQ_INSTS_VALU*4 cycles / SIMD cycles = 0.9-1.0 on C4), then by the vector-memory front end")
         out["kernel_ms_per_step"] = {"trace_closest": round(closest_ms / args.steps, 4),
                                      "trace_shadow": round(shadow_ms / args.steps, 4),
                                      "raygen+shade+accumulate": round(shade_ms / args.steps, 4)}
