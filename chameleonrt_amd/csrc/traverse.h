@@ -141,7 +141,7 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 // model (tools/traverse_sim.cpp, real rays) this visits 0-3 % more nodes and removes ~19 of the
 // ~170 VALU instructions of a step; NOT yet run on a GPU, the counters test expects rule 0.
 #ifndef CRT_CHILD_ORDER
-#define CRT_CHILD_ORDER 0
+#define CRT_CHILD_ORDER 1 // on this branch: the candidate rule (the oracle's walker mirrors it here)
 #endif
 // occlusion rays visit children nearest first too: unsorted (lowest slot first) is 9 % faster on C2
 // but 14 % slower on C4, where the nearer child is much more often the occluder

@@ -1792,9 +1792,10 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 // rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
 // fixed point, ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
 // ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
-// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; 48-byte triangle records. Children whose box is entered are
-// visited in ascending order of the key (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked
-// farthest first.
+// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; 48-byte triangle
+// records. Of the children whose box is entered, the one with the smallest key
+// (bits(t_entry) & 0x7ffffffc) | slot is visited first; the others are stacked in slot order, highest
+// slot deepest (traverse.h, CRT_CHILD_ORDER = 1).
 namespace {
 struct FChild {
     uint16_t q[3][2]; // per axis {lo, hi}; an unused slot is stored inverted (lo > hi)
@@ -1860,11 +1861,19 @@ extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const
                     }
                 }
                 if (n_hit > 0) {
-                    std::sort(keys, keys + n_hit);
-                    for (int k = n_hit - 1; k >= 1; --k) {
-                        stack[sp++] = nd.child[keys[k] & 3u].ref;
+                    // nearest entered child first, the others stacked in slot order (highest slot deepest)
+                    int best = 0;
+                    for (int k = 1; k < n_hit; ++k) {
+                        if (keys[k] < keys[best]) {
+                            best = k;
+                        }
                     }
-                    cur = nd.child[keys[0] & 3u].ref;
+                    for (int k = n_hit - 1; k >= 0; --k) {
+                        if (k != best) {
+                            stack[sp++] = nd.child[keys[k] & 3u].ref;
+                        }
+                    }
+                    cur = nd.child[keys[best] & 3u].ref;
                     continue;
                 }
             } else {
