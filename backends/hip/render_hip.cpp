@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <future>
@@ -206,13 +207,24 @@ void RenderHIP::set_scene(const Scene &scene)
     desc.n_lights = uint32_t(scene.lights.size());
     desc.samples_per_pixel = scene.samples_per_pixel;
 
-    // every GPU keeps a full scene replica (a San-Miguel-class scene is ~2 GB of 288 GB)
+    // Every GPU keeps a full scene replica (a San-Miguel-class scene is ~2 GB of 288 GB). The host
+    // half of set_scene (BVH build = rtcCommitScene's job, texture linearisation) runs ONCE with all
+    // host cores; only the uploads are per device.
+    crt_hip_prepared_scene *prepared = crt_hip_prepare_scene(&desc, 0);
+    if (!prepared) {
+        throw std::runtime_error(std::string("RenderHIP: crt_hip_prepare_scene: ") + crt_hip_last_error(nullptr));
+    }
     std::vector<std::future<int>> jobs;
     for (crt_hip_ctx *c : ctxs) {
-        jobs.push_back(std::async(std::launch::async, [c, &desc]() { return crt_hip_set_scene(c, &desc); }));
+        jobs.push_back(std::async(std::launch::async, [c, prepared]() { return crt_hip_set_prepared_scene(c, prepared); }));
     }
-    for (size_t i = 0; i < jobs.size(); ++i) {
-        check(ctxs[i], jobs[i].get(), "crt_hip_set_scene");
+    std::vector<int> rcs;
+    for (auto &j : jobs) {
+        rcs.push_back(j.get());
+    }
+    crt_hip_free_prepared_scene(prepared);
+    for (size_t i = 0; i < rcs.size(); ++i) {
+        check(ctxs[i], rcs[i], "crt_hip_set_prepared_scene");
     }
 }
 
@@ -236,6 +248,9 @@ RenderStats RenderHIP::render(const glm::vec3 &pos,
         copy_image(true);
         return stats;
     }
+    // one wall clock around trace + gather + assemble + read-back, like the reference's render()
+    // (render_embree.cpp:177-211 times its whole body) and like the single-GPU path above
+    const auto t_begin = std::chrono::high_resolution_clock::now();
     const size_t n = ctxs.size();
     std::vector<crt_render_stats> st(n);
     std::vector<std::future<int>> jobs;
@@ -247,11 +262,9 @@ RenderStats RenderHIP::render(const glm::vec3 &pos,
         }));
     }
     double rays = 0.0;
-    float ms = 0.f;
     for (size_t i = 0; i < n; ++i) {
         check(ctxs[i], jobs[i].get(), "crt_hip_render");
         rays += double(st[i].rays);
-        ms = st[i].render_time_ms > ms ? st[i].render_time_ms : ms;
     }
     // gather: every device sends its compact RGBA8 tile slab to device 0 (<= 4 MiB each at 4K)
     nccl_ok(ncclGroupStart(), "ncclGroupStart");
@@ -267,6 +280,7 @@ RenderStats RenderHIP::render(const glm::vec3 &pos,
     nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
     check(ctxs[0], crt_hip_assemble_tiles(ctxs[0], multi->gathered, int(n), 1), "crt_hip_assemble_tiles");
     copy_image(true);
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
     stats.render_time = ms;
     stats.rays_per_second = float(rays / (ms * 1.0e-3));
     return stats;

@@ -25,7 +25,10 @@ EXPORTS = [
     "crt_hip_initialize", "crt_hip_set_scene", "crt_hip_render", "crt_hip_framebuffer",
     "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_frame_id", "crt_hip_tile_buffer",
     "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
-    "crt_hip_bvh_copy",
+    "crt_hip_bvh_copy", "crt_hip_bvh_layout", "crt_hip_bvh_copy_instances", "crt_hip_prepare_scene",
+    "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
+    "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
+    "crt_hip_child_order", "crt_hip_lds_stack_entries",
 ]
 
 
@@ -92,10 +95,26 @@ def load():
     L.crt_hip_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
     L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p, fp]
     L.crt_hip_bvh_copy.argtypes = [vp, vp, vp]
+    L.crt_hip_bvh_layout.argtypes = [vp, i32p, u32p, u32p, u32p, i32p]
+    L.crt_hip_bvh_copy_instances.argtypes = [vp, vp]
+    L.crt_hip_prepare_scene.restype = vp
+    L.crt_hip_prepare_scene.argtypes = [C.POINTER(SceneDesc), C.c_int]
+    L.crt_hip_free_prepared_scene.argtypes = [vp]
+    L.crt_hip_free_prepared_scene.restype = None
+    L.crt_hip_set_prepared_scene.argtypes = [vp, vp]
+    L.crt_hip_save_prepared_scene.argtypes = [vp, C.c_char_p]
+    L.crt_hip_load_prepared_scene.restype = vp
+    L.crt_hip_load_prepared_scene.argtypes = [C.c_char_p]
+    u64p = C.POINTER(C.c_uint64)
+    L.crt_hip_prepared_scene_info.argtypes = [vp, u64p, u64p, u64p, i32p, fp, i32p, u32p, u32p, C.POINTER(C.c_double)]
+    L.crt_hip_prepared_scene_copy.argtypes = [vp, vp, vp, vp]
+    L.crt_hip_child_order.restype = C.c_int
+    L.crt_hip_lds_stack_entries.restype = C.c_uint32
     for fn in ("crt_hip_set_stream", "crt_hip_set_partition", "crt_hip_initialize", "crt_hip_set_scene",
                "crt_hip_render", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_tile_buffer",
                "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
-               "crt_hip_bvh_copy"):
+               "crt_hip_bvh_copy", "crt_hip_bvh_layout", "crt_hip_bvh_copy_instances", "crt_hip_set_prepared_scene",
+               "crt_hip_save_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy"):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L

@@ -638,12 +638,12 @@ QNode quantise(const BvhNode &n, const QFrame &f)
         return (uint16_t)std::min(std::max(x, 0.0), 65535.0);
     };
     for (int k = 0; k < BVH_WIDTH; ++k) {
+        const bool used = n.c[k] != EMPTY_CHILD;
         for (int a = 0; a < 3; ++a) {
-            const bool used = n.c[k] != EMPTY_CHILD;
-            q.child[k].lo[a] = used ? lo(n.lo[k][a], a) : 0;
-            q.child[k].hi[a] = used ? hi(n.hi[k][a], a) : 0;
+            q.child[k].q[a][0] = used ? lo(n.lo[k][a], a) : 65535; // unused: inverted box (crt_types.h)
+            q.child[k].q[a][1] = used ? hi(n.hi[k][a], a) : 0;
         }
-        q.child[k].ref = n.c[k];
+        q.child[k].ref = used ? n.c[k] : n.c[0]; // slot 0 is always used (used slots come first)
     }
     return q;
 }

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -184,9 +186,9 @@ struct crt_hip_ctx {
     uint32_t spp = 1;
     SceneView sv{};
     DeviceBuffer d_spill, d_tri_uvs;
-    DeviceBuffer d_nodes, d_tris, d_instances, d_geoms, d_indices, d_uvs, d_material_ids, d_materials, d_textures,
-        d_texels, d_lights;
+    DeviceBuffer d_nodes, d_tris, d_instances, d_material_ids, d_materials, d_textures, d_texels, d_lights;
     uint64_t n_nodes = 0, n_tris = 0;
+    uint32_t stack_need = 0; // traversal-stack entries the deepest path of this scene's BVH can need
 
     // wavefront state
     uint64_t capacity = 0; // paths per pass
@@ -352,7 +354,7 @@ void check_scene(const crt_scene_desc *s)
     if (!s) {
         throw std::runtime_error("scene is null");
     }
-    if (s->n_instances == 0 || s->n_meshes == 0 || s->n_geometries == 0) {
+    if (s->n_instances == 0 || s->n_meshes == 0 || s->n_geometries == 0 || s->n_parameterized_meshes == 0) {
         throw std::runtime_error("scene has no instances/meshes/geometries");
     }
     if (s->n_lights == 0) {
@@ -360,6 +362,11 @@ void check_scene(const crt_scene_desc *s)
     }
     if (s->n_materials == 0) {
         throw std::runtime_error("scene has no materials");
+    }
+    // every array with a non-zero count must be there: nothing may crash across the C ABI
+    if (!s->instances || !s->meshes || !s->geometries || !s->parameterized_meshes || !s->materials || !s->lights ||
+        (s->n_textures != 0 && !s->textures)) {
+        throw std::runtime_error("scene has a NULL array with a non-zero count");
     }
     for (uint32_t i = 0; i < s->n_instances; ++i) {
         const uint32_t pm = s->instances[i].parameterized_mesh_id;
@@ -370,6 +377,9 @@ void check_scene(const crt_scene_desc *s)
         if (p.mesh_id >= s->n_meshes || p.n_material_ids < s->meshes[p.mesh_id].n_geometries) {
             throw std::runtime_error("parameterized mesh / material id count mismatch");
         }
+        if (p.n_material_ids != 0 && !p.material_ids) {
+            throw std::runtime_error("parameterized mesh without its material id array");
+        }
         for (uint32_t k = 0; k < p.n_material_ids; ++k) {
             if (p.material_ids[k] >= s->n_materials) {
                 throw std::runtime_error("material id out of range");
@@ -377,12 +387,18 @@ void check_scene(const crt_scene_desc *s)
         }
     }
     for (uint32_t m = 0; m < s->n_meshes; ++m) {
-        if (s->meshes[m].first_geometry + s->meshes[m].n_geometries > s->n_geometries) {
+        if ((uint64_t)s->meshes[m].first_geometry + (uint64_t)s->meshes[m].n_geometries > (uint64_t)s->n_geometries) {
             throw std::runtime_error("mesh geometry range out of bounds");
         }
     }
     for (uint32_t g = 0; g < s->n_geometries; ++g) {
         const crt_geometry_desc &gd = s->geometries[g];
+        if ((gd.n_vertices != 0 && !gd.vertices) || (gd.n_triangles != 0 && !gd.indices)) {
+            throw std::runtime_error("geometry without its vertex / index array");
+        }
+        if (gd.n_triangles >= (1ull << 32) || gd.n_vertices >= (1ull << 32)) {
+            throw std::runtime_error("geometry too large for 32-bit indices");
+        }
         for (uint64_t t = 0; t < 3 * gd.n_triangles; ++t) {
             if (gd.indices[t] >= gd.n_vertices) {
                 throw std::runtime_error("triangle index out of range");
@@ -401,6 +417,32 @@ void check_scene(const crt_scene_desc *s)
             }
         }
     }
+}
+
+// Host cores this process may use: affinity mask, capped by the cgroup CPU quota (a container
+// with 16 of 128 cores must not start 128 build threads), overridable with CRT_HIP_BUILD_THREADS.
+int host_threads()
+{
+    if (const char *e = std::getenv("CRT_HIP_BUILD_THREADS")) {
+        const int v = std::atoi(e);
+        if (v > 0) {
+            return v;
+        }
+    }
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        n = std::max(1, std::min(n, CPU_COUNT(&set)));
+    }
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            n = std::max(1, std::min(n, (int)(std::atoll(quota) / period)));
+        }
+        std::fclose(f);
+    }
+    return n;
 }
 
 } // namespace
@@ -534,12 +576,36 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
     });
 }
 
-// RenderEmbree::set_scene (render_embree.cpp:58-133, embree_utils.cpp:9-136)
-int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
+} // extern "C"
+
+// ---- set_scene, host half: everything that does not need a device -------------------------------
+// RenderEmbree::set_scene (render_embree.cpp:58-133, embree_utils.cpp:9-136): one BLAS per Mesh, the
+// TLAS over the instances, sRGB -> linear textures in 8 bits, material and light tables -- as the flat
+// arrays the kernels read. Split from the upload so that the GPUs of one node share ONE build
+// (RenderHIP::set_scene prepares once and uploads to every context; bench.py's rank 0 prepares, saves
+// to /dev/shm and the other ranks load).
+struct crt_hip_prepared_scene {
+    std::vector<QNode> nodes;
+    std::vector<TriRec> tris;
+    std::vector<float> tri_uvs; // 6 per TriRec
+    std::vector<InstanceRec> insts;
+    std::vector<uint32_t> material_ids;
+    std::vector<float> materials, lights;
+    std::vector<TexRec> tex;
+    std::vector<uint8_t> texels;
+    QFrame root_frame{};
+    int32_t root = 0;
+    uint32_t two_level = 0, n_top = 0, n_lights = 0, n_instances = 0, spp = 1, stack_need = 0;
+    double build_ms = 0.0;
+};
+
+namespace {
+
+void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads)
 {
-    return guarded(ctx, [&]() -> int {
         const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
         auto t_phase = std::chrono::high_resolution_clock::now();
+        const auto t_begin = t_phase;
         auto phase = [&](const char *what) {
             const auto now = std::chrono::high_resolution_clock::now();
             if (dbg) {
@@ -550,47 +616,12 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         };
         check_scene(s);
         phase("validate");
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        ctx->frame_id = 0;
-        ctx->has_scene = false;
-        ctx->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
-        ctx->capacity = 0;
-        const int n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-
-        // geometry tables
-        std::vector<GeomRec> geoms(s->n_geometries);
-        std::vector<uint32_t> indices;
-        std::vector<float> uvs;
-        {
-            uint64_t n_idx = 0, n_uv = 0;
-            for (uint32_t g = 0; g < s->n_geometries; ++g) {
-                n_idx += 3 * s->geometries[g].n_triangles;
-                n_uv += s->geometries[g].uvs ? 2 * s->geometries[g].n_vertices : 0;
-            }
-            indices.reserve(n_idx);
-            uvs.reserve(n_uv);
-        }
-        for (uint32_t g = 0; g < s->n_geometries; ++g) {
-            const crt_geometry_desc &gd = s->geometries[g];
-            if (indices.size() / 3 + gd.n_triangles >= (1ull << 32) || uvs.size() / 2 + gd.n_vertices >= (1ull << 31)) {
-                throw std::runtime_error("scene too large for 32-bit geometry tables");
-            }
-            geoms[g].index_base = (uint32_t)(indices.size() / 3);
-            indices.insert(indices.end(), gd.indices, gd.indices + 3 * gd.n_triangles);
-            if (gd.uvs) {
-                geoms[g].uv_base = (int32_t)(uvs.size() / 2);
-                uvs.insert(uvs.end(), gd.uvs, gd.uvs + 2 * gd.n_vertices);
-            } else {
-                geoms[g].uv_base = -1;
-            }
-        }
-
-        phase("geometry tables");
+        ps->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
+        std::vector<QNode> &nodes = ps->nodes;
+        std::vector<TriRec> &tris = ps->tris;
+        std::vector<float> &tri_uvs = ps->tri_uvs;
         // one BLAS per Mesh (embree_utils.cpp:63-76)
         const bool two_level = s->n_instances > 1;
-        std::vector<QNode> nodes;
-        std::vector<TriRec> tris;
-        std::vector<float> tri_uvs; // 6 per TriRec
         std::vector<QFrame> blas_frame(s->n_meshes);
         std::vector<int32_t> blas_root(s->n_meshes);
         std::vector<Aabb> blas_bounds(s->n_meshes);
@@ -665,8 +696,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 
         phase("leaf-order triangles");
         // instances + TLAS (embree_utils.cpp:90-104, 121-129)
-        std::vector<InstanceRec> insts(s->n_instances);
-        std::vector<uint32_t> material_ids;
+        std::vector<InstanceRec> &insts = ps->insts;
+        insts.assign(s->n_instances, InstanceRec{});
+        std::vector<uint32_t> &material_ids = ps->material_ids;
         std::vector<Aabb> inst_boxes(s->n_instances);
         for (uint32_t i = 0; i < s->n_instances; ++i) {
             const crt_instance_desc &id = s->instances[i];
@@ -742,10 +774,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             built[m] = BuiltBvh();
         }
         // a ray's stack holds at most BVH_WIDTH-1 pending siblings per level of the path it is on,
-        // plus the instance-exit sentinel
-        if ((BVH_WIDTH - 1) * (blas_depth + tlas_depth) + 1 > traversal_stack_capacity()) {
-            throw std::runtime_error("BVH too deep for the traversal stack");
-        }
+        // plus the instance-exit sentinel. The LDS part of the stack is fixed; the HBM slab behind it is
+        // sized from this number at upload, so no tree is "too deep" (the reference renders any scene)
+        ps->stack_need = (BVH_WIDTH - 1) * (blas_depth + tlas_depth) + 2;
         if (tris.size() >= (1u << 28)) {
             throw std::runtime_error("too many triangles for the 28-bit leaf reference");
         }
@@ -761,8 +792,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 
         phase("TLAS + quantisation");
         // textures: sRGB -> linear in 8 bits, on the host, like the reference (render_embree.cpp:90-104)
-        std::vector<TexRec> tex(s->n_textures);
-        std::vector<uint8_t> texels;
+        std::vector<TexRec> &tex = ps->tex;
+        tex.assign(s->n_textures, TexRec{});
+        std::vector<uint8_t> &texels = ps->texels;
         {
             size_t total = 0;
             for (uint32_t t = 0; t < s->n_textures; ++t) {
@@ -801,54 +833,253 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
             }
             tex[t] = r;
         }
-        std::vector<float> materials((size_t)s->n_materials * 16);
+        std::vector<float> &materials = ps->materials;
+        materials.assign((size_t)s->n_materials * 16, 0.f);
         std::memcpy(materials.data(), s->materials, materials.size() * sizeof(float));
-        std::vector<float> lights((size_t)s->n_lights * 20);
+        std::vector<float> &lights = ps->lights;
+        lights.assign((size_t)s->n_lights * 20, 0.f);
         std::memcpy(lights.data(), s->lights, lights.size() * sizeof(float));
 
         phase("textures");
-        upload(ctx->d_nodes, nodes, ctx->stream);
-        upload(ctx->d_tris, tris, ctx->stream);
-        upload(ctx->d_tri_uvs, tri_uvs, ctx->stream);
-        upload(ctx->d_instances, insts, ctx->stream);
-        upload(ctx->d_geoms, geoms, ctx->stream);
-        upload(ctx->d_indices, indices, ctx->stream);
-        upload(ctx->d_uvs, uvs, ctx->stream);
-        upload(ctx->d_material_ids, material_ids, ctx->stream);
-        upload(ctx->d_materials, materials, ctx->stream);
-        upload(ctx->d_textures, tex, ctx->stream);
-        upload(ctx->d_texels, texels, ctx->stream);
-        upload(ctx->d_lights, lights, ctx->stream);
-        phase("upload");
-        ctx->n_nodes = nodes.size();
-        ctx->n_tris = tris.size();
+        ps->root_frame = root_frame;
+        ps->root = root;
+        ps->two_level = two_level ? 1u : 0u;
+        ps->n_top = n_top;
+        ps->n_lights = s->n_lights;
+        ps->n_instances = s->n_instances;
+        ps->build_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
+}
 
-        SceneView &sv = ctx->sv;
-        sv.nodes = ctx->d_nodes.as<QNode>();
-        sv.root_frame = root_frame;
-        sv.tris = ctx->d_tris.as<TriRec>();
-        sv.tri_uvs = ctx->d_tri_uvs.as<float>();
-        sv.instances = ctx->d_instances.as<InstanceRec>();
-        sv.geoms = ctx->d_geoms.as<GeomRec>();
-        sv.indices = ctx->d_indices.as<uint32_t>();
-        sv.uvs = ctx->d_uvs.as<float>();
-        sv.material_ids = ctx->d_material_ids.as<uint32_t>();
-        sv.materials = ctx->d_materials.as<float>();
-        sv.textures = ctx->d_textures.as<TexRec>();
-        sv.texels = ctx->d_texels.as<uint8_t>();
-        sv.lights = ctx->d_lights.as<float>();
-        sv.n_lights = s->n_lights;
-        sv.n_instances = s->n_instances;
-        sv.spill_stride = traversal_grid_threads(ctx->n_cus);
-        const size_t spill_words = (size_t)sv.spill_stride * traversal_spill_depth();
-        ctx->d_spill.alloc((ctx->overlap ? 2 : 1) * spill_words * sizeof(int32_t));
-        sv.stack_spill = ctx->d_spill.as<int32_t>();
-        sv.root = root;
-        sv.two_level = two_level ? 1u : 0u;
-        sv.n_top_nodes = n_top;
-        ctx->has_scene = true;
+// device half of set_scene: the prepared arrays -> HBM, SceneView, traversal-stack slab
+void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
+{
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->frame_id = 0;
+    ctx->has_scene = false;
+    ctx->spp = ps.spp;
+    ctx->capacity = 0;
+    upload(ctx->d_nodes, ps.nodes, ctx->stream);
+    upload(ctx->d_tris, ps.tris, ctx->stream);
+    upload(ctx->d_tri_uvs, ps.tri_uvs, ctx->stream);
+    upload(ctx->d_instances, ps.insts, ctx->stream);
+    upload(ctx->d_material_ids, ps.material_ids, ctx->stream);
+    upload(ctx->d_materials, ps.materials, ctx->stream);
+    upload(ctx->d_textures, ps.tex, ctx->stream);
+    upload(ctx->d_texels, ps.texels, ctx->stream);
+    upload(ctx->d_lights, ps.lights, ctx->stream);
+    ctx->n_nodes = ps.nodes.size();
+    ctx->n_tris = ps.tris.size();
+    ctx->stack_need = ps.stack_need;
+
+    SceneView &sv = ctx->sv;
+    sv.nodes = ctx->d_nodes.as<QNode>();
+    sv.root_frame = ps.root_frame;
+    sv.tris = ctx->d_tris.as<TriRec>();
+    sv.tri_uvs = ctx->d_tri_uvs.as<float>();
+    sv.instances = ctx->d_instances.as<InstanceRec>();
+    sv.material_ids = ctx->d_material_ids.as<uint32_t>();
+    sv.materials = ctx->d_materials.as<float>();
+    sv.textures = ctx->d_textures.as<TexRec>();
+    sv.texels = ctx->d_texels.as<uint8_t>();
+    sv.lights = ctx->d_lights.as<float>();
+    sv.n_lights = ps.n_lights;
+    sv.n_instances = ps.n_instances;
+    // HBM part of the per-lane traversal stack: what the deepest path can need beyond the LDS part,
+    // [wave of the persistent grid][depth][lane]
+    sv.spill_depth = std::max<uint32_t>(8u, ps.stack_need > traversal_lds_stack() ? ps.stack_need - traversal_lds_stack() : 0u);
+    sv.spill_stride = traversal_grid_threads(ctx->n_cus);
+    const size_t spill_words = (size_t)sv.spill_stride * sv.spill_depth;
+    ctx->d_spill.alloc((ctx->overlap ? 2 : 1) * spill_words * sizeof(int32_t));
+    sv.stack_spill = ctx->d_spill.as<int32_t>();
+    sv.root = ps.root;
+    sv.two_level = ps.two_level;
+    sv.n_top_nodes = ps.n_top;
+    ctx->has_scene = true;
+}
+
+} // namespace
+
+// Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
+// path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
+namespace {
+constexpr uint64_t PREP_MAGIC = 0x3130505250545243ull; // "CRTPRP01"
+struct PrepHeader {
+    uint64_t magic, abi;
+    uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;
+    QFrame root_frame;
+    int32_t root;
+    uint32_t two_level, n_top, n_lights, n_instances, spp, stack_need, pad;
+};
+template <typename T> bool prep_put(FILE *f, const std::vector<T> &v) { return v.empty() || std::fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
+template <typename T> bool prep_get(FILE *f, std::vector<T> &v, uint64_t n)
+{
+    v.resize(n);
+    return n == 0 || std::fread(v.data(), sizeof(T), n, f) == n;
+}
+} // namespace
+
+extern "C" {
+
+crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads)
+{
+    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
+    try {
+        prepare_scene(scene, ps.get(), n_threads > 0 ? n_threads : host_threads());
+    } catch (const std::exception &e) {
+        g_create_error = e.what();
+        return nullptr;
+    }
+    return ps.release();
+}
+
+void crt_hip_free_prepared_scene(crt_hip_prepared_scene *ps) { delete ps; }
+
+int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *ps)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ps) {
+            return fail(ctx, CRT_HIP_EINVAL, "prepared scene is null");
+        }
+        upload_scene(ctx, *ps);
         return CRT_HIP_OK;
     });
+}
+
+// RenderBackend::set_scene = prepare + upload
+int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
+{
+    return guarded(ctx, [&]() -> int {
+        crt_hip_prepared_scene ps;
+        prepare_scene(s, &ps, host_threads());
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        upload_scene(ctx, ps);
+        if (std::getenv("CRT_HIP_DEBUG")) {
+            std::fprintf(stderr, "[crt_hip] set_scene %-22s %8.1f ms\n", "upload",
+                         std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *ps, uint64_t *n_nodes, uint64_t *n_tris,
+                                uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
+                                uint32_t *n_top_nodes, uint32_t *stack_need, double *build_ms)
+{
+    if (!ps) {
+        return fail(nullptr, CRT_HIP_EINVAL, "prepared scene is null");
+    }
+    if (n_nodes) {
+        *n_nodes = ps->nodes.size();
+    }
+    if (n_tris) {
+        *n_tris = ps->tris.size();
+    }
+    if (n_instances) {
+        *n_instances = ps->insts.size();
+    }
+    if (two_level) {
+        *two_level = (int32_t)ps->two_level;
+    }
+    if (root_frame) {
+        std::memcpy(root_frame, &ps->root_frame, sizeof(QFrame));
+    }
+    if (root) {
+        *root = ps->root;
+    }
+    if (n_top_nodes) {
+        *n_top_nodes = ps->n_top;
+    }
+    if (stack_need) {
+        *stack_need = ps->stack_need;
+    }
+    if (build_ms) {
+        *build_ms = ps->build_ms;
+    }
+    return CRT_HIP_OK;
+}
+
+int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *ps, void *nodes, void *tris, void *instances)
+{
+    if (!ps) {
+        return fail(nullptr, CRT_HIP_EINVAL, "prepared scene is null");
+    }
+    if (nodes) {
+        std::memcpy(nodes, ps->nodes.data(), ps->nodes.size() * sizeof(QNode));
+    }
+    if (tris) {
+        std::memcpy(tris, ps->tris.data(), ps->tris.size() * sizeof(TriRec));
+    }
+    if (instances) {
+        std::memcpy(instances, ps->insts.data(), ps->insts.size() * sizeof(InstanceRec));
+    }
+    return CRT_HIP_OK;
+}
+
+int crt_hip_child_order(void) { return traversal_child_order(); }
+uint32_t crt_hip_lds_stack_entries(void) { return traversal_lds_stack(); }
+
+int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *path)
+{
+    if (!ps || !path) {
+        return fail(nullptr, CRT_HIP_EINVAL, "save_prepared_scene: bad arguments");
+    }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) {
+        return fail(nullptr, CRT_HIP_EINVAL, std::string("cannot write ") + path);
+    }
+    PrepHeader h{};
+    h.magic = PREP_MAGIC;
+    h.abi = CRT_HIP_ABI_VERSION;
+    h.n_nodes = ps->nodes.size();
+    h.n_tris = ps->tris.size();
+    h.n_insts = ps->insts.size();
+    h.n_matids = ps->material_ids.size();
+    h.n_materials = ps->materials.size();
+    h.n_lights_f = ps->lights.size();
+    h.n_tex = ps->tex.size();
+    h.n_texels = ps->texels.size();
+    h.root_frame = ps->root_frame;
+    h.root = ps->root;
+    h.two_level = ps->two_level;
+    h.n_top = ps->n_top;
+    h.n_lights = ps->n_lights;
+    h.n_instances = ps->n_instances;
+    h.spp = ps->spp;
+    h.stack_need = ps->stack_need;
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && prep_put(f, ps->nodes) && prep_put(f, ps->tris) && prep_put(f, ps->tri_uvs) &&
+                    prep_put(f, ps->insts) && prep_put(f, ps->material_ids) && prep_put(f, ps->materials) && prep_put(f, ps->lights) &&
+                    prep_put(f, ps->tex) && prep_put(f, ps->texels);
+    const bool closed = std::fclose(f) == 0;
+    return ok && closed ? CRT_HIP_OK : fail(nullptr, CRT_HIP_EINVAL, std::string("short write to ") + path);
+}
+
+crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
+{
+    FILE *f = path ? std::fopen(path, "rb") : nullptr;
+    if (!f) {
+        g_create_error = std::string("cannot read ") + (path ? path : "(null)");
+        return nullptr;
+    }
+    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
+    PrepHeader h{};
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == PREP_MAGIC && h.abi == CRT_HIP_ABI_VERSION;
+    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->tris, h.n_tris) && prep_get(f, ps->tri_uvs, 6 * h.n_tris) &&
+         prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
+         prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
+    std::fclose(f);
+    if (!ok) {
+        g_create_error = std::string("not a prepared scene of this build: ") + path;
+        return nullptr;
+    }
+    ps->root_frame = h.root_frame;
+    ps->root = h.root;
+    ps->two_level = h.two_level;
+    ps->n_top = h.n_top;
+    ps->n_lights = h.n_lights;
+    ps->n_instances = h.n_instances;
+    ps->spp = h.spp;
+    ps->stack_need = h.stack_need;
+    return ps.release();
 }
 
 // RenderEmbree::render (render_embree.cpp:135-216)
@@ -924,7 +1155,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         aux_cfg.stream = ctx->aux_stream;
         SceneView aux_sv = ctx->sv;
         if (overlap) {
-            aux_sv.stack_spill += (size_t)aux_sv.spill_stride * traversal_spill_depth();
+            aux_sv.stack_spill += (size_t)aux_sv.spill_stride * aux_sv.spill_depth;
         }
         const auto t0 = std::chrono::high_resolution_clock::now();
         uint32_t pass = 0;
@@ -1284,6 +1515,45 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
         if (tris) {
             HIP_CHECK(hipMemcpy(tris, ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
         }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_bvh_layout(crt_hip_ctx *ctx, int32_t *root, uint32_t *n_top_nodes, uint32_t *stack_need,
+                       uint32_t *lds_stack, int32_t *child_order)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene) {
+            return fail(ctx, CRT_HIP_ESTATE, "bvh_layout before set_scene");
+        }
+        if (root) {
+            *root = ctx->sv.root;
+        }
+        if (n_top_nodes) {
+            *n_top_nodes = ctx->sv.n_top_nodes;
+        }
+        if (stack_need) {
+            *stack_need = ctx->stack_need;
+        }
+        if (lds_stack) {
+            *lds_stack = traversal_lds_stack();
+        }
+        if (child_order) {
+            *child_order = traversal_child_order();
+        }
+        return CRT_HIP_OK;
+    });
+}
+
+int crt_hip_bvh_copy_instances(crt_hip_ctx *ctx, void *instances)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!ctx->has_scene || !instances) {
+            return fail(ctx, CRT_HIP_ESTATE, "bvh_copy_instances: no scene / null buffer");
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpy(instances, ctx->d_instances.ptr, (size_t)ctx->sv.n_instances * sizeof(InstanceRec),
+                            hipMemcpyDeviceToHost));
         return CRT_HIP_OK;
     });
 }

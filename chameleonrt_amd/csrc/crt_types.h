@@ -10,10 +10,10 @@ namespace crt {
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
 //                              BLAS: triangles [first, first+count) of Scene::tris
 //                              TLAS: instance `first` (count is 1)
-//                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children
-// The BVH is 4-wide: traversal is a chain of dependent node fetches whose latency, not bytes or
-// box-test ALU, bounds incoherent rays on MI355X (DESIGN.md "Traversal"), and a 4-wide node about
-// halves the length of that chain. BvhNode is what the host builder produces (full-precision
+//                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children (builder output only)
+// The BVH is 4-wide: one fetch decides four children, which about halves the chain of dependent
+// node fetches of a ray and the per-node bookkeeping (DESIGN.md "Traversal"; what bounds the kernel
+// is analysed there with PMC counters, not assumed here). BvhNode is what the host builder produces (full-precision
 // boxes of all children); the traversal kernels read the 64-byte quantised form below.
 constexpr int BVH_WIDTH = 4;
 constexpr int32_t EMPTY_CHILD = (int32_t)0x80000002;
@@ -30,14 +30,19 @@ struct QFrame {
 };
 
 // One BVH4 node as the kernels see it: 64 B = 4 x dwordx4 per lane, one 16-byte quarter per child:
-// its AABB as 16-bit fixed point in the BVH's QFrame, rounded OUTWARD by at least one quantum
+// its AABB as 16-bit fixed point in the BVH's QFrame (one lo|hi dword per axis), rounded OUTWARD by at least one quantum
 // (conservative: a box may only grow, so no hit can be missed; which triangle wins never depends
 // on the boxes), and its reference. 64 B per 4 children is 2/3 of the bytes the same tree took as
 // 32-byte binary nodes.
 struct alignas(16) QChild {
-    uint16_t lo[3], hi[3];
+    uint16_t q[3][2]; // per axis: {lo, hi} -> one dword per axis, lo in the low half
     int32_t ref;
 };
+// An unused slot holds an INVERTED box (lo = 65535, hi = 0 on every axis), which the slab test
+// rejects by itself because it picks the near plane by the sign of the ray direction instead of
+// symmetrising with min/max (slab.h), and a COPY of slot 0's reference: should a degenerate ray get
+// through (origin so far away that both planes round to the same parameter), it revisits a sibling,
+// which cannot change any result. EMPTY_CHILD marks unused slots in the builder's BvhNode only.
 struct alignas(16) QNode {
     QChild child[BVH_WIDTH];
 };
@@ -64,13 +69,6 @@ struct alignas(16) InstanceRec {
 };
 static_assert(sizeof(InstanceRec) == 128, "InstanceRec must be 128 bytes");
 
-// Per-geometry shading data (ISPCGeometry, backends/embree/embree_utils.h:38-46): only the
-// index buffer and UVs are ever read by the hot path (normals are ignored, quirk Q7).
-struct GeomRec {
-    uint32_t index_base; // first uint3 of this geometry in Scene::indices (in triangles)
-    int32_t uv_base;     // first float2 in Scene::uvs, or -1 if the geometry has no UVs
-};
-
 // ISPCTexture2D (backends/embree/texture2d.ih:6-11); texels live in one byte blob.
 struct alignas(16) TexRec {
     int32_t width, height, channels, pad;
@@ -92,10 +90,7 @@ struct SceneView {
     const QNode *nodes;
     const TriRec *tris;
     const InstanceRec *instances;
-    const GeomRec *geoms;
     const float *tri_uvs;         // 6 floats per TriRec (uv of v0, v1, v2), same order as `tris`
-    const uint32_t *indices;      // 3 per triangle (kept for introspection; the hot path reads tri_uvs)
-    const float *uvs;             // 2 per vertex
     const uint32_t *material_ids; // per instance per geomID
     const float *materials;       // 16 floats per material (14 used, MaterialParams order)
     const TexRec *textures;
@@ -109,6 +104,7 @@ struct SceneView {
     uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
     int32_t *stack_spill;         // traversal-stack overflow slab, [wave of the persistent grid][depth][lane]
     uint32_t spill_stride;        // threads the slab was sized for
+    uint32_t spill_depth;         // entries per lane in the slab (sized at set_scene from the depth of this scene's BVH)
 };
 
 constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)

@@ -21,8 +21,8 @@ struct LaunchCfg {
 
 // Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).
 uint32_t traversal_grid_threads(int n_cus);
-uint32_t traversal_spill_depth();
-uint32_t traversal_stack_capacity(); // entries a ray may have pending (LDS part + slab part)
+uint32_t traversal_lds_stack(); // per-lane stack entries kept in LDS; deeper ones go to the HBM slab
+int traversal_child_order();    // the build's CRT_CHILD_ORDER (the oracle's BVH walker mirrors the rule)
 
 // K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.
 void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,

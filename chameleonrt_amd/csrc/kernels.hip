@@ -249,7 +249,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, Pat
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(SceneView sc, Shad
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const ShadowSource src{sa, sb, radiance};
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (SPILL_STACK * 64) +
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
@@ -840,8 +840,8 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 
 // ---- launchers ---------------------------------------------------------------------------------
 uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
-uint32_t traversal_spill_depth() { return (uint32_t)SPILL_STACK; }
-uint32_t traversal_stack_capacity() { return (uint32_t)(LDS_STACK + SPILL_STACK); }
+uint32_t traversal_lds_stack() { return (uint32_t)LDS_STACK; }
+int traversal_child_order() { return CRT_CHILD_ORDER; }
 
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
 static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)

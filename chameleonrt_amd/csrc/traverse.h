@@ -14,6 +14,7 @@
 // a wave's accesses are conflict-free) and the rest in an HBM slab.
 #pragma once
 #include "pt_device.h"
+#include "slab.h"
 
 namespace crt {
 
@@ -22,10 +23,10 @@ namespace crt {
 #endif
 constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
-// and compact per wave (22 KB), so deep traversals stay within a few pages.
+// and compact per wave, so deep traversals stay within a few pages. Its depth is a property of the
+// scene (SceneView::spill_depth, sized at set_scene from the BVH's depth), not a compile-time limit.
 // Not a private array: scratch-backed kernels get their wave occupancy throttled by the
 // runtime's scratch ring, which cost this kernel most of its latency hiding.
-constexpr int SPILL_STACK = 96 - CRT_LDS_STACK;
 constexpr int32_t STACK_SENTINEL = (int32_t)0x80000000; // marks "leave instance" (two-level)
 
 struct RayHit {
@@ -74,31 +75,11 @@ CRT_DEV V3 xfm_vector(const float *m, V3 v)
 
 CRT_DEV float box_dir(float x) { return fabsf(x) < 1e-18f ? copysignf(1e-18f, x) : x; }
 
-// Slab test of one quantised child box. A plane at fixed-point coordinate q lies at
-// base + q*step, so its ray parameter is ((base + q*step) - o) * inv = q*qa + qb with
-// qa = step*inv and qb = (base - o)*inv computed once per ray and frame: one FMA per plane.
-// The boxes carry a full quantum of outward slack, far more than the FMA's rounding error.
-CRT_DEV bool slab_q(uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix, uint32_t hiy, uint32_t hiz, V3 qa, V3 qb,
-                    float tmin, float tmax, float &tn)
-{
-    const float t0x = __builtin_fmaf((float)lox, qa.x, qb.x), t1x = __builtin_fmaf((float)hix, qa.x, qb.x);
-    const float t0y = __builtin_fmaf((float)loy, qa.y, qb.y), t1y = __builtin_fmaf((float)hiy, qa.y, qb.y);
-    const float t0z = __builtin_fmaf((float)loz, qa.z, qb.z), t1z = __builtin_fmaf((float)hiz, qa.z, qb.z);
-    tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    return tn <= tf * 1.0000004f;
-}
-
-// Sort key of one child of a wide node (see the inner-node phase of trace_wavefront).
-// (Packed v_pk_fma_f32 for the two planes of an axis was measured: +1.6 % on C2, -1.5 % on C4,
-// where the kernel is VALU-issue bound; the scalar form stays.)
+// The ray / quantised-box test lives in slab.h (shared with the host-side check).
 typedef uint32_t tv_u4 __attribute__((ext_vector_type(4))); // plain vector: loadable from any address space
-CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, V3 qa, V3 qb, float tmin, float tmax)
+CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, const SlabRay &sr, float tmin, float tmax)
 {
-    float tn;
-    const bool hit = slab_q(k.x & 0xffffu, k.x >> 16, k.y & 0xffffu, k.y >> 16, k.z & 0xffffu, k.z >> 16, qa, qb, tmin,
-                            tmax, tn);
-    return hit && (int32_t)k.w != EMPTY_CHILD ? ((__float_as_uint(tn) & 0x7ffffffcu) | slot) : 0xffffffffu;
+    return slab_child_key(k.x, k.y, k.z, slot, sr, tmin, tmax);
 }
 
 CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D, float tnear, float tfar,
@@ -216,7 +197,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     int32_t cur = CUR_DONE;
     V3 org = v3(0.f), dir = v3(0.f); // world-space ray
     V3 o = v3(0.f), d = v3(0.f);                 // ray in the space being traversed
-    V3 qa = v3(0.f), qb = v3(0.f);               // that ray in the fixed-point frame of the current BVH
+    SlabRay sr;                                  // that ray in the fixed-point frame of the current BVH
+    sr.qa[0] = sr.qa[1] = sr.qa[2] = sr.qb[0] = sr.qb[1] = sr.qb[2] = 0.f;
+    sr.rot[0] = sr.rot[1] = sr.rot[2] = 0u;
     float tfar = 0.f;
     RayHit hit;
     hit.t = 0.f;
@@ -238,8 +221,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     // than the boxes' one-quantum margin, so the test stays conservative. Triangles use the true d.
     auto set_frame = [&](const QFrame &f) {
         const V3 inv = v3(1.f / box_dir(d.x), 1.f / box_dir(d.y), 1.f / box_dir(d.z));
-        qa = v3(f.step[0] * inv.x, f.step[1] * inv.y, f.step[2] * inv.z);
-        qb = v3((f.base[0] - o.x) * inv.x, (f.base[1] - o.y) * inv.y, (f.base[2] - o.z) * inv.z);
+        sr.qa[0] = f.step[0] * inv.x;
+        sr.qa[1] = f.step[1] * inv.y;
+        sr.qa[2] = f.step[2] * inv.z;
+        sr.qb[0] = (f.base[0] - o.x) * inv.x;
+        sr.qb[1] = (f.base[1] - o.y) * inv.y;
+        sr.qb[2] = (f.base[2] - o.z) * inv.z;
+        sr.rot[0] = slab_rot_of(sr.qa[0]);
+        sr.rot[1] = slab_rot_of(sr.qa[1]);
+        sr.rot[2] = slab_rot_of(sr.qa[2]);
     };
 
     // start traversing the world-space ray (org, dir, tfar)
@@ -342,7 +332,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 break;
             }
             if (inner) {
-                // one 16-byte quarter per child: {lox|loy, loz|hix, hiy|hiz, ref}
+                // one 16-byte quarter per child: {x: lo|hi, y: lo|hi, z: lo|hi, ref}
                 tv_u4 k0, k1, k2, k3;
                 if (cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
                     const TV_LDS tv_u4 *p = (const TV_LDS tv_u4 *)(top + (cur - top_lo));
@@ -366,10 +356,10 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
                 // the slot makes keys distinct and breaks ties towards the lower slot); children
                 // that are missed, or unused slots, get the all-ones key.
-                const uint32_t s0 = child_key(k0, 0u, qa, qb, tnear, hit.t);
-                const uint32_t s1 = child_key(k1, 1u, qa, qb, tnear, hit.t);
-                const uint32_t s2 = child_key(k2, 2u, qa, qb, tnear, hit.t);
-                const uint32_t s3 = child_key(k3, 3u, qa, qb, tnear, hit.t);
+                const uint32_t s0 = child_key(k0, 0u, sr, tnear, hit.t);
+                const uint32_t s1 = child_key(k1, 1u, sr, tnear, hit.t);
+                const uint32_t s2 = child_key(k2, 2u, sr, tnear, hit.t);
+                const uint32_t s3 = child_key(k3, 3u, sr, tnear, hit.t);
                 // 5-comparator sorting network
                 const uint32_t a0 = min(s0, s1), a1 = max(s0, s1), a2 = min(s2, s3), a3 = max(s2, s3);
                 const uint32_t b0 = min(a0, a2), b2 = max(a0, a2), b1 = min(a1, a3), b3 = max(a1, a3);

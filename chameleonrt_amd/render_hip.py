@@ -56,6 +56,11 @@ class RenderHIP:
         core.check(self._ctx, self._lib.crt_hip_set_scene(self._ctx, packed.ptr()), "set_scene")
         self.samples_per_pixel = scene.samples_per_pixel
 
+    def set_prepared_scene(self, prepared: "PreparedScene"):
+        """Device half of set_scene: upload a scene prepared once per node (multi-GPU)."""
+        core.check(self._ctx, self._lib.crt_hip_set_prepared_scene(self._ctx, prepared.handle), "set_prepared_scene")
+        self.samples_per_pixel = prepared.samples_per_pixel
+
     def render(self, pos, dir, up, fovy, camera_changed, readback_framebuffer=False) -> core.RenderStats:
         a = [np.ascontiguousarray(v, np.float32) for v in (pos, dir, up)]
         st = core.RenderStats()
@@ -115,7 +120,16 @@ class RenderHIP:
         tris = np.zeros((nt.value, 12), np.float32)
         core.check(self._ctx, self._lib.crt_hip_bvh_copy(self._ctx, nodes.ctypes.data_as(C.c_void_p),
                                                          tris.ctypes.data_as(C.c_void_p)), "bvh_copy")
-        return dict(nodes=nodes, tris=tris, n_instances=ni.value, two_level=bool(tl.value), frame=frame)
+        root, child_order = C.c_int32(), C.c_int32()
+        n_top, need, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        core.check(self._ctx, self._lib.crt_hip_bvh_layout(self._ctx, C.byref(root), C.byref(n_top), C.byref(need),
+                                                           C.byref(lds), C.byref(child_order)), "bvh_layout")
+        insts = np.zeros((ni.value, 32), np.uint32)  # 128-byte instance records
+        core.check(self._ctx, self._lib.crt_hip_bvh_copy_instances(self._ctx, insts.ctypes.data_as(C.c_void_p)),
+                   "bvh_copy_instances")
+        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
+                    frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
+                    lds_stack=lds.value, child_order=child_order.value)
 
     # ---- multi-GPU tile assembly ---------------------------------------------------------
     def tile_buffer(self):
@@ -126,3 +140,51 @@ class RenderHIP:
     def assemble_tiles(self, gathered_device_ptr: int, world: int, readback: bool = True):
         core.check(self._ctx, self._lib.crt_hip_assemble_tiles(self._ctx, C.c_void_p(gathered_device_ptr), world,
                                                                int(readback)), "assemble_tiles")
+
+
+class PreparedScene:
+    """Host half of set_scene (BVH build, texture linearisation), done once and uploaded to every
+    GPU of the node: crt_hip_prepare_scene / save / load (include/crt_hip.h)."""
+
+    def __init__(self, scene: Scene = None, path: str = None, n_threads: int = 0):
+        self._lib = core.load()
+        if scene is not None:
+            packed = PackedScene(scene)
+            self.handle = self._lib.crt_hip_prepare_scene(packed.ptr(), n_threads)
+            self.samples_per_pixel = scene.samples_per_pixel
+        else:
+            self.handle = self._lib.crt_hip_load_prepared_scene(path.encode())
+            self.samples_per_pixel = None  # the caller knows (it is stored in the prepared scene too)
+        if not self.handle:
+            raise core.CoreError("prepare/load scene failed: " + self._lib.crt_hip_last_error(None).decode())
+
+    def bvh(self):
+        """The host-built traversal arrays, same dict as RenderHIP.bvh() (no device involved)."""
+        nn, nt, ni, tl, root = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32(), C.c_int32()
+        n_top, need, ms = C.c_uint32(), C.c_uint32(), C.c_double()
+        frame = np.zeros(6, np.float32)
+        rc = self._lib.crt_hip_prepared_scene_info(self.handle, C.byref(nn), C.byref(nt), C.byref(ni), C.byref(tl),
+                                                   core.fptr(frame), C.byref(root), C.byref(n_top), C.byref(need),
+                                                   C.byref(ms))
+        assert rc == 0
+        nodes = np.zeros((nn.value, 16), np.uint32)
+        tris = np.zeros((nt.value, 12), np.float32)
+        insts = np.zeros((ni.value, 32), np.uint32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert self._lib.crt_hip_prepared_scene_copy(self.handle, vp(nodes), vp(tris), vp(insts)) == 0
+        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
+                    frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
+                    child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(),
+                    build_ms=ms.value)
+
+    def save(self, path: str):
+        rc = self._lib.crt_hip_save_prepared_scene(self.handle, path.encode())
+        if rc != 0:
+            raise core.CoreError("save_prepared_scene failed: " + self._lib.crt_hip_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.crt_hip_free_prepared_scene(self.handle)
+            self.handle = None
+
+    __del__ = close

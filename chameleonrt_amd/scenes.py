@@ -389,7 +389,7 @@ def _trs(tx, ty, tz, rot_y, s) -> np.ndarray:
     return m
 
 
-def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
+def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param, glass=False):
     mats = []
     for m in range(n_mats):
         r = np.random.default_rng(seed * 1000 + m)
@@ -411,19 +411,31 @@ def _sanmiguel_materials(seed, n_mats, n_tex_color, n_tex_param):
         if kind == 6:
             mat[7] = 0.3 + 0.6 * r.random()  # anisotropic
             mat[5] = 0.3
-        # no specular_transmission here: the OBJ importer never produces it (util/scene.cpp:196 sets
-        # it to 0), and the reference's transmission lobe yields negative pdfs / inf throughput that
-        # would flood a benchmark image with NaNs. instanced_grove() keeps a glass material so the
-        # parity tests still cover that code path.
+        # specular_transmission: the OBJ importer never produces it (util/scene.cpp:196 sets it to 0),
+        # so the flattened OBJ-like variant has none. SURVEY 8d asks the stand-in for "a few": with
+        # glass=True three of the pot materials (small objects: the reference's transmission lobe yields
+        # negative pdfs / inf throughput, i.e. NaN pixels, which parity reproduces but a benchmark image
+        # should not be flooded with) become dielectrics.
+        if glass and m in (43, 51, 59):
+            mat = disney_material(base_color=(0.92, 0.95, 0.97), roughness=0.02 + 0.1 * r.random(), ior=1.3 + 0.3 * r.random(),
+                                  specular_transmission=0.85 + 0.1 * r.random())
         mats.append(mat)
     return mats
 
 
 def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per_tree: int = 1900,
-                   tex_size: int = 2048, n_tex: int = 64, n_mats: int = 128, detail: float = 1.0) -> Scene:
-    """S4: courtyard with arcades, tiled floor, furniture and flattened foliage. Defaults give
-    ~10 M triangles in one mesh (like the San Miguel OBJ), 128 materials (diffuse, metallic,
-    clear-coat, sheen, anisotropic; textured base colour and parameter maps), 64 textures."""
+                   tex_size: int = 2048, n_tex: int = 64, n_mats: int = 128, detail: float = 1.0,
+                   n_instanced: int = 0, glass: bool = False) -> Scene:
+    """S4: courtyard with arcades, tiled floor, furniture and foliage; 128 materials (diffuse,
+    metallic, clear-coat, sheen, anisotropic; textured base colour and parameter maps), 64 textures.
+
+    n_instanced = 0: everything flattened into ONE mesh with one identity instance, ~10 M triangles
+    -- what the reference's OBJ importer hands over for the San Miguel OBJ (workload "C4F").
+    n_instanced > 0 (workload "C4"): `n_trees - n_instanced` trees stay flattened in
+    the courtyard mesh and `n_instanced` shrubs become single-level instances (util/mesh.h:40-47) of
+    the four tree meshes on a jittered grid, each with its own rotation / scale and one of eight
+    (trunk, leaf) material pairs: the same ~10 M triangles on screen, ~6 M unique, a TLAS of
+    n_instanced + 1 instances over 5 BLASes. glass: three dielectric pot materials."""
     rng = np.random.default_rng(seed)
     d = lambda n: max(2, int(round(n * math.sqrt(detail))))
     n_tc = n_tex * 3 // 4
@@ -464,7 +476,8 @@ def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per
     # flattened foliage
     proto = [_tree(np.random.default_rng(seed * 77 + i), leaves_per_tree) for i in range(4)]
     trunks, leaves = [[] for _ in range(8)], [[] for _ in range(8)]
-    for t in range(n_trees):
+    n_flat = max(0, n_trees - n_instanced)
+    for t in range(n_flat):
         x, z = (rng.random(2) - 0.5) * (S - 6)
         m = _trs(x, 0.0, z, rng.random() * 6.28, 0.7 + 0.6 * rng.random())
         tr, lv = proto[t % 4]
@@ -476,9 +489,27 @@ def sanmiguel_like(spp: int = 16, seed: int = 4, n_trees: int = 2000, leaves_per
             add(_merge(leaves[k]), 72 + k * 3)
     tex = [_color_texture(np.random.default_rng(seed * 31 + i), tex_size) for i in range(n_tc)] + \
           [_param_texture(np.random.default_rng(seed * 37 + i), tex_size) for i in range(n_tp)]
-    materials = _sanmiguel_materials(seed, n_mats, n_tc, n_tp)
+    materials = _sanmiguel_materials(seed, n_mats, n_tc, n_tp, glass)
     cam = Camera(np.array([-13.0, 1.7, 12.0], F), np.array([2.0, 2.4, -1.0], F), np.array([0, 1, 0], F), 60.0)
-    return _finish("sanmiguel_like", geoms, mats, materials, tex, cam, spp)
+    sc = _finish("sanmiguel_like", geoms, mats, materials, tex, cam, spp)
+    if n_instanced > 0:
+        sc.name = "sanmiguel_like_instanced"
+        for tr, lv in proto:
+            sc.meshes.append(Mesh([tr, lv]))
+        for k in range(8):  # (tree mesh, trunk material, leaf material) combinations
+            sc.parameterized_meshes.append(ParameterizedMesh(1 + k % 4, [(64 + k) % n_mats, (72 + k * 3) % n_mats]))
+        irng = np.random.default_rng(seed * 131 + 7)
+        side = int(math.ceil(math.sqrt(n_instanced)))
+        pitch = (S - 6) / side
+        for k in range(n_instanced):
+            gx, gz = k % side, k // side
+            x = -(S - 6) / 2 + (gx + 0.15 + 0.7 * irng.random()) * pitch
+            z = -(S - 6) / 2 + (gz + 0.15 + 0.7 * irng.random()) * pitch
+            m = _trs(x, 0.0, z, irng.random() * 6.28, 0.3 + 0.3 * irng.random())
+            if k % 11 == 0:
+                m[:3, :3] = m[:3, :3] @ np.diag([1.0, 1.3, 0.8])  # non-uniform scale
+            sc.instances.append(Instance(m.T.astype(F).reshape(16), 1 + k % 8))  # column-major
+    return sc
 
 
 # ---------------------------------------------------------------- instanced test scene
@@ -536,8 +567,11 @@ WORKLOADS = {
     "C1": (cornell, {}, 512, 512, 1),
     "C2": (sponza_like, {}, 1280, 720, 4),
     "C3": (rungholt_like, {}, 1920, 1080, 8),
-    "C4": (sanmiguel_like, {}, 1920, 1080, 16),
-    "C5": (sanmiguel_like, {}, 3840, 2160, 64),
+    "C4": (sanmiguel_like, {"n_instanced": 1024, "glass": True}, 1920, 1080, 16),
+    "C5": (sanmiguel_like, {"n_instanced": 1024, "glass": True}, 3840, 2160, 64),
+    # the round-1 stand-in: everything flattened into one mesh / one identity instance, no glass -- what the
+    # reference's OBJ importer would hand over (util/scene.cpp:94-228); kept for A/B against C4
+    "C4F": (sanmiguel_like, {}, 1920, 1080, 16),
 }
 
 

@@ -158,6 +158,30 @@ int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world);
 int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height);
 int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *scene);
 
+/* set_scene in two halves, for the multi-GPU case (new functionality): the host half
+ * (BLAS/TLAS build = the reference's rtcCommitScene, embree_utils.cpp:63-76,121-129; 8-bit texture
+ * linearisation, render_embree.cpp:90-104; material and light tables) runs ONCE per node and its
+ * result is uploaded to every GPU's context, instead of N identical builds oversubscribing the
+ * host. crt_hip_set_scene(ctx, s) == prepare + set_prepared + free. n_threads 0 = the host cores this
+ * process may use (affinity mask and cgroup quota honoured; CRT_HIP_BUILD_THREADS overrides).
+ * prepare/load return NULL on failure (message via crt_hip_last_error(NULL)). save/load move a
+ * prepared scene between the processes of one node through a file (meant for /dev/shm): rank 0
+ * prepares and saves, the other ranks load -- same build, same machine, not an exchange format. */
+typedef struct crt_hip_prepared_scene crt_hip_prepared_scene;
+crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads);
+void crt_hip_free_prepared_scene(crt_hip_prepared_scene *prepared);
+int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *prepared);
+int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *prepared, const char *path);
+/* Introspection of the host-built arrays (no device needed: the CPU tests check the builder and the
+ * quantiser this way). Same records as crt_hip_bvh_info / _layout / _copy / _copy_instances below. */
+int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *prepared, uint64_t *n_nodes, uint64_t *n_tris,
+                                uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
+                                uint32_t *n_top_nodes, uint32_t *stack_need, double *build_ms);
+int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *prepared, void *nodes, void *tris, void *instances);
+int crt_hip_child_order(void); /* the build's CRT_CHILD_ORDER (see crt_hip_bvh_layout) */
+uint32_t crt_hip_lds_stack_entries(void); /* per-lane traversal-stack entries kept in LDS; deeper ones live in HBM */
+crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
+
 /* One frame. fovy in degrees; camera_changed resets accumulation (frame_id = 0). When
  * readback != 0 the RGBA8 image is copied to the host buffer behind crt_hip_framebuffer
  * (for world > 1 only this rank's tiles are valid; see crt_hip_assemble_tiles). */
@@ -205,6 +229,15 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,
                      uint64_t *n_instances, int32_t *two_level, float *root_frame);
 int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris);
+/* root: node index traversal starts at; n_top_nodes: BFS-ordered top levels staged in LDS;
+ * stack_need: traversal-stack entries the deepest path of this BVH can need (the HBM slab behind the
+ * lds_stack entries kept in LDS is sized from it); child_order: the build's visit rule (0 = entered
+ * children fully sorted by entry distance, 1 = nearest first, rest in slot order). */
+int crt_hip_bvh_layout(crt_hip_ctx *ctx, int32_t *root, uint32_t *n_top_nodes, uint32_t *stack_need,
+                       uint32_t *lds_stack, int32_t *child_order);
+/* n_instances 128-byte instance records (world_to_object[16], blas_root, geom_base, mat_base,
+ * identity, frame[6], pad[6]) as the two-level traversal reads them. */
+int crt_hip_bvh_copy_instances(crt_hip_ctx *ctx, void *instances);
 
 #ifdef __cplusplus
 }

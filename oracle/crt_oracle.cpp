@@ -1789,31 +1789,43 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 }
 
 // Foreign (product) BVH walk with the product's documented visit rule (DESIGN.md "Traversal
-// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {lo[3] hi[3] as uint16 fixed point,
-// ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
+// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
+// fixed point, ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
 // ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
-// ref == 0x80000002 unused slot; 48-byte triangle records. Children whose box is entered are
-// visited in ascending order of the key (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked
-// farthest first.
+// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; 48-byte triangle
+// records. child_order 0: the children whose box is entered are visited in ascending order of the key
+// (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked farthest first. child_order 1: the child with
+// the smallest key first, the others stacked in slot order, highest slot deepest.
+// Two-level scenes (instances != NULL): a TLAS leaf names an instance (128-byte product record:
+// world_to_object[16], blas_root, geom_base, mat_base, identity, frame[6], pad); the ray is moved into
+// the instance's space (t preserved), a sentinel is stacked, the BLAS is walked in its own fixed-point
+// frame; popping the sentinel restores the world ray. TLAS leaves are not counted as node visits.
 namespace {
 struct FChild {
-    uint16_t lo[3], hi[3];
+    uint16_t q[3][2]; // per axis {lo, hi}; an unused slot is stored inverted (lo > hi)
     int32_t ref;
 };
 struct FNode {
     FChild child[4];
 };
-constexpr int32_t F_EMPTY = (int32_t)0x80000002;
 struct FTri {
     f3 v0, e1, e2;
     uint32_t geom, prim, pad;
 };
-static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48, "product BVH record sizes");
-inline bool fbox(const uint16_t lo[3], const uint16_t hi[3], f3 qa, f3 qb, float tmin, float tmax, float &tn)
+struct FInst {
+    float w2o[16];
+    int32_t blas_root;
+    uint32_t geom_base, mat_base, identity;
+    float frame[6];
+    uint32_t pad[6];
+};
+static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48 && sizeof(FInst) == 128, "product BVH record sizes");
+constexpr int32_t F_SENTINEL = (int32_t)0x80000000;
+inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
-    const float t0x = std::fma((float)lo[0], qa.x, qb.x), t1x = std::fma((float)hi[0], qa.x, qb.x);
-    const float t0y = std::fma((float)lo[1], qa.y, qb.y), t1y = std::fma((float)hi[1], qa.y, qb.y);
-    const float t0z = std::fma((float)lo[2], qa.z, qb.z), t1z = std::fma((float)hi[2], qa.z, qb.z);
+    const float t0x = std::fma((float)q[0][0], qa.x, qb.x), t1x = std::fma((float)q[0][1], qa.x, qb.x);
+    const float t0y = std::fma((float)q[1][0], qa.y, qb.y), t1y = std::fma((float)q[1][1], qa.y, qb.y);
+    const float t0z = std::fma((float)q[2][0], qa.z, qb.z), t1z = std::fma((float)q[2][1], qa.z, qb.z);
     tn = std::fmax(std::fmax(std::fmin(t0x, t1x), std::fmin(t0y, t1y)), std::fmax(std::fmin(t0z, t1z), tmin));
     const float tf = std::fmin(std::fmin(std::fmax(t0x, t1x), std::fmax(t0y, t1y)),
                                std::fmin(std::fmax(t0z, t1z), tmax));
@@ -1821,81 +1833,193 @@ inline bool fbox(const uint16_t lo[3], const uint16_t hi[3], f3 qa, f3 qb, float
 }
 } // namespace
 
-extern "C" int orc_count_foreign_bvh(const void *nodes_, uint64_t n_nodes, const void *tris_,
-                                     uint64_t n_tris, const float frame[6], uint64_t n, const float *org,
-                                     const float *dir, const float *tmin, const float *tmax, int closest,
-                                     uint64_t *nodes_visited, uint64_t *tris_tested)
+extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const void *instances_,
+                                    uint64_t n_instances, int32_t root, const float root_frame[6], int child_order,
+                                    uint64_t n, const float *org, const float *dir, const float *tmin,
+                                    const float *tmax, int closest, uint64_t *nodes_visited, uint64_t *tris_tested,
+                                    uint32_t *max_stack, float *out_t, int32_t *out_inst, int32_t *out_geom,
+                                    int32_t *out_prim)
 {
-    (void)n_nodes;
-    (void)n_tris;
     const FNode *nodes = static_cast<const FNode *>(nodes_);
     const FTri *tris = static_cast<const FTri *>(tris_);
-    uint64_t nv = 0, tt = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-        const f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-        // the product clamps |d| to >= 1e-18 for the box tests (exactly zero components)
-        auto box_dir = [](float x) { return std::fabs(x) < 1e-18f ? std::copysign(1e-18f, x) : x; };
-        const f3 inv = mk3(1.f / box_dir(d.x), 1.f / box_dir(d.y), 1.f / box_dir(d.z));
-        const f3 qa = mk3(frame[3] * inv.x, frame[4] * inv.y, frame[5] * inv.z);
-        const f3 qb = mk3((frame[0] - o.x) * inv.x, (frame[1] - o.y) * inv.y, (frame[2] - o.z) * inv.z);
-        float best = tmax[i];
-        int32_t stack[256];
-        int sp = 0;
-        int32_t cur = 0;
-        bool done = false;
-        while (!done) {
-            if (cur >= 0) {
-                const FNode &nd = nodes[cur];
-                ++nv;
-                uint32_t keys[4];
-                int n_hit = 0;
-                for (uint32_t k = 0; k < 4; ++k) {
-                    float tn;
-                    uint32_t tb;
-                    if (nd.child[k].ref != F_EMPTY && fbox(nd.child[k].lo, nd.child[k].hi, qa, qb, tmin[i], best, tn)) {
-                        std::memcpy(&tb, &tn, 4);
-                        keys[n_hit++] = (tb & 0x7ffffffcu) | k;
+    const FInst *insts = static_cast<const FInst *>(instances_);
+    const bool two_level = insts != nullptr && n_instances > 1;
+    const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0);
+    std::vector<uint32_t> ms_t(nthreads, 0);
+    std::vector<int> bad_t(nthreads, 0);
+    auto work = [&](int tid) {
+        uint64_t nv = 0, tt = 0;
+        uint32_t ms = 0;
+        std::vector<int32_t> stack(1024);
+        for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
+            const f3 worg = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+            const f3 wdir = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+            f3 o = worg, d = wdir, qa, qb;
+            // the product clamps |d| to >= 1e-18 for the box tests (exactly zero components)
+            auto box_dir = [](float x) { return std::fabs(x) < 1e-18f ? std::copysign(1e-18f, x) : x; };
+            auto set_frame = [&](const float *fr) {
+                const f3 inv = mk3(1.f / box_dir(d.x), 1.f / box_dir(d.y), 1.f / box_dir(d.z));
+                qa = mk3(fr[3] * inv.x, fr[4] * inv.y, fr[5] * inv.z);
+                qb = mk3((fr[0] - o.x) * inv.x, (fr[1] - o.y) * inv.y, (fr[2] - o.z) * inv.z);
+            };
+            int32_t cur_inst = 0;
+            bool in_blas = !two_level;
+            if (!two_level && insts != nullptr && !insts[0].identity) {
+                o = xfm_point(insts[0].w2o, worg);
+                d = xfm_vector(insts[0].w2o, wdir);
+            }
+            set_frame(root_frame);
+            float best = tmax[i];
+            int32_t b_tri = -1, b_inst = -1;
+            uint32_t b_geom = 0, b_prim = 0;
+            size_t sp = 0;
+            int32_t cur = root;
+            bool done = false;
+            while (!done) {
+                if (cur >= 0) {
+                    const FNode &nd = nodes[cur];
+                    ++nv;
+                    uint32_t keys[4];
+                    int n_hit = 0;
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        float tn;
+                        uint32_t tb;
+                        // (the kernel rejects inverted boxes inside its sign-ordered slab test; here, with the
+                        // symmetric min/max form, they are skipped explicitly -- same entry distances otherwise)
+                        if (nd.child[k].q[0][0] <= nd.child[k].q[0][1] && fbox(nd.child[k].q, qa, qb, tmin[i], best, tn)) {
+                            std::memcpy(&tb, &tn, 4);
+                            keys[n_hit++] = (tb & 0x7ffffffcu) | k;
+                        }
                     }
-                }
-                if (n_hit > 0) {
-                    std::sort(keys, keys + n_hit);
-                    for (int k = n_hit - 1; k >= 1; --k) {
-                        stack[sp++] = nd.child[keys[k] & 3u].ref;
-                    }
-                    cur = nd.child[keys[0] & 3u].ref;
-                    continue;
-                }
-            } else {
-                const uint32_t x = ~(uint32_t)cur;
-                const uint32_t first = x >> 3, count = (x & 7u) + 1u;
-                for (uint32_t k = first; k < first + count; ++k) {
-                    ++tt;
-                    TriRec tr{tris[k].v0, tris[k].e1, tris[k].e2, tris[k].geom, tris[k].prim};
-                    float t, u, v;
-                    if (tri_test(tr, o, d, tmin[i], tmax[i], t, u, v)) {
-                        if (!closest) {
+                    if (n_hit > 0) {
+                        if (child_order == 0) {
+                            std::sort(keys, keys + n_hit);
+                            for (int k = n_hit - 1; k >= 1; --k) {
+                                stack[sp++] = nd.child[keys[k] & 3u].ref;
+                            }
+                            cur = nd.child[keys[0] & 3u].ref;
+                        } else {
+                            int nearest = 0;
+                            for (int k = 1; k < n_hit; ++k) {
+                                if (keys[k] < keys[nearest]) {
+                                    nearest = k;
+                                }
+                            }
+                            for (int k = n_hit - 1; k >= 0; --k) {
+                                if (k != nearest) {
+                                    stack[sp++] = nd.child[keys[k] & 3u].ref;
+                                }
+                            }
+                            cur = nd.child[keys[nearest] & 3u].ref;
+                        }
+                        ms = std::max<uint32_t>(ms, (uint32_t)sp);
+                        if (sp + 8 > stack.size()) {
+                            bad_t[tid] = 1;
                             done = true;
-                            break;
                         }
-                        if (t < best) {
-                            best = t;
+                        continue;
+                    }
+                } else {
+                    const uint32_t x = ~(uint32_t)cur;
+                    const uint32_t first = x >> 3, count = (x & 7u) + 1u;
+                    if (two_level && !in_blas) {
+                        const FInst &in = insts[first];
+                        cur_inst = (int32_t)first;
+                        if (!in.identity) {
+                            o = xfm_point(in.w2o, worg);
+                            d = xfm_vector(in.w2o, wdir);
+                        }
+                        set_frame(in.frame);
+                        in_blas = true;
+                        stack[sp++] = F_SENTINEL;
+                        ms = std::max<uint32_t>(ms, (uint32_t)sp);
+                        cur = in.blas_root;
+                        continue;
+                    }
+                    for (uint32_t k = first; k < first + count; ++k) {
+                        ++tt;
+                        TriRec tr{tris[k].v0, tris[k].e1, tris[k].e2, tris[k].geom, tris[k].prim};
+                        float t, u, v;
+                        if (tri_test(tr, o, d, tmin[i], tmax[i], t, u, v)) {
+                            if (!closest) {
+                                done = true;
+                                b_tri = 0;
+                                break;
+                            }
+                            bool take = t < best;
+                            if (t == best && b_tri >= 0) {
+                                take = cur_inst != b_inst ? cur_inst < b_inst
+                                                          : (tr.geom != b_geom ? tr.geom < b_geom : tr.prim < b_prim);
+                            } else if (t == best) {
+                                take = true;
+                            }
+                            if (take) {
+                                best = t;
+                                b_tri = (int32_t)k;
+                                b_inst = cur_inst;
+                                b_geom = tr.geom;
+                                b_prim = tr.prim;
+                            }
                         }
                     }
+                    if (done) {
+                        break;
+                    }
                 }
-                if (done) {
+                // pop (the instance-exit sentinel restores the world-space ray)
+                for (;;) {
+                    if (sp == 0) {
+                        done = true;
+                        break;
+                    }
+                    cur = stack[--sp];
+                    if (two_level && cur == F_SENTINEL) {
+                        o = worg;
+                        d = wdir;
+                        set_frame(root_frame);
+                        in_blas = false;
+                        continue;
+                    }
                     break;
                 }
             }
-            if (sp == 0) {
-                break;
+            if (out_t) {
+                out_t[i] = closest ? best : (b_tri < 0 ? 1.f : 0.f);
             }
-            cur = stack[--sp];
+            if (closest && out_inst) {
+                out_inst[i] = b_tri < 0 ? -1 : b_inst;
+                out_geom[i] = b_tri < 0 ? -1 : (int32_t)b_geom;
+                out_prim[i] = b_tri < 0 ? -1 : (int32_t)b_prim;
+            }
         }
+        nv_t[tid] = nv;
+        tt_t[tid] = tt;
+        ms_t[tid] = ms;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) {
+        pool.emplace_back(work, t);
+    }
+    work(0);
+    for (std::thread &t : pool) {
+        t.join();
+    }
+    uint64_t nv = 0, tt = 0;
+    uint32_t ms = 0;
+    int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        nv += nv_t[t];
+        tt += tt_t[t];
+        ms = std::max(ms, ms_t[t]);
+        bad |= bad_t[t];
     }
     *nodes_visited = nv;
     *tris_tested = tt;
-    return 0;
+    if (max_stack) {
+        *max_stack = ms;
+    }
+    return bad ? -1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------

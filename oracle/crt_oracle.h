@@ -80,13 +80,19 @@ int orc_intersect1(const orc_scene *s, const float org[3], const float dir[3], f
                    float *t, float *u, float *v, int32_t *inst, int32_t *geom, int32_t *prim);
 int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar);
 
-/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frame / 48-byte triangles,
- * DESIGN.md) with the product's documented visit rule and count nodes fetched / triangles
- * tested, to cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers. Single-level only. */
-int orc_count_foreign_bvh(const void *nodes, uint64_t n_nodes, const void *tris,
-                          uint64_t n_tris, const float frame[6], uint64_t n, const float *org, const float *dir,
-                          const float *tmin, const float *tmax, int closest,
-                          uint64_t *nodes_visited, uint64_t *tris_tested);
+/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frames / 48-byte triangles /
+ * 128-byte instance records) with the product's documented visit rule (child_order =
+ * the product's CRT_CHILD_ORDER build setting): counts nodes fetched / triangles tested, to
+ * cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers (the roofline input), reports the
+ * deepest traversal stack any ray needed, and optionally returns the hits (closest: t / inst / geom /
+ * prim, miss = -1 ids and t = tmax; occlusion: out_t = 1 visible, 0 occluded). instances == NULL or
+ * n_instances <= 1: single-level walk from `root` (instance 0's transform applied if it is given and
+ * not the identity). Outputs other than the two counters may be NULL. */
+int orc_walk_foreign_bvh(const void *nodes, const void *tris, const void *instances, uint64_t n_instances,
+                         int32_t root, const float root_frame[6], int child_order, uint64_t n, const float *org,
+                         const float *dir, const float *tmin, const float *tmax, int closest,
+                         uint64_t *nodes_visited, uint64_t *tris_tested, uint32_t *max_stack, float *out_t,
+                         int32_t *out_inst, int32_t *out_geom, int32_t *out_prim);
 
 /* Shading-function KATs, record layouts in include/crt_kat.h. scene may be NULL for the
  * functions that need none. */

@@ -136,16 +136,20 @@ int main(int argc, char **argv)
     for (const BvhNode &nd : b.nodes) {
         const QNode q = quantise(nd, f);
         for (int c = 0; c < BVH_WIDTH; ++c) {
+            if (nd.c[c] == EMPTY_CHILD) { // unused slot: inverted box on every axis, a copy of slot 0's reference
+                for (int k = 0; k < 3; ++k) {
+                    errors += !(q.child[c].q[k][0] > q.child[c].q[k][1]);
+                }
+                errors += q.child[c].ref != nd.c[0];
+                continue;
+            }
             if (q.child[c].ref != nd.c[c]) {
                 ++errors;
             }
-            if (nd.c[c] == EMPTY_CHILD) {
-                continue;
-            }
             for (int k = 0; k < 3; ++k) {
                 // the kernels place the plane at base + q*step (as fma(q, step/d, (base-o)/d)); in fp32:
-                const float dl = f.base[k] + (float)q.child[c].lo[k] * f.step[k];
-                const float dh = f.base[k] + (float)q.child[c].hi[k] * f.step[k];
+                const float dl = f.base[k] + (float)q.child[c].q[k][0] * f.step[k];
+                const float dh = f.base[k] + (float)q.child[c].q[k][1] * f.step[k];
                 if (!(dl <= nd.lo[c][k]) || !(dh >= nd.hi[c][k])) {
                     ++errors;
                 }

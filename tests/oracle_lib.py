@@ -45,8 +45,9 @@ def lib():
         L.orc_num_tiles.argtypes = [vp]
         L.orc_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                      i32p, i32p, i32p, C.POINTER(OrcStats)]
-        L.orc_count_foreign_bvh.argtypes = [vp, C.c_uint64, vp, C.c_uint64, fp, C.c_uint64, fp, fp, fp, fp,
-                                            C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_walk_foreign_bvh.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32, fp, C.c_int, C.c_uint64, fp, fp, fp, fp,
+                                           C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint32), fp, i32p, i32p, i32p]
         L.orc_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
         _LIB = L
     return _LIB
@@ -87,6 +88,28 @@ class OracleScene:
 
     def kat(self, fn, rec_in, n_out):
         return kat(fn, rec_in, n_out, self.h)
+
+
+def walk_product_bvh(bvh, org, dirs, tmin, tmax, closest=True):
+    """Walk the PRODUCT's BVH arrays (RenderHIP.bvh(): quantised 4-wide nodes, triangle and instance
+    records) on the CPU with the product's documented visit rule. Returns node / triangle visit counts
+    (what the instrumented kernels must report), the deepest stack any ray needed, and the hits."""
+    org = np.ascontiguousarray(org, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    n = org.shape[0]
+    tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
+    tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
+    nv, tt, ms = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    t = np.zeros(n, np.float32)
+    inst, geom, prim = (np.zeros(n, np.int32) for _ in range(3))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().orc_walk_foreign_bvh(vp(bvh["nodes"]), vp(bvh["tris"]), vp(bvh["instances"]), bvh["n_instances"],
+                                    bvh["root"], _fp(bvh["frame"]), bvh["child_order"], n, _fp(org), _fp(dirs),
+                                    _fp(tmin), _fp(tmax), int(closest), C.byref(nv), C.byref(tt), C.byref(ms),
+                                    _fp(t), ip(inst), ip(geom), ip(prim))
+    assert rc == 0
+    return dict(nodes=nv.value, tris=tt.value, max_stack=ms.value, t=t, inst=inst, geom=geom, prim=prim)
 
 
 def kat(fn, rec_in, n_out, scene_handle=None):

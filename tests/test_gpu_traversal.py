@@ -117,23 +117,23 @@ def test_axis_parallel_rays(pair):
 
 
 def test_counters_match_oracle_walk_of_the_same_bvh(pair, oracle):
-    """The instrumented kernel's node/triangle counts (roofline input) equal the oracle walking
-    the product's own BVH arrays with the documented visit rule. Single-level scenes only."""
-    import ctypes as C
+    """The instrumented kernels' node/triangle counts (the roofline input) equal the oracle walking
+    the product's own BVH arrays with the documented visit rule -- closest-hit and occlusion rays,
+    single-level scenes, a single non-identity instance, and the two-level (TLAS -> instance frame ->
+    BLAS, sentinel on the stack) walk. The walker's hits must also be the kernel's hits."""
     r, _, sc = pair
-    if len(sc.instances) != 1 or not np.array_equal(np.asarray(sc.instances[0].transform).reshape(16),
-                                                     np.eye(4, dtype=np.float32).reshape(16)):
-        pytest.skip("foreign-BVH walk covers the single identity-instance layout")
     bvh = r.bvh()
     org, dirs = probe_rays(sc, 5000, seed=8)
-    n = len(org)
-    tmin = np.zeros(n, np.float32)
-    tmax = np.full(n, 1e20, np.float32)
-    g = r.trace(org, dirs, tmin, tmax, closest=True)
-    nv, tt = C.c_uint64(), C.c_uint64()
-    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-    rc = oracle.lib().orc_count_foreign_bvh(bvh["nodes"].ctypes.data_as(C.c_void_p), len(bvh["nodes"]),
-                                            bvh["tris"].ctypes.data_as(C.c_void_p), len(bvh["tris"]), fp(bvh["frame"]), n,
-                                            fp(org), fp(dirs), fp(tmin), fp(tmax), 1, C.byref(nv), C.byref(tt))
-    assert rc == 0
-    assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (nv.value, tt.value)
+    g = r.trace(org, dirs, 0.0, 1e20, closest=True)
+    w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (w["nodes"], w["tris"])
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(g[k], w[k]), k
+    hit = w["inst"] >= 0
+    assert np.array_equal(g["t"][hit].view(np.uint32), w["t"][hit].view(np.uint32))
+    assert w["max_stack"] <= bvh["stack_need"]
+    tmax = np.random.default_rng(11).random(len(org)).astype(np.float32) * 10
+    g = r.trace(org, dirs, 1e-4, tmax, closest=False)
+    w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, tmax, closest=False)
+    assert (g["stats"].shadow_nodes, g["stats"].shadow_tris) == (w["nodes"], w["tris"])
+    assert np.array_equal(g["t"], w["t"])

@@ -1,0 +1,122 @@
+"""CPU: the host half of set_scene (crt_hip_prepare_scene: SAH build, 4-wide collapse, 16-bit
+quantisation, leaf-order triangle records, instance records) checked WITHOUT a device.
+
+The oracle walks the product's host-built arrays with the product's visit rule
+(orc_walk_foreign_bvh) and must find exactly what the oracle finds by testing every triangle with
+no BVH at all -- so builder, quantiser and the documented rule are pinned on the CPU, and the GPU
+tests only have to show that the kernels walk these arrays the same way (same hits, same visit
+counts: tests/test_gpu_traversal.py, tests/test_gpu_scale.py).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from chameleonrt_amd import core, scenes
+from chameleonrt_amd.render_hip import PreparedScene
+from chameleonrt_amd.scene import PackedScene
+from tests.parity import probe_rays
+
+SCENES = {
+    "cornell": lambda: scenes.cornell(),
+    "grove_two_level": lambda: scenes.instanced_grove(),
+    "sponza_small": lambda: scenes.sponza_like(detail=0.05, tex_size=32),
+    "rungholt_small": lambda: scenes.rungholt_like(n=160),
+    "sanmiguel_small_instanced": lambda: scenes.sanmiguel_like(detail=0.01, tex_size=16, n_trees=60, leaves_per_tree=200,
+                                                               n_instanced=40, glass=True),
+}
+
+
+@pytest.fixture(scope="module", params=list(SCENES))
+def prepared(request, oracle):
+    sc = SCENES[request.param]()
+    ps = PreparedScene(sc)
+    yield sc, ps.bvh(), oracle.OracleScene(sc), ps
+    ps.close()
+
+
+def test_walk_of_host_built_bvh_equals_brute_force(prepared, oracle):
+    sc, bvh, o, _ = prepared
+    org, dirs = probe_rays(sc, 8000, seed=21)
+    w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w[k], c[k]), k
+    hit = c["inst"] >= 0
+    assert hit.sum() > 50
+    assert np.array_equal(w["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    assert w["max_stack"] <= bvh["stack_need"]
+    # occlusion rays with finite segments, tnear = EPSILON
+    tmax = np.random.default_rng(22).random(len(org)).astype(np.float32) * 10
+    w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, tmax, closest=False)
+    c = o.trace(org, dirs, 1e-4, tmax, closest=False, brute_force=True)
+    assert np.array_equal(w["t"], c["t"])
+
+
+def test_instanced_scene_layout(prepared):
+    sc, bvh, _, _ = prepared
+    assert bvh["n_instances"] == len(sc.instances)
+    assert bvh["two_level"] == (len(sc.instances) > 1)
+    assert bvh["tris"].shape[0] == sum(m.num_tris() for m in sc.meshes)  # one BLAS per Mesh, shared by its instances
+    assert bvh["child_order"] in (0, 1)
+
+
+def test_save_load_round_trip(prepared, tmp_path):
+    _, bvh, _, ps = prepared
+    path = str(tmp_path / "prepared.bin")
+    ps.save(path)
+    back = PreparedScene(path=path)
+    b2 = back.bvh()
+    for k in ("nodes", "tris", "instances", "frame"):
+        assert np.array_equal(bvh[k], b2[k]), k
+    for k in ("root", "n_top_nodes", "stack_need", "n_instances", "two_level"):
+        assert bvh[k] == b2[k], k
+    back.close()
+    with open(path, "r+b") as f:  # a damaged header must be refused, not crash
+        f.write(b"\0" * 8)
+    with pytest.raises(core.CoreError):
+        PreparedScene(path=path)
+
+
+def test_malformed_scenes_are_refused_not_crashed():
+    """The header promises CRT_HIP_EINVAL for a malformed scene and no crash across the C ABI: NULL
+    arrays with non-zero counts, mesh ranges that wrap in 32 bits, out-of-range ids."""
+    L = core.load()
+    sc = scenes.cornell()
+
+    def refused(mutate):
+        packed = PackedScene(sc)
+        mutate(packed.desc)
+        h = L.crt_hip_prepare_scene(C.byref(packed.desc), 1)
+        assert not h, "malformed scene accepted"
+        assert L.crt_hip_last_error(None)
+
+    def null_instances(d):
+        d.instances = None
+
+    def null_materials(d):
+        d.materials = None
+
+    def null_lights(d):
+        d.lights = None
+
+    def null_vertices(d):
+        d.geometries[0].vertices = None
+
+    def null_indices(d):
+        d.geometries[0].indices = None
+
+    def null_material_ids(d):
+        d.parameterized_meshes[0].material_ids = None
+
+    def wrapped_mesh_range(d):
+        d.meshes[0].first_geometry = 0xFFFFFFFF
+        d.meshes[0].n_geometries = 2
+
+    def bad_instance(d):
+        d.instances[0].parameterized_mesh_id = 7
+
+    for m in (null_instances, null_materials, null_lights, null_vertices, null_indices, null_material_ids,
+              wrapped_mesh_range, bad_instance):
+        refused(m)

@@ -1,0 +1,20 @@
+"""CPU: the ray / quantised-box test of the traversal kernels (chameleonrt_amd/csrc/slab.h) is one
+source compiled for the device and for the host. The host build is checked here, bit for bit, against
+the plain formulation the oracle's BVH walker uses: both plane parameters per axis and min / max,
+unused child slots skipped explicitly (tests/native/slab_check.cpp) -- millions of random boxes and
+rays including exactly-zero direction components of both signs, origins far outside the frame, flat
+boxes, clipped intervals, and the inverted boxes that mark unused slots."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_header_matches_the_min_max_formulation(tmp_path):
+    exe = str(tmp_path / "slab_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I",
+                           os.path.join(ROOT, "chameleonrt_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "slab_check.cpp"), "-o", exe])
+    p = subprocess.run([exe, "1500000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "errors 0" in p.stdout and "inverted boxes entered 0" in p.stdout

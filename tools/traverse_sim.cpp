@@ -65,8 +65,8 @@ inline bool slab(const QChild &ch, const RayCtx &c, float tmin, float tmax, floa
 {
     float t0[3], t1[3];
     for (int k = 0; k < 3; ++k) {
-        t0[k] = std::fma((float)ch.lo[k], c.qa[k], c.qb[k]);
-        t1[k] = std::fma((float)ch.hi[k], c.qa[k], c.qb[k]);
+        t0[k] = std::fma((float)ch.q[k][0], c.qa[k], c.qb[k]);
+        t1[k] = std::fma((float)ch.q[k][1], c.qa[k], c.qb[k]);
     }
     tn = std::fmax(std::fmax(std::fmin(t0[0], t1[0]), std::fmin(t0[1], t1[1])), std::fmax(std::fmin(t0[2], t1[2]), tmin));
     const float tf = std::fmin(std::fmin(std::fmax(t0[0], t1[0]), std::fmax(t0[1], t1[1])),
@@ -149,7 +149,7 @@ struct Lane {
         int n = 0;
         for (uint32_t k = 0; k < 4; ++k) {
             float tn;
-            if (nd.child[k].ref != EMPTY_CHILD && slab(nd.child[k], ctx, ctx.r->tmin, best, tn)) {
+            if (nd.child[k].q[0][0] <= nd.child[k].q[0][1] && slab(nd.child[k], ctx, ctx.r->tmin, best, tn)) { // not an unused slot
                 uint32_t b;
                 std::memcpy(&b, &tn, 4);
                 keys[n++] = (b & 0x7ffffffcu) | k;
