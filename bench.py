@@ -1,18 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- MRay/s (REPORT_RAY_STATS semantics) of the HIP wavefront path tracer.
 
-    python bench.py --gpus N --steps K --warmup W [--workload C2]
+    python bench.py --gpus N --steps K --warmup W [--workload C4] [--scaling strong|weak]
 
 A "step" is one frame: one pass of the hot path over every pixel-sample of the workload
-(`-benchmark-frames` protocol of the reference, main.cpp:293-345: fixed camera,
-camera_changed only on frame 0). Inputs (scene, BVH, textures) are resident in HBM before the
-timed region. N > 1: one process per GPU (torch.distributed / RCCL), the framebuffer is split
-into 64x64 tiles (tile_id % N == rank), every step ends with the gather of the compact RGBA8
-tile buffers to rank 0 and the K8 un-permute. Scaling is weak: samples per pixel grow with N
-(4*N spp at C2) so the work per GPU stays fixed, as BASELINE.json's own configs do (16 spp on
-4 GPUs, 64 spp on 8).
+(`-benchmark-frames` protocol of the reference, main.cpp:293-345: fixed camera, camera_changed only on
+frame 0). Default workload: the north-star target, the San-Miguel-like scene at 1920x1080, 16 spp
+(BASELINE.json C4; it fits one GPU). Inputs (scene, BVH, textures) are resident in HBM before the
+timed region: rank 0 generates the scene and runs the host half of set_scene ONCE (BVH build,
+texture linearisation), the prepared arrays reach the other ranks through /dev/shm.
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline arithmetic.
+N > 1: one process per GPU (torch.distributed / RCCL), the framebuffer is split into 64x64 tiles
+(tile_id % N == rank), every step ends with the gather of the compact RGBA8 tile buffers to rank 0
+and the K8 un-permute; the gather of frame f overlaps the tracing of frame f+1 (the tile buffer is
+double-buffered). The headline is STRONG scaling -- the same frame, total work fixed, which is what
+north_star's ">= 6x at 8 GPUs" asks; the weak-scaling figure (spp x N, BASELINE.json's own C4/C5
+pattern) is measured right after it and reported under "weak_scaling".
+
+Rank 0 prints ONE JSON line; DESIGN.md "Measurement" explains every field of `roofline`.
 """
 import argparse
 import json
@@ -25,9 +30,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLOCK_GHZ, N_CUS, SIMDS = 2.4, 256, 4  # MI355X_MICROARCH.md chip-level parameters
 NODE_BYTES, TRI_BYTES = 64, 48  # quantised BVH4 node / triangle record
-QUEUE_BYTES_CLOSEST = 24 + 36   # o,d read + t,u,v,tri,inst,Ng,geomID written per ray
+QUEUE_BYTES_CLOSEST = 24 + 36   # o,d read + t,u,v,tri,inst,Ng,material written per ray
 QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
+MAX_PATH_DEPTH = 5
 
 
 def parse():
@@ -35,10 +42,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", help="BASELINE.json config: C1..C5")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="C4", help="BASELINE.json config: C1..C5 (C4F: C4 flattened, no glass)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
+    ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
     return ap.parse_args()
 
 
@@ -65,13 +74,82 @@ def wrap_device_buffer(ptr, nbytes):
     return torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device()))
 
 
+class FrameLoop:
+    """render -> (N > 1) gather + assemble, with the gather of frame f overlapping frame f+1."""
+
+    def __init__(self, r, cam, dist, rank, world):
+        self.r, self.cam, self.dist, self.rank, self.world = r, cam, dist, rank, world
+        from chameleonrt_amd import multi_gpu
+        self.multi_gpu = multi_gpu
+        self.views = {}
+        self.pending = None  # (work handle, gathered tensor) of the previous frame
+
+    def _finish_pending(self):
+        if self.pending is not None:
+            work, gathered = self.pending
+            work.wait()
+            if self.rank == 0:
+                self.r.assemble_tiles(gathered.data_ptr(), self.world, readback=False)
+            self.pending = None
+
+    def step(self, frame):
+        eye, cdir, up, fovy = self.cam
+        st = self.r.render(eye, cdir, up, fovy, frame == 0, False)
+        if self.dist:
+            self._finish_pending()  # frame f-1's image is assembled while nothing else needs the stream
+            ptr, nbytes = self.r.tile_buffer()  # alternates between two buffers by frame parity
+            view = self.views.get(ptr)
+            if view is None:
+                view = self.views[ptr] = wrap_device_buffer(ptr, nbytes)
+            gathered, work = self.multi_gpu.gather_tile_buffers(view, async_op=True)
+            self.pending = (work, gathered)
+        return st
+
+    def drain(self):
+        self._finish_pending()
+
+
+def timed_frames(loop, args, dist, first_frame):
+    """W warm-up + exactly K timed steps, barrier + synchronize on both sides; sums over the K steps."""
+    import torch
+    acc = dict(rays=0, closest_rays=0, shadow_rays=0, closest_ms=0.0, shadow_ms=0.0, shade_ms=0.0)
+    for f in range(args.warmup):
+        loop.step(first_frame + f)
+    loop.drain()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        st = loop.step(first_frame + args.warmup + k)
+        acc["rays"] += st.rays
+        acc["closest_rays"] += st.closest_rays
+        acc["shadow_rays"] += st.shadow_rays
+        acc["closest_ms"] += st.closest_ms
+        acc["shadow_ms"] += st.shadow_ms
+        acc["shade_ms"] += st.shade_ms
+    loop.drain()  # the last frame's gather + assemble belong to the timed region
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    total_rays = acc["rays"]
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(acc["rays"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        elapsed, total_rays = float(t.item()), int(c.item())
+    return elapsed, total_rays, acc
+
+
 def main():
     args = parse()
     import numpy as np
     import torch
-    from chameleonrt_amd import core, multi_gpu, scenes
-    from chameleonrt_amd.render_hip import RenderHIP
+    from chameleonrt_amd import core, scenes
     from chameleonrt_amd.camera import camera_of
+    from chameleonrt_amd.render_hip import PreparedScene, RenderHIP
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,76 +167,63 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    base_spp = scenes.WORKLOADS[args.workload][4]
+    gen, kw, width, height, base_spp = scenes.WORKLOADS[args.workload]
     spp = base_spp * (world if args.scaling == "weak" else 1)
-    t0 = time.time()
-    gen, kw, width, height, _ = scenes.WORKLOADS[args.workload]
-    scene = gen(spp=spp, **kw)
-    t_gen = time.time() - t0
-    eye, cdir, up, fovy = camera_of(scene)
+    # ---- scene: generated and prepared ONCE per node (rank 0), shared through /dev/shm ----------------
+    tag = f"{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid() if dist else os.getpid()}"
+    # tmpfs if it has room for a prepared San-Miguel-class scene (~2 GB: nodes, triangles, 8-bit texels); every
+    # rank evaluates the same rule on the same node, so they agree on the path
+    shm = "/tmp"
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > (6 << 30):
+            shm = "/dev/shm"
+    except OSError:
+        pass
+    prepared_path, meta_path = f"{shm}/crt_prepared_{tag}.bin", f"{shm}/crt_prepared_{tag}.json"
+    scene = None
+    t_gen = t_prep = 0.0
+    if rank == 0:
+        t0 = time.time()
+        scene = gen(spp=spp, **kw)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        ps = PreparedScene(scene, n_threads=usable_cores())
+        t_prep = time.time() - t0
+        eye, cdir, up, fovy = camera_of(scene)
+        if world > 1 or not (args.no_pmc or args.no_roofline):
+            ps.save(prepared_path)
+            with open(meta_path, "w") as f:
+                json.dump({"width": width, "height": height, "eye": [float(x) for x in eye], "dir": [float(x) for x in cdir],
+                           "up": [float(x) for x in up], "fovy": float(fovy), "name": scene.name,
+                           "triangles": scene.total_tris(), "textures": len(scene.textures)}, f)
+    if dist:
+        dist.barrier()
+    if rank != 0:
+        ps = PreparedScene(path=prepared_path)
+        ps.set_samples_per_pixel(spp)
+        with open(meta_path) as f:
+            m = json.load(f)
+        eye, cdir, up = (np.array(m[k], np.float32) for k in ("eye", "dir", "up"))
+        fovy = m["fovy"]
 
     # a dedicated (non-default) torch stream: the legacy default stream serialises against every
     # other stream of the process, which RCCL's internal streams do not like
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    own_stream = os.environ.get("CRT_BENCH_OWN_STREAM") == "1"
-    r = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, rank=rank, world=world,
-                  stream=None if own_stream else stream.cuda_stream)
+    r = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, rank=rank, world=world, stream=stream.cuda_stream)
     r.initialize(width, height)
     t0 = time.time()
-    r.set_scene(scene)
-    t_scene = time.time() - t0
-    tile_view = None
-    if dist:
-        ptr, nbytes = r.tile_buffer()
-        tile_view = wrap_device_buffer(ptr, nbytes)
-
-    def step(frame):
-        st = r.render(eye, cdir, up, fovy, frame == 0, False)
-        if dist:
-            gathered = multi_gpu.gather_tile_buffers(tile_view)
-            if rank == 0:
-                r.assemble_tiles(gathered.data_ptr(), world, readback=False)
-        return st
+    r.set_prepared_scene(ps)
+    t_upload = time.time() - t0
 
     # keep the Python cyclic GC (tens of ms per full collection with torch imported) out of the
     # timed region; the frame loop itself allocates almost nothing
     import gc
     gc.collect()
     gc.disable()
-    for f in range(args.warmup):
-        step(f)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    rays = closest_rays = shadow_rays = 0
-    closest_ms = shadow_ms = shade_ms = 0.0
-    dbg = os.environ.get("CRT_BENCH_DEBUG") == "1"
-    for k in range(args.steps):
-        t_k = time.perf_counter()
-        st = step(args.warmup + k)
-        if dbg and rank == 0:
-            print(f"step {k}: wall {(time.perf_counter() - t_k) * 1e3:.3f} ms, render_time {st.render_time_ms:.3f} ms, "
-                  f"kernels {st.closest_ms + st.shadow_ms + st.shade_ms:.3f} ms", file=sys.stderr)
-        rays += st.rays
-        closest_rays += st.closest_rays
-        shadow_rays += st.shadow_rays
-        closest_ms += st.closest_ms
-        shadow_ms += st.shadow_ms
-        shade_ms += st.shade_ms
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        c = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        elapsed, total_rays = float(t.item()), int(c.item())
-    else:
-        total_rays = rays
+    loop = FrameLoop(r, (eye, cdir, up, fovy), dist, rank, world)
+    elapsed, total_rays, acc = timed_frames(loop, args, dist, 0)
 
     out = None
     if rank == 0:
@@ -168,19 +233,35 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {scene.name} {width}x{height} (synthetic stand-in, SURVEY 8d)",
-                       "spp_per_frame": spp, "triangles": scene.total_tris(), "textures": len(scene.textures),
+                       "spp_per_frame": spp, "triangles": scene.total_tris(), "instances": len(scene.instances),
+                       "textures": len(scene.textures), "materials": len(scene.materials),
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
-                                      (" + RCCL gather to rank 0 every step" if dist else ""),
-                       "scene_gen_s": round(t_gen, 2), "set_scene_s": round(t_scene, 2)},
+                                      (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist and world > 1 else ""),
+                       "scene_gen_s": round(t_gen, 2), "set_scene_host_s": round(t_prep, 2),
+                       "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},
         }
+
+    # ---- N > 1: the weak-scaling figure next to the strong-scaling headline (or the other way round) ----
+    if world > 1:
+        other = "weak" if args.scaling == "strong" else "strong"
+        spp2 = base_spp * (world if other == "weak" else 1)
+        ps.set_samples_per_pixel(spp2)
+        r.set_prepared_scene(ps)
+        e2, rays2, _ = timed_frames(loop, args, dist, 0)
+        if rank == 0:
+            out[f"{other}_scaling"] = {"value": round(rays2 / e2 / 1e6, 2), "unit": "MRay/s", "spp_per_frame": spp2,
+                                       "ms_per_step": round(e2 / args.steps * 1e3, 4), "steps": args.steps}
+        ps.set_samples_per_pixel(spp)
+
     # ---- roofline of the traversal kernels (rank 0's share; identical code on every rank) ----
     if rank == 0 and not args.no_roofline:
+        # (1) algorithmic bytes: nodes / triangles counted by the instrumented build of the same kernels
         ri = RenderHIP(device=local_rank, flags=core.FLAG_COUNTERS, rank=rank, world=world, stream=stream.cuda_stream)
         ri.initialize(width, height)
-        ri.set_scene(scene)
+        ri.set_prepared_scene(ps)
         cn = ct = sn = stt = cr = sr = 0
-        n_probe = min(4, args.warmup + args.steps)
+        n_probe = min(3, args.warmup + args.steps)
         for f in range(n_probe):  # same frames -> same rays as the timed run (deterministic)
             s2 = ri.render(eye, cdir, up, fovy, f == 0, False)
             cn, ct, sn, stt = cn + s2.closest_nodes, ct + s2.closest_tris, sn + s2.shadow_nodes, stt + s2.shadow_tris
@@ -188,36 +269,79 @@ def main():
         ri.close()
         bytes_closest = QUEUE_BYTES_CLOSEST + NODE_BYTES * cn / cr + TRI_BYTES * ct / cr
         bytes_shadow = QUEUE_BYTES_SHADOW + NODE_BYTES * sn / max(1, sr) + TRI_BYTES * stt / max(1, sr)
-        launches = 5 * args.steps
+        launches = MAX_PATH_DEPTH * args.steps
+        # (2) hardware counters of the same frames, measured now (separate rocprofv3 passes of a child process)
+        pmc = {}
+        if not args.no_pmc and world == 1:
+            from chameleonrt_amd import pmc as pmc_mod
+            pmc = pmc_mod.measure(prepared_path, meta_path, frames=3, keep_dir=args.keep_pmc)
+
+        def counter(pass_name, kernel, name):
+            d = pmc.get(pass_name, {})
+            k = d.get(kernel)
+            return (k.get(name), k.get("calls")) if isinstance(k, dict) and name in k else (None, None)
 
         def roof(name, b_per_ray, n_rays, ms):
-            achieved = b_per_ray * n_rays / (ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_ray": round(b_per_ray, 1), "rays_per_launch": n_rays // launches,
-                    "avg_launch_ms": round(ms / launches, 4)}
+            avg_ms = ms / launches
+            algorithmic = b_per_ray * n_rays / (ms * 1e-3) / 1e9
+            out_k = {"kernel": name, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": n_rays // launches}
+            # measured HBM-side traffic per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reports half of the
+            # bytes on gfx950 (MI355X_MICROARCH.md, HBM section); averaged over the launches of the counter pass
+            fs, nf = counter("fetch", name, "FETCH_SIZE")
+            ws, nw = counter("write", name, "WRITE_SIZE")
+            traffic = None
+            if fs is not None and ws is not None and nf and nw:
+                traffic = (2.0 * fs / nf + ws / nw) * 1024.0
+            # VALU: share of the kernel's SIMD-cycles in which a VALU instruction was executing
+            va, _ = counter("sq", name, "SQ_ACTIVE_INST_VALU")
+            busy, _ = counter("sq", name, "SQ_BUSY_CYCLES")
+            insts, _ = counter("sq", name, "SQ_INSTS_VALU")
+            thr, _ = counter("sq", name, "SQ_THREAD_CYCLES_VALU")
+            wave_cyc, _ = counter("sq", name, "SQ_WAVE_CYCLES")
+            wait_any, _ = counter("sq", name, "SQ_WAIT_ANY")
+            wait_inst, _ = counter("sq", name, "SQ_WAIT_INST_ANY")
+            out_k["hbm_measured"] = None if traffic is None else {
+                "bytes_per_launch": round(traffic), "achieved": round(traffic / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            out_k["algorithmic"] = {"bytes_per_ray": round(b_per_ray, 1), "GB_per_s": round(algorithmic, 1),
+                                    "over_hbm_peak": round(algorithmic / HBM_PEAK_GBS, 4),
+                                    "note": "every node / triangle touch priced as an HBM access (SURVEY 8d); the caches absorb "
+                                            "most of it, so this is demand, not HBM traffic, and not a roofline fraction"}
+            if insts and thr and wave_cyc:
+                out_k["valu"] = {"lanes_active_per_instruction": round(thr / insts, 1),
+                                 "wave_cycles_waiting": round((wait_any or 0) / wave_cyc, 3),
+                                 "wave_cycles_issue_stalled": round((wait_inst or 0) / wave_cyc, 3)}
+                if va and busy:
+                    out_k["valu"]["busy_frac_of_simd_cycles"] = round(va / busy, 4)
+            out_k["traffic"] = None if traffic is None else round(traffic)
+            return out_k
 
-        rc = roof("k_trace_closest", bytes_closest, closest_rays, closest_ms)
-        rs = roof("k_trace_shadow", bytes_shadow, shadow_rays, shadow_ms)
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file):
-            with open(traffic_file) as f:
-                tr = json.load(f)
-            # measured HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-            rc["traffic"] = tr.get("k_trace_closest", {}).get(args.workload)
-            rs["traffic"] = tr.get("k_trace_shadow", {}).get(args.workload)
-        dom, other = (rc, rs) if closest_ms >= shadow_ms else (rs, rc)
-        out["roofline"] = dom
-        out["roofline_other"] = other
-        # the contract's roofline axis for this path is HBM; what the PMC passes show to be binding is not
-        # (profiles/README.md): stated here so the line is not read as "HBM-bound"
-        out["roofline_note"] = ("achieved = algorithmic bytes (every node / triangle touch priced as an HBM access) / time; "
-                                "measured HBM-side traffic is `traffic` per launch (L2 + Infinity Cache absorb the rest). "
-                                "PMC: the traversal kernels are bound by VALU issue at ~32 of 64 lanes "
-                                "(SQ_INSTS_VALU*4 cycles / SIMD cycles = 0.9-1.0 on C4), then by the vector-memory front end")
-        out["kernel_ms_per_step"] = {"trace_closest": round(closest_ms / args.steps, 4),
-                                     "trace_shadow": round(shadow_ms / args.steps, 4),
-                                     "raygen+shade+accumulate": round(shade_ms / args.steps, 4)}
+        rc = roof("k_trace_closest", bytes_closest, acc["closest_rays"], acc["closest_ms"])
+        rs = roof("k_trace_shadow", bytes_shadow, acc["shadow_rays"], acc["shadow_ms"])
+        dom, other_k = (rc, rs) if acc["closest_ms"] >= acc["shadow_ms"] else (rs, rc)
+
+        def contract(k):
+            """The contract's roofline object for one kernel: the HBM axis on MEASURED traffic (never above 1)."""
+            h = k["hbm_measured"]
+            base = {"kernel": k["kernel"], "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "achieved": h["achieved"] if h else None, "frac": h["frac"] if h else None, "traffic": k["traffic"],
+                    "avg_launch_ms": k["avg_launch_ms"], "rays_per_launch": k["rays_per_launch"],
+                    "algorithmic": k["algorithmic"]}
+            if "valu" in k:
+                base["valu"] = k["valu"]
+            return base
+
+        out["roofline"] = contract(dom)
+        out["roofline_other"] = contract(other_k)
+        out["roofline_note"] = ("bound: the contract's axis for this path is HBM; achieved / frac / traffic are the MEASURED HBM-side "
+                                "bytes of this run's counter passes (rocprofv3 child processes on the same prepared scene), not the "
+                                "algorithmic demand, which the caches absorb. What binds the traversal kernels is in `valu` and "
+                                "DESIGN.md section 6.")
+        if pmc and any("error" in v for v in pmc.values() if isinstance(v, dict)):
+            out["pmc_errors"] = {k: v["error"] for k, v in pmc.items() if isinstance(v, dict) and "error" in v}
+        out["kernel_ms_per_step"] = {"trace_closest": round(acc["closest_ms"] / args.steps, 4),
+                                     "trace_shadow": round(acc["shadow_ms"] / args.steps, 4),
+                                     "raygen+shade+accumulate": round(acc["shade_ms"] / args.steps, 4)}
     # ---- CPU baseline: the oracle restatement on this box's host cores (reported, not a target) ----
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from tests.oracle_lib import OracleRenderer
@@ -228,14 +352,20 @@ def main():
         stp = o.render(eye, cdir, up, fovy, True, 0, probe)  # calibrate on a few tiles
         per_tile = stp.render_time_ms / probe
         n_sample = int(max(probe, min(ntiles, args.cpu_seconds * 1e3 / max(per_tile, 1e-3))))
-        # spread the sample over the image: every k-th block of tiles
         stc = o.render(eye, cdir, up, fovy, True, 0, n_sample)
         out["cpu_baseline"] = {"value": round(stc.rays_per_second / 1e6, 3), "unit": "MRay/s", "cores": cores,
                                "kind": "port",
-                               "sample": f"CPU restatement (not Embree): frame 0 of the same workload, first {n_sample} of "
-                                         f"{ntiles} 64x64 tiles, {stc.rays} rays in {stc.render_time_ms / 1e3:.1f} s"}
+                               "sample": f"CPU restatement (scalar C++, own BVH2 -- NOT Embree/ISPC/TBB, which cannot be built here): "
+                                         f"frame 0 of the same workload, first {n_sample} of {ntiles} 64x64 tiles, "
+                                         f"{stc.rays} rays in {stc.render_time_ms / 1e3:.1f} s"}
     r.close()
+    ps.close()
+    if dist:
+        dist.barrier()
     if rank == 0:
+        for p in (prepared_path, meta_path):
+            if os.path.exists(p):
+                os.remove(p)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -28,7 +28,7 @@ EXPORTS = [
     "crt_hip_bvh_copy", "crt_hip_bvh_layout", "crt_hip_bvh_copy_instances", "crt_hip_prepare_scene",
     "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
-    "crt_hip_child_order", "crt_hip_lds_stack_entries",
+    "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp",
 ]
 
 
@@ -109,6 +109,8 @@ def load():
     L.crt_hip_prepared_scene_info.argtypes = [vp, u64p, u64p, u64p, i32p, fp, i32p, u32p, u32p, C.POINTER(C.c_double)]
     L.crt_hip_prepared_scene_copy.argtypes = [vp, vp, vp, vp]
     L.crt_hip_child_order.restype = C.c_int
+    L.crt_hip_prepared_scene_set_spp.argtypes = [vp, C.c_uint32]
+    L.crt_hip_prepared_scene_set_spp.restype = C.c_int
     L.crt_hip_lds_stack_entries.restype = C.c_uint32
     for fn in ("crt_hip_set_stream", "crt_hip_set_partition", "crt_hip_initialize", "crt_hip_set_scene",
                "crt_hip_render", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_tile_buffer",

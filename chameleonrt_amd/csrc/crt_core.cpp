@@ -177,7 +177,10 @@ struct crt_hip_ctx {
     int width = 0, height = 0, ntx = 0, nty = 0;
     std::vector<uint32_t> tile_ids; // tiles this rank renders
     uint32_t n_local_tiles = 0, n_tiles_padded = 0;
-    DeviceBuffer d_tile_ids, d_accum, d_tile_fb, d_img, d_ray_counts;
+    DeviceBuffer d_tile_ids, d_accum, d_tile_fb[2], d_img, d_ray_counts;
+    // The compact RGBA8 tile buffer is double-buffered by frame parity: the gather of frame f (RCCL, on
+    // another stream) may still read its buffer while frame f+1 is traced and accumulated into the other.
+    int tile_fb_last = 0; // buffer the last rendered frame wrote
     std::vector<uint32_t> img;
     uint32_t frame_id = 0;
 
@@ -564,11 +567,15 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
         const size_t slots = (size_t)std::max(1u, ctx->n_local_tiles) * TILE_PIXELS;
         ctx->d_accum.alloc(slots * sizeof(float4));
         ctx->d_ray_counts.alloc(slots * sizeof(uint32_t));
-        ctx->d_tile_fb.alloc((size_t)std::max(1u, ctx->n_tiles_padded) * TILE_PIXELS * sizeof(uint32_t));
+        for (DeviceBuffer &b : ctx->d_tile_fb) {
+            b.alloc((size_t)std::max(1u, ctx->n_tiles_padded) * TILE_PIXELS * sizeof(uint32_t));
+        }
         ctx->d_img.alloc((size_t)fb_width * fb_height * sizeof(uint32_t));
         HIP_CHECK(hipMemsetAsync(ctx->d_accum.ptr, 0, ctx->d_accum.bytes, ctx->stream));
         HIP_CHECK(hipMemsetAsync(ctx->d_ray_counts.ptr, 0, ctx->d_ray_counts.bytes, ctx->stream));
-        HIP_CHECK(hipMemsetAsync(ctx->d_tile_fb.ptr, 0, ctx->d_tile_fb.bytes, ctx->stream));
+        for (DeviceBuffer &b : ctx->d_tile_fb) {
+            HIP_CHECK(hipMemsetAsync(b.ptr, 0, b.bytes, ctx->stream));
+        }
         HIP_CHECK(hipMemsetAsync(ctx->d_img.ptr, 0, ctx->d_img.bytes, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->capacity = 0; // queues are (re)sized lazily: they depend on spp too
@@ -1015,6 +1022,15 @@ int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *ps, void *nodes, v
     return CRT_HIP_OK;
 }
 
+int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *ps, uint32_t samples_per_pixel)
+{
+    if (!ps || samples_per_pixel == 0) {
+        return fail(nullptr, CRT_HIP_EINVAL, "prepared_scene_set_spp: bad arguments");
+    }
+    ps->spp = samples_per_pixel;
+    return CRT_HIP_OK;
+}
+
 int crt_hip_child_order(void) { return traversal_child_order(); }
 uint32_t crt_hip_lds_stack_entries(void) { return traversal_lds_stack(); }
 
@@ -1198,7 +1214,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             }
             mark(2);
             launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
-                              ctx->d_tile_fb.as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
+                              ctx->d_tile_fb[ctx->frame_id & 1u].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
                               ctx->d_ray_counts.as<uint32_t>());
             mark_end();
             HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost,
@@ -1271,6 +1287,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         if (stats) {
             *stats = st;
         }
+        ctx->tile_fb_last = (int)(ctx->frame_id & 1u);
         ++ctx->frame_id;
         return CRT_HIP_OK;
     });
@@ -1349,7 +1366,7 @@ int crt_hip_tile_buffer(crt_hip_ctx *ctx, void **device_ptr, size_t *n_bytes)
             return fail(ctx, CRT_HIP_ESTATE, "tile_buffer before initialize");
         }
         if (device_ptr) {
-            *device_ptr = ctx->d_tile_fb.ptr;
+            *device_ptr = ctx->d_tile_fb[ctx->tile_fb_last].ptr;
         }
         if (n_bytes) {
             *n_bytes = (size_t)ctx->n_tiles_padded * TILE_PIXELS * sizeof(uint32_t);

@@ -32,20 +32,22 @@ def padded_tiles(width: int, height: int, world: int) -> int:
     return (ntx * nty + world - 1) // world
 
 
-def gather_tile_buffers(local, group=None, dst: int = 0):
+def gather_tile_buffers(local, group=None, dst: int = 0, async_op: bool = False):
     """Gather every rank's compact tile buffer (1-D uint8/int32 tensor, same length on all
-    ranks) to `dst`. Returns the (world * n) tensor on dst, None elsewhere."""
+    ranks) to `dst`. Returns the (world * n) tensor on dst, None elsewhere. async_op: returns
+    (tensor or None, work handle) instead and does not wait -- the core double-buffers the tile
+    buffer by frame parity, so the gather of frame f may run while frame f+1 is traced; wait on the
+    handle before frame f+2 is rendered."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    out, parts = None, None
     if rank == dst:
         import torch
         out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
         parts = list(out.chunk(world))
-        dist.gather(local, parts, dst=dst, group=group)
-        return out
-    dist.gather(local, None, dst=dst, group=group)
-    return None
+    work = dist.gather(local, parts, dst=dst, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def reduce_ray_stats(rays: int, ms: float, group=None, device="cpu"):

@@ -177,6 +177,10 @@ class PreparedScene:
                     child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(),
                     build_ms=ms.value)
 
+    def set_samples_per_pixel(self, spp: int):
+        assert self._lib.crt_hip_prepared_scene_set_spp(self.handle, spp) == 0
+        self.samples_per_pixel = spp
+
     def save(self, path: str):
         rc = self._lib.crt_hip_save_prepared_scene(self.handle, path.encode())
         if rc != 0:

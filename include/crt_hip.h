@@ -178,6 +178,9 @@ int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *prepared, uint64_t
                                 uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
                                 uint32_t *n_top_nodes, uint32_t *stack_need, double *build_ms);
 int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *prepared, void *nodes, void *tris, void *instances);
+/* Scene::samples_per_pixel of a prepared scene (the one thing bench.py varies between its strong-
+ * and weak-scaling legs; everything else in a prepared scene is immutable). */
+int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *prepared, uint32_t samples_per_pixel);
 int crt_hip_child_order(void); /* the build's CRT_CHILD_ORDER (see crt_hip_bvh_layout) */
 uint32_t crt_hip_lds_stack_entries(void); /* per-lane traversal-stack entries kept in LDS; deeper ones live in HBM */
 crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
@@ -196,8 +199,10 @@ int crt_hip_read_accum(crt_hip_ctx *ctx, float *rgb /* W*H*3 */);
 int crt_hip_read_ray_counts(crt_hip_ctx *ctx, uint32_t *counts /* W*H, last frame */);
 uint32_t crt_hip_frame_id(const crt_hip_ctx *ctx);
 
-/* Multi-GPU assembly. Each rank exposes its compact tile-major RGBA8 buffer
- * (n_local_tiles_padded * 64*64 uint32, same size on every rank) as a device pointer; the
+/* Multi-GPU assembly. Each rank exposes the compact tile-major RGBA8 buffer of the frame it rendered
+ * LAST (n_local_tiles_padded * 64*64 uint32, same size on every rank) as a device pointer -- two
+ * buffers alternate by frame parity, so the gather of frame f may overlap the tracing of frame f+1
+ * and must have completed before frame f+2 is rendered; the
  * caller gathers them (RCCL gather/all_gather) into world consecutive slabs on the root,
  * which un-permutes them into its row-major image (kernel K8). */
 int crt_hip_tile_buffer(crt_hip_ctx *ctx, void **device_ptr, size_t *n_bytes);

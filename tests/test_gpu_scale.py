@@ -33,7 +33,7 @@ FRAME_CASES = {
                                       n_instanced=100, glass=True), 640, 360, 2),
     # the flattened, OBJ-like variant of the same content (single level)
     "sanmiguel_flat_480x270_4spp": (
-        lambda: scenes.sanmiguel_like(spp=4, detail=0.05, tex_size=128, n_trees=100, leaves_per_tree=600), 480, 270, 2),
+        lambda: scenes.sanmiguel_like(spp=4, detail=0.05, tex_size=128, n_trees=120, leaves_per_tree=600), 480, 270, 2),
 }
 
 

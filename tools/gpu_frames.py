@@ -13,11 +13,13 @@ elif which == "cornell":
     sc, w, h = scenes.cornell(spp=2), 256, 256
 else:
     wd = which.endswith("wd")
+    if wd:
+        which = which[:-2]
     over = {}
     if ":" in which:  # e.g. C4:tex_size=512,n_tex=16
         which, _, kv = which.partition(":")
         over = {k: int(v) for k, v in (x.split("=") for x in kv.split(","))}
-    t = time.time(); sc, w, h, spp = scenes.make_workload(which[:2], **over); print("scene gen", time.time() - t, "s", sc.total_tris(), "tris")
+    t = time.time(); sc, w, h, spp = scenes.make_workload(which, **over); print("scene gen", time.time() - t, "s", sc.total_tris(), "tris")
     if wd:
         sc = sc.white_diffuse()
 r = RenderHIP(flags=flags); r.initialize(w, h)
