@@ -237,7 +237,7 @@ def main():
                        "textures": len(scene.textures), "materials": len(scene.materials),
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
-                                      (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist and world > 1 else ""),
+                                      (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist else ""),
                        "scene_gen_s": round(t_gen, 2), "set_scene_host_s": round(t_prep, 2),
                        "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},
         }
@@ -281,6 +281,10 @@ def main():
             k = d.get(kernel)
             return (k.get(name), k.get("calls")) if isinstance(k, dict) and name in k else (None, None)
 
+        def k_total_us(kernel):
+            k = pmc.get("sq", {}).get(kernel)
+            return k.get("total_us") if isinstance(k, dict) else None
+
         def roof(name, b_per_ray, n_rays, ms):
             avg_ms = ms / launches
             algorithmic = b_per_ray * n_rays / (ms * 1e-3) / 1e9
@@ -311,8 +315,14 @@ def main():
                 out_k["valu"] = {"lanes_active_per_instruction": round(thr / insts, 1),
                                  "wave_cycles_waiting": round((wait_any or 0) / wave_cyc, 3),
                                  "wave_cycles_issue_stalled": round((wait_inst or 0) / wave_cyc, 3)}
-                if va and busy:
-                    out_k["valu"]["busy_frac_of_simd_cycles"] = round(va / busy, 4)
+                gui, _ = counter("sq", name, "GRBM_GUI_ACTIVE")
+                if gui:
+                    # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 =
+                    # 2 cyc); GRBM_GUI_ACTIVE is summed over the 8 XCDs. A lower bound of pipe occupancy: quarter-rate
+                    # instructions (rcp, sqrt, 64-bit) hold the pipe longer.
+                    cycles = gui / 8.0
+                    out_k["valu"]["pipe_busy_frac"] = round(insts * 2.0 / (N_CUS * SIMDS * cycles), 4)
+                    out_k["valu"]["clock_GHz"] = round(cycles / (k_total_us(name) * 1e-6) / 1e9, 3) if k_total_us(name) else None
             out_k["traffic"] = None if traffic is None else round(traffic)
             return out_k
 

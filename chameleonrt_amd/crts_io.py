@@ -61,7 +61,9 @@ def crts_default_light() -> np.ndarray:
     """The light load_crts generates for a file without one (scene.cpp:611-623)."""
     n = _normalize([0.5, -0.8, -0.5])
     v_x, v_y = ortho_basis(n)
-    return quad_light([10.0, 10.0, 10.0, 10.0], (np.float32(-10.0) * n).astype(np.float32), n, v_x, v_y, 5.0, 5.0)
+    l = quad_light([10.0, 10.0, 10.0, 10.0], (np.float32(-10.0) * n).astype(np.float32), n, v_x, v_y, 5.0, 5.0)
+    l[7] = np.float32(-0.0)  # position = -10.f * vec4(normal, 0): w is minus zero (scene.cpp:617)
+    return l
 
 
 def _view(header: dict, blob: memoryview, view_id: int, want: Tuple[type, int]) -> np.ndarray:

@@ -35,6 +35,12 @@ namespace crt {
 #ifndef CRT_TRACE_BLOCKS_PER_CU
 #define CRT_TRACE_BLOCKS_PER_CU 7
 #endif
+// waves per SIMD the register allocator must leave room for in the traversal kernels (= blocks per CU
+// for 256-thread blocks). 1 = no constraint: forcing 7 makes the allocator spill to scratch, and a
+// scratch-backed kernel loses more than the occupancy buys
+#ifndef CRT_TRACE_MIN_WAVES
+#define CRT_TRACE_MIN_WAVES 1
+#endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
 constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each; 85 = 4 full levels)
 constexpr int SHADE_BLOCK = 256;
@@ -241,7 +247,7 @@ struct ClosestSource {
 };
 
 template <bool TWO_LEVEL, bool COUNTERS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
+__global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;
@@ -323,7 +329,7 @@ struct ShadowSource {
 };
 
 template <bool TWO_LEVEL, bool COUNTERS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
+__global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
     __shared__ TraceLds lds;

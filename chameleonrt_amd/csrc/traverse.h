@@ -60,6 +60,10 @@ struct TraversalStack {
         --sp;
         return sp < LDS_STACK ? lds[sp * stride] : spill[(sp - LDS_STACK) * 64];
     }
+    CRT_DEV int32_t peek() const // the top entry (sp > 0), left on the stack
+    {
+        return sp - 1 < LDS_STACK ? lds[(sp - 1) * stride] : spill[(sp - 1 - LDS_STACK) * 64];
+    }
 };
 
 CRT_DEV V3 xfm_point(const float *m, V3 p) // column-major affine, rows evaluated left to right
@@ -153,6 +157,10 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 #endif
 #ifndef CRT_POOL_CHUNK
 #define CRT_POOL_CHUNK 128
+#endif
+// leaf step: 1 = all loads of the step (both triangles, next stack entry) in flight before the first test
+#ifndef CRT_LEAF_V2
+#define CRT_LEAF_V2 1
 #endif
 constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
 
@@ -444,6 +452,78 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             } else {
                 const uint32_t count = (x & 7u) + 1u;
                 bool occluded = false;
+#if CRT_LEAF_V2
+                // All of the leaf's loads are issued before anything is tested -- both triangles of a
+                // two-triangle leaf (the builder makes leaves of <= 2) and the stack entry the lane will
+                // continue with -- so a leaf step pays ONE memory latency instead of up to three in a
+                // row (PMC + wave profile, DESIGN.md section 6: leaf steps ran 4 700 cycles each with a
+                // third of the lanes and took 31-39 % of the traversal kernels' wave time).
+                const float4 *p = reinterpret_cast<const float4 *>(sc.tris + first);
+                const float4 a0 = p[0], b0 = p[1], c0 = p[2];
+                float4 a1 = a0, b1 = b0, c1 = c0;
+                if (count > 1u) {
+                    a1 = p[3];
+                    b1 = p[4];
+                    c1 = p[5];
+                }
+                const bool have_next = st.sp > 0;
+                const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
+                auto test_one = [&](const float4 a, const float4 b, const float4 c, uint32_t k) {
+                    if (COUNTERS) {
+                        ++n_tris;
+                    }
+                    float t, u, v;
+                    if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
+                        if (ANY_HIT) {
+                            occluded = true;
+                            return;
+                        }
+                        const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
+                        bool take = t < hit.t;
+                        if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
+                            take = cur_inst != hit.inst ? cur_inst < hit.inst
+                                                        : (geom != best_geom ? geom < best_geom : prim < best_prim);
+                        } else if (t == hit.t) {
+                            take = true; // first hit exactly at tfar
+                        }
+                        if (take) {
+                            hit.t = t;
+                            hit.u = u;
+                            hit.v = v;
+                            hit.tri = (int32_t)k;
+                            hit.inst = cur_inst;
+                            best_geom = geom;
+                            best_prim = prim;
+                        }
+                    }
+                };
+                test_one(a0, b0, c0, first);
+                if (count > 1u && !(ANY_HIT && occluded)) {
+                    test_one(a1, b1, c1, first + 1u);
+                }
+                for (uint32_t k = first + 2u; k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of > 2 (CRT_BVH_MAX_LEAF)
+                    const float4 *pk = reinterpret_cast<const float4 *>(sc.tris + k);
+                    test_one(pk[0], pk[1], pk[2], k);
+                }
+                if (ANY_HIT && occluded) {
+                    hit.tri = 0;
+                    hit.inst = cur_inst;
+                    hit.t = 0.f;
+                    cur = CUR_DONE;
+                } else if (!have_next) {
+                    cur = CUR_DONE;
+                } else {
+                    --st.sp; // consume the entry read above
+                    cur = next_ref;
+                    if (TWO_LEVEL && cur == STACK_SENTINEL) {
+                        o = org;
+                        d = dir;
+                        set_frame(sc.root_frame);
+                        in_blas = false;
+                        pop_next();
+                    }
+                }
+#else
                 for (uint32_t k = first; k < first + count; ++k) {
                     const float4 *p = reinterpret_cast<const float4 *>(sc.tris + k);
                     const float4 a = p[0], b = p[1], c = p[2];
@@ -483,6 +563,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 } else {
                     pop_next();
                 }
+#endif
             }
         }
 

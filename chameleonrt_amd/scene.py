@@ -118,6 +118,7 @@ def obj_default_light() -> np.ndarray:
     pos = (np.float32(-10.0) * n).astype(np.float32)
     v_x, v_y = ortho_basis(n)
     l = quad_light([20.0, 20.0, 20.0, 20.0], pos, n, v_x, v_y, 5.0, 5.0)
+    l[7] = np.float32(-0.0)  # `light.position = -10.f * light.normal` with normal.w = 0 (scene.cpp:222): minus zero
     return l
 
 

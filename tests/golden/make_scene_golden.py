@@ -1,0 +1,97 @@
+"""Golden Scene dumps from the REFERENCE's importer (development container only).
+
+    make -C oracle ref            # builds oracle/_ref/libref_scene.so from /root/reference/util/*.cpp
+    python tests/golden/make_scene_golden.py
+
+Writes small scene files of every on-disk format the reference's `Scene::Scene` dispatches on
+(util/scene.cpp:49-72) under tests/golden/scenes/ and, next to them, what the reference's own
+load_obj / load_gltf / load_crts (compiled from where they lie, GLM replaced by the stand-in of
+oracle/ref_shim_scene/) make of each: tests/golden/refscene_<name>.npz, in DEFAULT and WHITE_DIFFUSE
+material mode. tests/test_importers_pinned.py compares chameleonrt_amd's importers to these dumps
+wherever the suite runs, and to the live library where it exists.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENES = os.path.join(HERE, "scenes")
+
+
+def write_files():
+    """Every test file, deterministic. Returns {name: path}."""
+    from chameleonrt_amd import scenes
+    from chameleonrt_amd.crts_io import save_crts
+    from chameleonrt_amd.obj_io import save_obj
+    from tests import test_crts_io, test_gltf_io
+    os.makedirs(SCENES, exist_ok=True)
+    out = {}
+    p = os.path.join(SCENES, "cornell.obj")
+    save_obj(scenes.cornell(), p)
+    out["obj_cornell"] = p
+    p = os.path.join(SCENES, "atrium.obj")  # textured (map_Kd -> flipped RGBA8 sRGB), UVs outside [0, 1], 24 materials
+    save_obj(scenes.sponza_like(detail=0.004, tex_size=8), p)
+    out["obj_atrium"] = p
+    with open(os.path.join(SCENES, "quirks.mtl"), "w") as f:
+        f.write("newmtl shiny\nKd 0.2 0.4 0.6\nNs 250\nnewmtl dull\nKd 1 0 0\nNs 0\nnewmtl over\nKd 0.3 0.3 0.3\nNs 900\n")
+    p = os.path.join(SCENES, "quirks.obj")
+    with open(p, "w") as f:  # polygon fan, negative indices, first-face material, material-less group, vn/vt triples
+        f.write("mtllib quirks.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 1\nvn 0 2 0\n"
+                "o quad\nusemtl shiny\nf 1 2 3 4\n"
+                "o mixed\nusemtl dull\nf 1 2 5\nusemtl shiny\nf -1 -2 -3\n"
+                "o triples\nusemtl over\nf 1/1/1 2/2/1 3/3/2\nf 1/1/2 3/3/2 4/2/2\n"
+                "g tail\nf 1 3 5\n")
+    out["obj_quirks"] = p
+    p = os.path.join(SCENES, "bare.obj")
+    with open(p, "w") as f:
+        f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    out["obj_bare"] = p
+    p = os.path.join(SCENES, "scene.gltf")
+    test_gltf_io._scene_file(p, glb=False)
+    out["gltf_scene"] = p
+    p = os.path.join(SCENES, "scene.glb")
+    test_gltf_io._scene_file(p, glb=True)
+    out["glb_scene"] = p
+    # a node tree with rotations: flatten_gltf.cpp
+    b = test_gltf_io.Builder()
+    a_pos = b.accessor(b.view(test_gltf_io.QUAD_POS.tobytes()), 5126, "VEC3", 4)
+    a_idx = b.accessor(b.view(np.uint16(test_gltf_io.QUAD_IDX).tobytes()), 5123, "SCALAR", 6)
+    b.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": a_pos}, "indices": a_idx}]}] * 2
+    s = float(np.sqrt(0.5))
+    b.doc["nodes"] = [{"translation": [10, 0, 0], "rotation": [0.0, s, 0.0, s], "children": [1, 3]},
+                      {"mesh": 0, "scale": [2, 3, 0.5], "rotation": [0.1825742, 0.3651484, 0.5477226, 0.7302967], "children": [2]},
+                      {"mesh": 1, "translation": [0.25, 1, -3]},
+                      {"mesh": 1, "translation": [0, 0, 5], "scale": [1.5, 1.5, 1.5]},
+                      {"mesh": 0, "matrix": [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 1, 2, 3, 1]}]
+    b.doc["scenes"][0]["nodes"] = [0, 4]
+    p = os.path.join(SCENES, "tree.gltf")
+    b.finish(p)
+    out["gltf_tree"] = p
+    p = os.path.join(SCENES, "handmade.crts")
+    test_crts_io._handmade(p, with_light=True)
+    out["crts_handmade"] = p
+    p = os.path.join(SCENES, "nolight.crts")
+    test_crts_io._handmade(p, with_light=False)
+    out["crts_nolight"] = p
+    p = os.path.join(SCENES, "grove.crts")  # two-level scene with textures, lights and a camera, written by save_crts
+    save_crts(scenes.instanced_grove(n_instances=12, leaves_per_tree=40, tex_size=8), p)
+    out["crts_grove"] = p
+    return out
+
+
+def main():
+    from tests import ref_scene_lib as R
+    if not R.available():
+        raise SystemExit("oracle/_ref/libref_scene.so is missing: `make -C oracle ref` (needs /root/reference)")
+    for name, path in write_files().items():
+        for wd in (False, True):
+            d = R.load(path, white_diffuse=wd)
+            np.savez_compressed(os.path.join(HERE, f"refscene_{name}{'_wd' if wd else ''}.npz"), **d)
+            print(name, "white_diffuse" if wd else "default", dict(zip("mesh pmesh inst mat tex light cam".split(), d["counts"])))
+
+
+if __name__ == "__main__":
+    main()
