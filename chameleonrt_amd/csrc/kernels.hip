@@ -33,13 +33,14 @@ namespace crt {
 #define CRT_TRACE_BLOCK 256
 #endif
 #ifndef CRT_TRACE_BLOCKS_PER_CU
-#define CRT_TRACE_BLOCKS_PER_CU 7
+#define CRT_TRACE_BLOCKS_PER_CU 6
 #endif
 // waves per SIMD the register allocator must leave room for in the traversal kernels (= blocks per CU
-// for 256-thread blocks). 1 = no constraint: forcing 7 makes the allocator spill to scratch, and a
-// scratch-backed kernel loses more than the occupancy buys
+// for 256-thread blocks). 6: every variant fits 80 VGPRs without scratch (the two-level closest-hit
+// kernel would otherwise take 82 and run 5 waves). Forcing 7 makes the allocator spill, and a
+// scratch-backed kernel loses far more than the seventh wave buys (measured: C4 +19 % frame time).
 #ifndef CRT_TRACE_MIN_WAVES
-#define CRT_TRACE_MIN_WAVES 1
+#define CRT_TRACE_MIN_WAVES 6
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
 constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each; 85 = 4 full levels)
@@ -191,12 +192,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 }
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
-struct TraceLds {
+template <bool TWO_LEVEL> struct TraceLds {
     QNode top[MAX_TOP_NODES + 1];
     int32_t stack[LDS_STACK][TRACE_BLOCK];
+    // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
+    float cold[TWO_LEVEL ? 10 : 1][TRACE_BLOCK];
 };
 
-CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, TraceLds &lds)
+template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, Lds &lds)
 {
     // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step.
     const uint32_t n = min(sc.n_top_nodes, (uint32_t)MAX_TOP_NODES);
@@ -250,11 +253,12 @@ template <bool TWO_LEVEL, bool COUNTERS>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
-    __shared__ TraceLds lds;
+    __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
@@ -332,11 +336,12 @@ template <bool TWO_LEVEL, bool COUNTERS>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
-    __shared__ TraceLds lds;
+    __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
@@ -706,11 +711,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
                                                             int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
                                                             unsigned long long *counters)
 {
-    __shared__ TraceLds lds;
+    __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
     TraversalStack st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;

@@ -44,6 +44,7 @@ struct RayHit {
 struct TraversalStack {
     TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
+    TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
     int sp;
     CRT_DEV void push(int32_t x)
@@ -203,7 +204,29 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     // per-lane ray state
     int32_t ray = -1;
     int32_t cur = CUR_DONE;
-    V3 org = v3(0.f), dir = v3(0.f); // world-space ray
+    // World-space ray. Single level: registers (dead once the ray has started). Two level: needed again
+    // only when an instance is entered or left and when the ray retires, so it lives in LDS -- six
+    // VGPRs fewer is the difference between 5 and 6 resident waves per SIMD for the two-level kernels.
+    V3 org_r = v3(0.f), dir_r = v3(0.f);
+    auto world_org = [&]() -> V3 {
+        return TWO_LEVEL ? v3(st.cold[0], st.cold[st.stride], st.cold[2 * st.stride]) : org_r;
+    };
+    auto world_dir = [&]() -> V3 {
+        return TWO_LEVEL ? v3(st.cold[3 * st.stride], st.cold[4 * st.stride], st.cold[5 * st.stride]) : dir_r;
+    };
+    auto set_world = [&](V3 wo, V3 wd) {
+        if (TWO_LEVEL) {
+            st.cold[0] = wo.x;
+            st.cold[st.stride] = wo.y;
+            st.cold[2 * st.stride] = wo.z;
+            st.cold[3 * st.stride] = wd.x;
+            st.cold[4 * st.stride] = wd.y;
+            st.cold[5 * st.stride] = wd.z;
+        } else {
+            org_r = wo;
+            dir_r = wd;
+        }
+    };
     V3 o = v3(0.f), d = v3(0.f);                 // ray in the space being traversed
     SlabRay sr;                                  // that ray in the fixed-point frame of the current BVH
     sr.qa[0] = sr.qa[1] = sr.qa[2] = sr.qb[0] = sr.qb[1] = sr.qb[2] = 0.f;
@@ -214,6 +237,27 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     hit.u = hit.v = 0.f;
     hit.tri = hit.inst = -1;
     uint32_t best_geom = 0, best_prim = 0;
+    // Two level: the barycentrics and ids of the best hit so far are written when a hit is accepted and
+    // read when the ray retires (ids also on an exact tie in t): cold state, kept in LDS next to the
+    // world-space ray (slots 6..9).
+    auto store_hit_cold = [&](float u, float v, uint32_t geom, uint32_t prim) {
+        if (TWO_LEVEL) {
+            st.cold[6 * st.stride] = u;
+            st.cold[7 * st.stride] = v;
+            st.cold[8 * st.stride] = __uint_as_float(geom);
+            st.cold[9 * st.stride] = __uint_as_float(prim);
+        } else {
+            hit.u = u;
+            hit.v = v;
+            best_geom = geom;
+            best_prim = prim;
+        }
+    };
+    auto tie_break = [&](uint32_t geom, uint32_t prim) -> bool { // (geom, prim) < (best_geom, best_prim)
+        const uint32_t bg = TWO_LEVEL ? __float_as_uint(st.cold[8 * st.stride]) : best_geom;
+        const uint32_t bp = TWO_LEVEL ? __float_as_uint(st.cold[9 * st.stride]) : best_prim;
+        return geom != bg ? geom < bg : prim < bp;
+    };
     int32_t cur_inst = 0;
     bool in_blas = !TWO_LEVEL;
     st.sp = 0;
@@ -242,6 +286,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
 
     // start traversing the world-space ray (org, dir, tfar)
     auto begin_ray = [&]() {
+        const V3 org = world_org(), dir = world_dir();
         o = org;
         d = dir;
         cur_inst = 0;
@@ -271,8 +316,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
             cur = st.pop();
             if (TWO_LEVEL && cur == STACK_SENTINEL) {
-                o = org;
-                d = dir;
+                o = world_org();
+                d = world_dir();
                 set_frame(sc.root_frame);
                 in_blas = false;
                 continue;
@@ -310,7 +355,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     const uint32_t rank = tv_lanes_below(idle_mask);
                     if (rank < take) {
                         ray = (int32_t)(pool_next + rank);
-                        src.load((uint32_t)ray, org, dir, tfar);
+                        V3 wo, wd;
+                        src.load((uint32_t)ray, wo, wd, tfar);
+                        set_world(wo, wd);
                         stage = 0;
                         begin_ray();
                     }
@@ -442,8 +489,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 const InstanceRec &in = sc.instances[first];
                 cur_inst = (int32_t)first;
                 if (!in.identity) {
-                    o = xfm_point(in.w2o, org);
-                    d = xfm_vector(in.w2o, dir);
+                    o = xfm_point(in.w2o, world_org());
+                    d = xfm_vector(in.w2o, world_dir());
                 }
                 set_frame(in.frame);
                 in_blas = true;
@@ -460,8 +507,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 // third of the lanes and took 31-39 % of the traversal kernels' wave time).
                 const float4 *p = reinterpret_cast<const float4 *>(sc.tris + first);
                 const float4 a0 = p[0], b0 = p[1], c0 = p[2];
+                // (two-level kernels hold more ray state: there the second triangle is fetched after the first
+                // has been tested, which keeps them at 6 waves per SIMD instead of 5)
+                constexpr bool PRELOAD_BOTH = !TWO_LEVEL;
                 float4 a1 = a0, b1 = b0, c1 = c0;
-                if (count > 1u) {
+                if (PRELOAD_BOTH && count > 1u) {
                     a1 = p[3];
                     b1 = p[4];
                     c1 = p[5];
@@ -481,24 +531,25 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                         const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
                         bool take = t < hit.t;
                         if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
-                            take = cur_inst != hit.inst ? cur_inst < hit.inst
-                                                        : (geom != best_geom ? geom < best_geom : prim < best_prim);
+                            take = cur_inst != hit.inst ? cur_inst < hit.inst : tie_break(geom, prim);
                         } else if (t == hit.t) {
                             take = true; // first hit exactly at tfar
                         }
                         if (take) {
                             hit.t = t;
-                            hit.u = u;
-                            hit.v = v;
                             hit.tri = (int32_t)k;
                             hit.inst = cur_inst;
-                            best_geom = geom;
-                            best_prim = prim;
+                            store_hit_cold(u, v, geom, prim);
                         }
                     }
                 };
                 test_one(a0, b0, c0, first);
                 if (count > 1u && !(ANY_HIT && occluded)) {
+                    if (!PRELOAD_BOTH) {
+                        a1 = p[3];
+                        b1 = p[4];
+                        c1 = p[5];
+                    }
                     test_one(a1, b1, c1, first + 1u);
                 }
                 for (uint32_t k = first + 2u; k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of > 2 (CRT_BVH_MAX_LEAF)
@@ -516,8 +567,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     --st.sp; // consume the entry read above
                     cur = next_ref;
                     if (TWO_LEVEL && cur == STACK_SENTINEL) {
-                        o = org;
-                        d = dir;
+                        o = world_org();
+                        d = world_dir();
                         set_frame(sc.root_frame);
                         in_blas = false;
                         pop_next();
@@ -539,19 +590,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                         const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
                         bool take = t < hit.t;
                         if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
-                            take = cur_inst != hit.inst ? cur_inst < hit.inst
-                                                        : (geom != best_geom ? geom < best_geom : prim < best_prim);
+                            take = cur_inst != hit.inst ? cur_inst < hit.inst : tie_break(geom, prim);
                         } else if (t == hit.t) {
                             take = true; // first hit exactly at tfar
                         }
                         if (take) {
                             hit.t = t;
-                            hit.u = u;
-                            hit.v = v;
                             hit.tri = (int32_t)k;
                             hit.inst = cur_inst;
-                            best_geom = geom;
-                            best_prim = prim;
+                            store_hit_cold(u, v, geom, prim);
                         }
                     }
                 }
@@ -585,6 +632,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         if (do_retire && ray >= 0 && cur == CUR_DONE) {
             if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
                 if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
+                    const V3 org = world_org(), dir = world_dir();
                     worst_ray[0] = org.x;
                     worst_ray[1] = org.y;
                     worst_ray[2] = org.z;
@@ -596,7 +644,13 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 }
             }
             ray_nodes = 0;
-            if (src.retire((uint32_t)ray, stage, hit, org, dir, tfar, carry)) {
+            if (TWO_LEVEL) {
+                hit.u = st.cold[6 * st.stride];
+                hit.v = st.cold[7 * st.stride];
+            }
+            V3 wo = world_org(), wd = world_dir();
+            if (src.retire((uint32_t)ray, stage, hit, wo, wd, tfar, carry)) {
+                set_world(wo, wd);
                 begin_ray();
             } else {
                 ray = -1;
