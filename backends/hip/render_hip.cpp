@@ -235,17 +235,34 @@ RenderStats RenderHIP::render(const glm::vec3 &pos,
                               const bool camera_changed,
                               const bool readback_framebuffer)
 {
-    const float p[3] = {pos.x, pos.y, pos.z}, d[3] = {dir.x, dir.y, dir.z}, u[3] = {up.x, up.y, up.z};
-    RenderStats stats;
     // GLDisplay uploads `img` every frame (util/display/gldisplay.cpp:113-121), so the image is
     // always brought back, like the Embree backend which renders into host memory.
     (void)readback_framebuffer;
+    return render_impl(pos, dir, up, fovy, camera_changed, true);
+}
+
+RenderStats RenderHIP::render_to_device(const glm::vec3 &pos, const glm::vec3 &dir, const glm::vec3 &up, const float fovy,
+                                        const bool camera_changed, const bool readback_framebuffer)
+{
+    return render_impl(pos, dir, up, fovy, camera_changed, readback_framebuffer);
+}
+
+void RenderHIP::device_framebuffer(void **device_ptr, size_t *pitch_bytes)
+{
+    check(ctxs[0], crt_hip_device_framebuffer(ctxs[0], device_ptr, pitch_bytes), "crt_hip_device_framebuffer");
+}
+
+RenderStats RenderHIP::render_impl(const glm::vec3 &pos, const glm::vec3 &dir, const glm::vec3 &up, const float fovy,
+                                   const bool camera_changed, const bool readback)
+{
+    const float p[3] = {pos.x, pos.y, pos.z}, d[3] = {dir.x, dir.y, dir.z}, u[3] = {up.x, up.y, up.z};
+    RenderStats stats;
     if (!multi) {
         crt_render_stats st;
-        check(ctxs[0], crt_hip_render(ctxs[0], p, d, u, fovy, camera_changed, 1, &st), "crt_hip_render");
+        check(ctxs[0], crt_hip_render(ctxs[0], p, d, u, fovy, camera_changed, readback ? 1 : 0, &st), "crt_hip_render");
         stats.render_time = st.render_time_ms;
         stats.rays_per_second = st.rays_per_second;
-        copy_image(true);
+        copy_image(readback);
         return stats;
     }
     // one wall clock around trace + gather + assemble + read-back, like the reference's render()
@@ -278,8 +295,8 @@ RenderStats RenderHIP::render(const glm::vec3 &pos,
                 "ncclRecv");
     }
     nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-    check(ctxs[0], crt_hip_assemble_tiles(ctxs[0], multi->gathered, int(n), 1), "crt_hip_assemble_tiles");
-    copy_image(true);
+    check(ctxs[0], crt_hip_assemble_tiles(ctxs[0], multi->gathered, int(n), readback ? 1 : 0), "crt_hip_assemble_tiles");
+    copy_image(readback);
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
     stats.render_time = ms;
     stats.rays_per_second = float(rays / (ms * 1.0e-3));

@@ -37,6 +37,12 @@ struct RenderHIP : RenderBackend {
                        const bool camera_changed,
                        const bool readback_framebuffer) override;
 
+    // Display interop (render_hip_gl.h): render without the per-frame copy into `img` unless asked, and the
+    // assembled row-major RGBA8 image as it sits in device 0's HBM (crt_hip_device_framebuffer).
+    RenderStats render_to_device(const glm::vec3 &pos, const glm::vec3 &dir, const glm::vec3 &up, const float fovy,
+                                 const bool camera_changed, const bool readback_framebuffer);
+    void device_framebuffer(void **device_ptr, size_t *pitch_bytes);
+
 private:
     struct MultiGpu; // RCCL communicators + per-device streams (render_hip.cpp)
 
@@ -46,4 +52,6 @@ private:
 
     void check(crt_hip_ctx *ctx, int rc, const char *what) const;
     void copy_image(bool readback);
+    RenderStats render_impl(const glm::vec3 &pos, const glm::vec3 &dir, const glm::vec3 &up, float fovy, bool camera_changed,
+                            bool readback);
 };

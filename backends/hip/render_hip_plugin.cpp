@@ -6,6 +6,9 @@
 #include "display/gldisplay.h"
 #include "imgui.h"
 #include "render_hip.h"
+#ifdef CRT_HIP_GL_INTEROP
+#include "render_hip_gl.h"
+#endif
 #include "render_plugin.h"
 
 static uint32_t hip_window_flags()
@@ -23,8 +26,16 @@ static std::unique_ptr<Display> hip_make_display(SDL_Window *window)
     return std::make_unique<GLDisplay>(window);
 }
 
-static std::unique_ptr<RenderBackend> hip_make_renderer(Display *)
+static std::unique_ptr<RenderBackend> hip_make_renderer(Display *display)
 {
+#ifdef CRT_HIP_GL_INTEROP
+    // like backends/optix/render_optix_plugin.cpp: the native path only when the display is the GL one
+    if (dynamic_cast<GLDisplay *>(display) != nullptr) {
+        return std::make_unique<RenderHIPGL>();
+    }
+#else
+    (void)display;
+#endif
     return std::make_unique<RenderHIP>();
 }
 

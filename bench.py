@@ -323,6 +323,16 @@ def main():
                     cycles = gui / 8.0
                     out_k["valu"]["pipe_busy_frac"] = round(insts * 2.0 / (N_CUS * SIMDS * cycles), 4)
                     out_k["valu"]["clock_GHz"] = round(cycles / (k_total_us(name) * 1e-6) / 1e9, 3) if k_total_us(name) else None
+            # vector-memory front end: share of the kernel's cycles in which a CU's texture addresser (TA) was busy --
+            # the binding resource of this kernel (tools/ta_quad_microbench.hip prices a random
+            # 64-byte node visit at 2.8 TA-bound CU-cycles when it hits L2 and ~10 when it misses)
+            ta, _ = counter("mem", name, "TA_TA_BUSY_sum")
+            gui_m, _ = counter("mem", name, "GRBM_GUI_ACTIVE")
+            hit, _ = counter("mem", name, "TCC_HIT_sum")
+            miss, _ = counter("mem", name, "TCC_MISS_sum")
+            if ta and gui_m:
+                out_k["vmem_front_end"] = {"ta_busy_frac": round(ta / (N_CUS * gui_m / 8.0), 4),
+                                           "l2_hit_rate": round(hit / (hit + miss), 4) if hit is not None and miss else None}
             out_k["traffic"] = None if traffic is None else round(traffic)
             return out_k
 
@@ -339,14 +349,18 @@ def main():
                     "algorithmic": k["algorithmic"]}
             if "valu" in k:
                 base["valu"] = k["valu"]
+            if "vmem_front_end" in k:
+                # what actually binds the kernel, next to the contract's HBM axis: never above 1 by construction
+                base["binding"] = {"resource": "per-CU vector-memory front end (TA busy cycles / kernel cycles)",
+                                   "frac": k["vmem_front_end"]["ta_busy_frac"], "l2_hit_rate": k["vmem_front_end"]["l2_hit_rate"]}
             return base
 
         out["roofline"] = contract(dom)
         out["roofline_other"] = contract(other_k)
         out["roofline_note"] = ("bound: the contract's axis for this path is HBM; achieved / frac / traffic are the MEASURED HBM-side "
                                 "bytes of this run's counter passes (rocprofv3 child processes on the same prepared scene), not the "
-                                "algorithmic demand, which the caches absorb. What binds the traversal kernels is in `valu` and "
-                                "DESIGN.md section 6.")
+                                "algorithmic demand, which the caches absorb. What binds the traversal kernels is `binding`: the per-CU "
+                                "vector-memory front end (divergent 16-byte lane requests), then the waits it causes (`valu`); DESIGN.md section 6.")
         if pmc and any("error" in v for v in pmc.values() if isinstance(v, dict)):
             out["pmc_errors"] = {k: v["error"] for k, v in pmc.items() if isinstance(v, dict) and "error" in v}
         out["kernel_ms_per_step"] = {"trace_closest": round(acc["closest_ms"] / args.steps, 4),

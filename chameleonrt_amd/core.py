@@ -23,10 +23,10 @@ EXPORTS = [
     "crt_hip_abi_version", "crt_hip_device_count", "crt_hip_create", "crt_hip_destroy",
     "crt_hip_last_error", "crt_hip_name", "crt_hip_set_stream", "crt_hip_set_partition",
     "crt_hip_initialize", "crt_hip_set_scene", "crt_hip_render", "crt_hip_framebuffer",
-    "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_frame_id", "crt_hip_tile_buffer",
+    "crt_hip_device_framebuffer", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_frame_id", "crt_hip_tile_buffer",
     "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
     "crt_hip_bvh_copy", "crt_hip_bvh_layout", "crt_hip_bvh_copy_instances", "crt_hip_prepare_scene",
-    "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
+    "crt_hip_prepare_scene_on", "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
     "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp",
 ]
@@ -84,6 +84,8 @@ def load():
     L.crt_hip_render.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.POINTER(RenderStats)]
     L.crt_hip_framebuffer.restype = u32p
     L.crt_hip_framebuffer.argtypes = [vp]
+    L.crt_hip_device_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.crt_hip_device_framebuffer.restype = C.c_int
     L.crt_hip_read_accum.argtypes = [vp, fp]
     L.crt_hip_read_ray_counts.argtypes = [vp, u32p]
     L.crt_hip_frame_id.restype = C.c_uint32
@@ -99,6 +101,8 @@ def load():
     L.crt_hip_bvh_copy_instances.argtypes = [vp, vp]
     L.crt_hip_prepare_scene.restype = vp
     L.crt_hip_prepare_scene.argtypes = [C.POINTER(SceneDesc), C.c_int]
+    L.crt_hip_prepare_scene_on.restype = vp
+    L.crt_hip_prepare_scene_on.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int]
     L.crt_hip_free_prepared_scene.argtypes = [vp]
     L.crt_hip_free_prepared_scene.restype = None
     L.crt_hip_set_prepared_scene.argtypes = [vp, vp]

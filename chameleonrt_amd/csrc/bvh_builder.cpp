@@ -1,5 +1,7 @@
 // bvh_builder.cpp — parallel top-down binned-SAH build, collapse to 4-wide nodes, cache-aware node layout.
 #include "bvh_builder.h"
+#include "bvh_device.h"
+#include "lbvh.h"
 
 #include <algorithm>
 #include <atomic>
@@ -607,6 +609,87 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         out.nodes[i] = nd;
     }
     phase("emit nodes");
+    return out;
+}
+
+// ---- linear BVH on the host: the device builder's algorithm (lbvh.h), run serially ---------------------
+BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes)
+{
+    BuiltBvh out;
+    box_reset(out.bounds);
+    for (size_t i = 0; i < n; ++i) {
+        box_grow(out.bounds, boxes[i]);
+    }
+    if (n < 3) { // degenerate sizes: the SAH builder's single-node forms
+        return build_bvh(boxes, n, max_leaf, 0, 0, false, max_top_nodes, 1);
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> ki(n);
+    for (size_t i = 0; i < n; ++i) {
+        ki[i] = {lbvh_key(boxes[i], out.bounds), (uint32_t)i};
+    }
+    std::stable_sort(ki.begin(), ki.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    std::vector<uint64_t> keys(n);
+    std::vector<Aabb> pbox(n), ibox(n);
+    out.order.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        keys[i] = ki[i].first;
+        out.order[i] = ki[i].second;
+        pbox[i] = boxes[ki[i].second];
+    }
+    std::vector<int32_t> left(n), right(n), lo(n), hi(n);
+    for (size_t i = 0; i + 1 < n; ++i) {
+        int a, b;
+        lbvh_node(keys.data(), (int)n, (int)i, left[i], right[i], a, b);
+        lo[i] = a;
+        hi[i] = b;
+    }
+    // boxes bottom-up: a node covers a narrower key range than its parent, so descending range size works
+    std::vector<uint32_t> by_size(n - 1);
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        by_size[i] = i;
+    }
+    std::sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return hi[a] - lo[a] < hi[b] - lo[b]; });
+    for (uint32_t k : by_size) {
+        box_reset(ibox[k]);
+        box_grow(ibox[k], left[k] >= 0 ? ibox[left[k]] : pbox[~left[k]]);
+        box_grow(ibox[k], right[k] >= 0 ? ibox[right[k]] : pbox[~right[k]]);
+    }
+    const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
+    std::vector<int32_t> frontier{0}, next;
+    uint32_t level_base = 0, depth = 0;
+    while (!frontier.empty()) {
+        next.clear();
+        const uint32_t n_in = (uint32_t)frontier.size();
+        for (uint32_t i = 0; i < n_in; ++i) {
+            int32_t sub[BVH_WIDTH];
+            const int nc = lbvh_wide_children(tree, frontier[i], (uint32_t)max_leaf, sub);
+            BvhNode nd;
+            std::memset(&nd, 0, sizeof(nd));
+            for (int c = 0; c < BVH_WIDTH; ++c) {
+                nd.c[c] = EMPTY_CHILD;
+            }
+            for (int c = 0; c < nc; ++c) {
+                const uint32_t count = lbvh_count(tree, sub[c]);
+                if (count <= (uint32_t)max_leaf) {
+                    nd.c[c] = lbvh_leaf_ref(sub[c] >= 0 ? (uint32_t)lo[sub[c]] : (uint32_t)~sub[c], count);
+                } else {
+                    nd.c[c] = (int32_t)(level_base + n_in + next.size());
+                    next.push_back(sub[c]);
+                }
+                const Aabb &b = lbvh_box(tree, sub[c]);
+                for (int a = 0; a < 3; ++a) {
+                    nd.lo[c][a] = b.lo[a];
+                    nd.hi[c][a] = b.hi[a];
+                }
+            }
+            out.nodes.push_back(nd);
+        }
+        level_base += n_in;
+        frontier.swap(next);
+        ++depth;
+    }
+    out.max_depth = depth;
+    out.n_top = std::min<uint32_t>((uint32_t)out.nodes.size(), max_top_nodes);
     return out;
 }
 

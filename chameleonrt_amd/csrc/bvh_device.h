@@ -1,0 +1,35 @@
+// bvh_device.h — BLAS construction on the device (bvh_device.hip); see lbvh.h for the algorithm.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "bvh_builder.h"
+#include "crt_types.h"
+
+namespace crt {
+
+// One mesh's BLAS as the device built it, copied back to the host: quantised 4-wide nodes in BFS
+// order (inner references are indices into `nodes`, leaf references index `tris`), the triangle
+// records and their vertex UVs (6 floats each) in leaf order.
+struct DeviceBuiltMesh {
+    std::vector<QNode> nodes;
+    std::vector<TriRec> tris;
+    std::vector<float> tri_uvs;
+    Aabb bounds;
+    QFrame frame;
+    uint32_t max_depth = 0; // levels of the wide tree
+    uint32_t n_top = 0;
+};
+
+// Builds the BLAS of the mesh made of geoms[0 .. n_geoms) on HIP device `device`. Returns false (and
+// leaves `out` alone) for meshes too small to be worth it -- the caller then uses the host builder.
+// Throws std::runtime_error on HIP errors.
+bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, uint32_t max_leaf, uint32_t max_top_nodes,
+                       DeviceBuiltMesh &out);
+
+// The same algorithm run serially on the host (shares lbvh.h with the kernels): what the CPU tests
+// check, and the reference the device result is compared against (CRT_BVH_BUILDER=lbvh).
+BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes);
+
+} // namespace crt

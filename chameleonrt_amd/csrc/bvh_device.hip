@@ -1,0 +1,410 @@
+// bvh_device.hip — BLAS construction on the MI355X (the step before the hot path,
+// rtcCommitScene in the reference, embree_utils.cpp:63-76).
+//
+// The host SAH builder (bvh_builder.cpp) takes seconds for a 10 M-triangle mesh; this path builds the same
+// kind of tree -- 4-wide, 64-byte quantised nodes, leaves of <= 2 triangles, triangles in leaf order -- on
+// the device in a fraction of that, at a lower tree quality (Morton-order splits instead of SAH; DESIGN.md
+// section 7 has the measured node-visit ratio). Opt-in: CRT_HIP_BUILD=device.
+//
+//   1. k_setup      triangle records (v0, e1, e2, geomID, primID), boxes, mesh bounds        (per triangle)
+//   2. k_keys       63-bit Morton code of the box centre in the mesh bounds                   (per triangle)
+//   3. rocPRIM      radix sort of (key, triangle)                                             (library sort)
+//   4. k_karras     binary radix tree over the sorted keys (Karras 2012; lbvh.h)             (per internal node)
+//   5. k_refit      boxes bottom-up, second arriver at a node continues                      (per leaf)
+//   6. k_collapse   level by level: binary subtree -> wide node, children allocated in the next level (BFS order)
+//   7. k_emit       triangles and their vertex UVs in leaf (= sorted) order
+//
+// The result is copied back into the host-side prepared scene, so everything after the build (TLAS,
+// instance records, sharing between the GPUs of a node) is the one code path of crt_core.cpp.
+#include <hip/hip_runtime.h>
+#include <string.h> // rocprim's texture_cache_iterator.hpp calls ::memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bvh_device.h"
+#include "lbvh.h"
+
+namespace crt {
+namespace {
+
+#define BD_CHECK(expr)                                                                                    \
+    do {                                                                                                  \
+        hipError_t err__ = (expr);                                                                        \
+        if (err__ != hipSuccess) {                                                                        \
+            throw std::runtime_error(std::string("device BVH build: ") + #expr + ": " + hipGetErrorString(err__)); \
+        }                                                                                                 \
+    } while (0)
+
+struct Buf {
+    void *p = nullptr;
+    void alloc(size_t n) { BD_CHECK(hipMalloc(&p, n ? n : 16)); }
+    ~Buf()
+    {
+        if (p) {
+            (void)hipFree(p);
+        }
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct GeomDev {
+    uint32_t tri_begin;  // first triangle of this geometry in the mesh-wide numbering
+    uint32_t vert_begin; // first vertex in the concatenated vertex array
+    int32_t uv_begin;    // first float2 in the concatenated uv array, -1: the geometry has no UVs
+    uint32_t pad;
+};
+
+// order-preserving float <-> uint (for atomicMin / atomicMax on bounds)
+__device__ inline uint32_t f2ord(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float ord2f(uint32_t o)
+{
+    const uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms, uint32_t n_geoms, const float *verts,
+                                               const uint32_t *indices, TriRec *recs, Aabb *boxes, uint32_t *bounds)
+{
+    __shared__ uint32_t s_b[6];
+    if (threadIdx.x < 6) {
+        s_b[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+    }
+    __syncthreads();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        uint32_t g_lo = 0, g_hi = n_geoms - 1; // last geometry whose tri_begin <= t
+        while (g_lo < g_hi) {
+            const uint32_t mid = (g_lo + g_hi + 1) / 2;
+            if (geoms[mid].tri_begin <= t) {
+                g_lo = mid;
+            } else {
+                g_hi = mid - 1;
+            }
+        }
+        const GeomDev g = geoms[g_lo];
+        const uint32_t prim = t - g.tri_begin;
+        const uint32_t *ix = indices + 3 * (size_t)t;
+        const float *v0 = verts + 3 * (size_t)(g.vert_begin + ix[0]);
+        const float *v1 = verts + 3 * (size_t)(g.vert_begin + ix[1]);
+        const float *v2 = verts + 3 * (size_t)(g.vert_begin + ix[2]);
+        TriRec r;
+        Aabb b;
+        for (int a = 0; a < 3; ++a) {
+            r.v0[a] = v0[a];
+            r.e1[a] = v0[a] - v1[a];
+            r.e2[a] = v2[a] - v0[a];
+            b.lo[a] = fminf(v0[a], fminf(v1[a], v2[a]));
+            b.hi[a] = fmaxf(v0[a], fmaxf(v1[a], v2[a]));
+        }
+        r.geom = g_lo;
+        r.prim = prim;
+        r.pad = 0;
+        recs[t] = r;
+        boxes[t] = b;
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&s_b[a], f2ord(b.lo[a]));
+            atomicMax(&s_b[3 + a], f2ord(b.hi[a]));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
+    } else if (threadIdx.x < 6) {
+        atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_keys(uint32_t n, const Aabb *boxes, Aabb bounds, uint64_t *keys, uint32_t *idx)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    keys[t] = lbvh_key(boxes[t], bounds);
+    idx[t] = t;
+}
+
+__global__ __launch_bounds__(256) void k_sorted_boxes(uint32_t n, const Aabb *boxes, const uint32_t *idx, Aabb *pbox)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        pbox[t] = boxes[idx[t]];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_karras(uint32_t n, const uint64_t *keys, int32_t *left, int32_t *right, int32_t *lo,
+                                                int32_t *hi, int32_t *parent_of_node, int32_t *parent_of_leaf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) {
+        return;
+    }
+    int32_t l, r;
+    int a, b;
+    lbvh_node(keys, (int)n, (int)i, l, r, a, b);
+    left[i] = l;
+    right[i] = r;
+    lo[i] = a;
+    hi[i] = b;
+    if (l >= 0) {
+        parent_of_node[l] = (int32_t)i;
+    } else {
+        parent_of_leaf[~l] = (int32_t)i;
+    }
+    if (r >= 0) {
+        parent_of_node[r] = (int32_t)i;
+    } else {
+        parent_of_leaf[~r] = (int32_t)i;
+    }
+    if (i == 0) {
+        parent_of_node[0] = -1;
+    }
+}
+
+// One thread per leaf climbs towards the root; at every node the FIRST arriver stops and the second,
+// which then sees both children complete, computes the node's box and continues.
+__global__ __launch_bounds__(256) void k_refit(uint32_t n, const int32_t *left, const int32_t *right, const int32_t *parent_of_node,
+                                               const int32_t *parent_of_leaf, const Aabb *pbox, Aabb *ibox, uint32_t *arrived)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) {
+        return;
+    }
+    int32_t k = parent_of_leaf[p];
+    while (k >= 0) {
+        __threadfence(); // the boxes written below must be visible to whoever arrives second
+        if (atomicAdd(&arrived[k], 1u) == 0u) {
+            return;
+        }
+        __threadfence();
+        const int32_t l = left[k], r = right[k];
+        // (volatile: the sibling's box was written by another CU; the loads must not be served from this CU's L1)
+        const volatile float *pl = reinterpret_cast<const volatile float *>(l >= 0 ? ibox + l : pbox + ~l);
+        const volatile float *pr = reinterpret_cast<const volatile float *>(r >= 0 ? ibox + r : pbox + ~r);
+        Aabb b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = fminf(pl[a], pr[a]);
+            b.hi[a] = fmaxf(pl[3 + a], pr[3 + a]);
+        }
+        ibox[k] = b;
+        k = parent_of_node[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_collapse(LbvhTree t, const int32_t *frontier_in, uint32_t n_in, int32_t *frontier_out,
+                                                  uint32_t *n_out, uint32_t level_base, QNode *nodes, QFrame frame,
+                                                  uint32_t max_leaf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) {
+        return;
+    }
+    const int32_t k = frontier_in[i];
+    int32_t sub[BVH_WIDTH];
+    const int n = lbvh_wide_children(t, k, max_leaf, sub);
+    QNode node;
+    for (int c = 0; c < n; ++c) {
+        const uint32_t count = lbvh_count(t, sub[c]);
+        int32_t ref;
+        if (count <= max_leaf) {
+            ref = lbvh_leaf_ref(sub[c] >= 0 ? (uint32_t)t.lo[sub[c]] : (uint32_t)~sub[c], count);
+        } else {
+            const uint32_t slot = atomicAdd(n_out, 1u);
+            frontier_out[slot] = sub[c];
+            ref = (int32_t)(level_base + n_in + slot);
+        }
+        lbvh_quantise_child(node.child[c], lbvh_box(t, sub[c]), ref, frame);
+    }
+    for (int c = n; c < BVH_WIDTH; ++c) {
+        lbvh_unused_child(node.child[c], node.child[0].ref);
+    }
+    nodes[level_base + i] = node;
+}
+
+__global__ __launch_bounds__(256) void k_emit(uint32_t n, const TriRec *recs, const uint32_t *idx, const GeomDev *geoms,
+                                              const uint32_t *indices, const float *uvs, TriRec *tris, float *tri_uvs)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) {
+        return;
+    }
+    const uint32_t t = idx[p];
+    const TriRec r = recs[t];
+    tris[p] = r;
+    const GeomDev g = geoms[r.geom];
+    float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.uv_begin >= 0) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t vi = indices[3 * (size_t)t + c];
+            out[2 * c] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi)];
+            out[2 * c + 1] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi) + 1];
+        }
+    }
+    for (int c = 0; c < 6; ++c) {
+        tri_uvs[6 * (size_t)p + c] = out[c];
+    }
+}
+
+inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+} // namespace
+
+bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, uint32_t max_leaf, uint32_t max_top_nodes,
+                       DeviceBuiltMesh &out)
+{
+    uint64_t n_tris = 0, n_verts = 0, n_uvs = 0;
+    for (uint32_t g = 0; g < n_geoms; ++g) {
+        n_tris += geoms[g].n_triangles;
+        n_verts += geoms[g].n_vertices;
+        n_uvs += geoms[g].uvs ? geoms[g].n_vertices : 0;
+    }
+    if (n_tris < 4096 || n_tris >= (1ull << 28)) {
+        return false; // small meshes: the host builder takes milliseconds and builds the better tree
+    }
+    BD_CHECK(hipSetDevice(device));
+    hipStream_t s = nullptr; // the legacy default stream: set_scene is not on the frame path
+    const uint32_t n = (uint32_t)n_tris;
+
+    // inputs, straight from the caller's arrays into concatenated device arrays
+    Buf d_verts, d_indices, d_uvs, d_geoms;
+    d_verts.alloc(n_verts * 12);
+    d_indices.alloc(n_tris * 12);
+    d_uvs.alloc(n_uvs * 8);
+    std::vector<GeomDev> gd(n_geoms);
+    {
+        uint64_t t0 = 0, v0 = 0, u0 = 0;
+        for (uint32_t g = 0; g < n_geoms; ++g) {
+            gd[g].tri_begin = (uint32_t)t0;
+            gd[g].vert_begin = (uint32_t)v0;
+            gd[g].uv_begin = geoms[g].uvs ? (int32_t)u0 : -1;
+            gd[g].pad = 0;
+            if (geoms[g].n_vertices) {
+                BD_CHECK(hipMemcpyAsync(d_verts.as<float>() + 3 * v0, geoms[g].vertices, geoms[g].n_vertices * 12, hipMemcpyHostToDevice, s));
+            }
+            if (geoms[g].n_triangles) {
+                BD_CHECK(hipMemcpyAsync(d_indices.as<uint32_t>() + 3 * t0, geoms[g].indices, geoms[g].n_triangles * 12,
+                                        hipMemcpyHostToDevice, s));
+            }
+            if (geoms[g].uvs && geoms[g].n_vertices) {
+                BD_CHECK(hipMemcpyAsync(d_uvs.as<float>() + 2 * u0, geoms[g].uvs, geoms[g].n_vertices * 8, hipMemcpyHostToDevice, s));
+                u0 += geoms[g].n_vertices;
+            }
+            t0 += geoms[g].n_triangles;
+            v0 += geoms[g].n_vertices;
+        }
+        // (a geometry without triangles shares its tri_begin with its successor; k_setup's search returns the LAST
+        // geometry whose tri_begin <= t, which is the one that owns t; trailing empty ones begin past the end)
+    }
+    d_geoms.alloc(n_geoms * sizeof(GeomDev));
+    BD_CHECK(hipMemcpyAsync(d_geoms.p, gd.data(), n_geoms * sizeof(GeomDev), hipMemcpyHostToDevice, s));
+
+    Buf d_recs, d_boxes, d_bounds;
+    d_recs.alloc((size_t)n * sizeof(TriRec));
+    d_boxes.alloc((size_t)n * sizeof(Aabb));
+    d_bounds.alloc(6 * 4);
+    {
+        const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        BD_CHECK(hipMemcpyAsync(d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    }
+    k_setup<<<grid_for(n), 256, 0, s>>>(n, d_geoms.as<GeomDev>(), n_geoms, d_verts.as<float>(), d_indices.as<uint32_t>(),
+                                        d_recs.as<TriRec>(), d_boxes.as<Aabb>(), d_bounds.as<uint32_t>());
+    uint32_t hb[6];
+    BD_CHECK(hipMemcpy(hb, d_bounds.p, sizeof(hb), hipMemcpyDeviceToHost));
+    Aabb bounds;
+    for (int a = 0; a < 3; ++a) {
+        bounds.lo[a] = ord2f(hb[a]);
+        bounds.hi[a] = ord2f(hb[3 + a]);
+    }
+    out.bounds = bounds;
+    const QFrame frame = make_frame(bounds);
+
+    // Morton keys, sort
+    Buf d_keys, d_keys2, d_idx, d_idx2, d_tmp;
+    d_keys.alloc((size_t)n * 8);
+    d_keys2.alloc((size_t)n * 8);
+    d_idx.alloc((size_t)n * 4);
+    d_idx2.alloc((size_t)n * 4);
+    k_keys<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), bounds, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    BD_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                       d_idx2.as<uint32_t>(), n, 0, 63, s));
+    d_tmp.alloc(tmp_bytes);
+    BD_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                       d_idx2.as<uint32_t>(), n, 0, 63, s));
+    const uint64_t *keys = d_keys2.as<uint64_t>();
+    const uint32_t *idx = d_idx2.as<uint32_t>();
+
+    // binary radix tree + boxes
+    Buf d_pbox, d_ibox, d_left, d_right, d_lo, d_hi, d_pn, d_pl, d_arrived;
+    d_pbox.alloc((size_t)n * sizeof(Aabb));
+    d_ibox.alloc((size_t)n * sizeof(Aabb));
+    for (Buf *b : {&d_left, &d_right, &d_lo, &d_hi, &d_pn, &d_pl, &d_arrived}) {
+        b->alloc((size_t)n * 4);
+    }
+    BD_CHECK(hipMemsetAsync(d_arrived.p, 0, (size_t)n * 4, s));
+    k_sorted_boxes<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), idx, d_pbox.as<Aabb>());
+    k_karras<<<grid_for(n), 256, 0, s>>>(n, keys, d_left.as<int32_t>(), d_right.as<int32_t>(), d_lo.as<int32_t>(), d_hi.as<int32_t>(),
+                                         d_pn.as<int32_t>(), d_pl.as<int32_t>());
+    k_refit<<<grid_for(n), 256, 0, s>>>(n, d_left.as<int32_t>(), d_right.as<int32_t>(), d_pn.as<int32_t>(), d_pl.as<int32_t>(),
+                                        d_pbox.as<Aabb>(), d_ibox.as<Aabb>(), d_arrived.as<uint32_t>());
+
+    // collapse, level by level; node indices come out in BFS order
+    Buf d_nodes, d_front_a, d_front_b, d_count;
+    d_nodes.alloc((size_t)n * sizeof(QNode));
+    d_front_a.alloc((size_t)n * 4);
+    d_front_b.alloc((size_t)n * 4);
+    d_count.alloc(4);
+    const LbvhTree tree{d_left.as<int32_t>(), d_right.as<int32_t>(), d_lo.as<int32_t>(), d_hi.as<int32_t>(), d_ibox.as<Aabb>(),
+                        d_pbox.as<Aabb>()};
+    const int32_t root = 0;
+    BD_CHECK(hipMemcpyAsync(d_front_a.p, &root, 4, hipMemcpyHostToDevice, s));
+    uint32_t n_in = 1, level_base = 0, depth = 0;
+    int32_t *fin = d_front_a.as<int32_t>(), *fout = d_front_b.as<int32_t>();
+    while (n_in > 0) {
+        BD_CHECK(hipMemsetAsync(d_count.p, 0, 4, s));
+        k_collapse<<<grid_for(n_in), 256, 0, s>>>(tree, fin, n_in, fout, d_count.as<uint32_t>(), level_base, d_nodes.as<QNode>(), frame,
+                                                  max_leaf);
+        uint32_t n_next = 0;
+        BD_CHECK(hipMemcpy(&n_next, d_count.p, 4, hipMemcpyDeviceToHost));
+        level_base += n_in;
+        n_in = n_next;
+        std::swap(fin, fout);
+        ++depth;
+        if (depth > 4096) {
+            throw std::runtime_error("device BVH build: collapse does not terminate");
+        }
+    }
+    const uint32_t n_nodes = level_base;
+
+    // triangles + vertex UVs in leaf order
+    Buf d_tris, d_tuv;
+    d_tris.alloc((size_t)n * sizeof(TriRec));
+    d_tuv.alloc((size_t)n * 6 * 4);
+    k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<TriRec>(), idx, d_geoms.as<GeomDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
+                                       d_tris.as<TriRec>(), d_tuv.as<float>());
+    BD_CHECK(hipGetLastError());
+    out.nodes.resize(n_nodes);
+    out.tris.resize(n);
+    out.tri_uvs.resize((size_t)n * 6);
+    BD_CHECK(hipMemcpy(out.nodes.data(), d_nodes.p, (size_t)n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
+    BD_CHECK(hipMemcpy(out.tris.data(), d_tris.p, (size_t)n * sizeof(TriRec), hipMemcpyDeviceToHost));
+    BD_CHECK(hipMemcpy(out.tri_uvs.data(), d_tuv.p, (size_t)n * 6 * 4, hipMemcpyDeviceToHost));
+    out.max_depth = depth;
+    out.n_top = std::min(n_nodes, max_top_nodes);
+    out.frame = frame;
+    return true;
+}
+
+} // namespace crt

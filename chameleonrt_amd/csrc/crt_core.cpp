@@ -23,6 +23,7 @@
 
 #include "../../include/crt_hip.h"
 #include "bvh_builder.h"
+#include "bvh_device.h"
 #include "crt_types.h"
 #include "kernels.h"
 #include "wavefront.h"
@@ -608,7 +609,9 @@ struct crt_hip_prepared_scene {
 
 namespace {
 
-void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads)
+// build_device >= 0: meshes large enough to be worth it get their BLAS from the device builder
+// (bvh_device.hip) on that HIP device; -1: the host SAH builder for everything.
+void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads, int build_device = -1)
 {
         const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
         auto t_phase = std::chrono::high_resolution_clock::now();
@@ -635,9 +638,33 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         std::vector<uint32_t> blas_top(s->n_meshes);
         // node 0.. are reserved for the TLAS when two_level so that the staged top levels are the TLAS's
         std::vector<BuiltBvh> built(s->n_meshes);
+        std::vector<std::vector<QNode>> built_q(s->n_meshes); // device-built meshes: already quantised
         uint32_t blas_depth = 0, tlas_depth = 0; // levels of the wide trees
+        // leaves of at most 2 triangles: with 4-wide nodes a leaf is one of four boxes tested per node
+        // fetch, so small leaves are cheap to reach, and every triangle test saved is 3 lane requests
+        static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
+        const char *builder_env = std::getenv("CRT_BVH_BUILDER"); // "lbvh": the device algorithm, run on the host
+        const bool host_lbvh = builder_env && std::strcmp(builder_env, "lbvh") == 0;
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
             const crt_mesh_desc &md = s->meshes[m];
+            if (build_device >= 0) {
+                DeviceBuiltMesh db;
+                if (device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries, (uint32_t)max_leaf,
+                                      two_level ? 0 : MAX_TOP_NODES_HOST, db)) {
+                    const size_t tri_base = tris.size();
+                    tris.insert(tris.end(), db.tris.begin(), db.tris.end());
+                    tri_uvs.insert(tri_uvs.end(), db.tri_uvs.begin(), db.tri_uvs.end());
+                    built_q[m] = std::move(db.nodes);
+                    built[m].n_top = db.n_top;
+                    built[m].max_depth = db.max_depth;
+                    built[m].bounds = db.bounds;
+                    blas_depth = std::max(blas_depth, db.max_depth);
+                    blas_bounds[m] = db.bounds;
+                    blas_frame[m] = db.frame;
+                    blas_root[m] = (int32_t)tri_base;
+                    continue;
+                }
+            }
             std::vector<TriRec> recs;
             std::vector<Aabb> boxes;
             {
@@ -673,11 +700,9 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             if (recs.empty()) {
                 throw std::runtime_error("mesh without triangles");
             }
-            // leaves of at most 2 triangles: with 4-wide nodes a leaf is one of four boxes tested per node
-            // fetch, so small leaves are cheap to reach, and every triangle test saved is 3 lane requests
-            static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
-            built[m] = build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, two_level ? 0 : MAX_TOP_NODES_HOST,
-                                 n_threads);
+            built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
+                                 : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
+                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
             blas_depth = std::max(blas_depth, built[m].max_depth);
             // triangles in leaf order
             const size_t tri_base = tris.size();
@@ -761,14 +786,20 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
             const int32_t node_base = (int32_t)nodes.size();
             const uint32_t tri_base = (uint32_t)blas_root[m];
+            auto rebase = [&](int32_t c) -> int32_t {
+                if (c >= 0) {
+                    return c + node_base;
+                }
+                const uint32_t x = ~(uint32_t)c;
+                return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
+            };
+            for (QNode q : built_q[m]) { // device-built: quantised already, references local to the mesh
+                for (int k = 0; k < BVH_WIDTH; ++k) {
+                    q.child[k].ref = rebase(q.child[k].ref);
+                }
+                nodes.push_back(q);
+            }
             for (BvhNode nd : built[m].nodes) {
-                auto rebase = [&](int32_t c) -> int32_t {
-                    if (c >= 0) {
-                        return c + node_base;
-                    }
-                    const uint32_t x = ~(uint32_t)c;
-                    return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
-                };
                 for (int k = 0; k < BVH_WIDTH; ++k) {
                     if (nd.c[k] != EMPTY_CHILD) {
                         nd.c[k] = rebase(nd.c[k]);
@@ -779,6 +810,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             blas_root[m] = node_base;
             blas_top[m] = built[m].n_top;
             built[m] = BuiltBvh();
+            built_q[m] = std::vector<QNode>();
         }
         // a ray's stack holds at most BVH_WIDTH-1 pending siblings per level of the path it is on,
         // plus the instance-exit sentinel. The LDS part of the stack is fixed; the HBM slab behind it is
@@ -927,6 +959,21 @@ template <typename T> bool prep_get(FILE *f, std::vector<T> &v, uint64_t n)
 
 extern "C" {
 
+crt_hip_prepared_scene *crt_hip_prepare_scene_on(const crt_scene_desc *scene, int n_threads, int build_device)
+{
+    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
+    try {
+        if (build_device >= crt_hip_device_count()) {
+            throw std::runtime_error("prepare_scene: no such HIP device to build on");
+        }
+        prepare_scene(scene, ps.get(), n_threads > 0 ? n_threads : host_threads(), build_device);
+    } catch (const std::exception &e) {
+        g_create_error = e.what();
+        return nullptr;
+    }
+    return ps.release();
+}
+
 crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads)
 {
     std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
@@ -957,7 +1004,8 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 {
     return guarded(ctx, [&]() -> int {
         crt_hip_prepared_scene ps;
-        prepare_scene(s, &ps, host_threads());
+        const char *where = std::getenv("CRT_HIP_BUILD"); // "device": BLAS of large meshes built on this context's GPU
+        prepare_scene(s, &ps, host_threads(), where && std::strcmp(where, "device") == 0 ? ctx->device : -1);
         const auto t0 = std::chrono::high_resolution_clock::now();
         upload_scene(ctx, ps);
         if (std::getenv("CRT_HIP_DEBUG")) {
@@ -1294,6 +1342,20 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
 }
 
 const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx) { return ctx ? ctx->img.data() : nullptr; }
+
+int crt_hip_device_framebuffer(crt_hip_ctx *ctx, void **device_ptr, size_t *pitch_bytes)
+{
+    return guarded(ctx, [&]() -> int {
+        if (ctx->width == 0 || !device_ptr) {
+            return fail(ctx, CRT_HIP_ESTATE, "device_framebuffer before initialize");
+        }
+        *device_ptr = ctx->d_img.ptr;
+        if (pitch_bytes) {
+            *pitch_bytes = (size_t)ctx->width * sizeof(uint32_t);
+        }
+        return CRT_HIP_OK;
+    });
+}
 
 int crt_hip_read_accum(crt_hip_ctx *ctx, float *rgb)
 {

@@ -26,6 +26,8 @@ PASSES = {
     "write": ["WRITE_SIZE"],
     "sq": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
            "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+    # the per-CU vector-memory front end (texture addresser): busy cycles summed over the 256 CUs, and the L2's hit rate
+    "mem": ["TA_TA_BUSY_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"],
 }
 
 
@@ -56,7 +58,7 @@ def read_db(path):
     return out
 
 
-def measure(prepared_path, meta_path, frames=3, passes=("fetch", "write", "sq"), timeout=240, keep_dir=None):
+def measure(prepared_path, meta_path, frames=3, passes=("fetch", "write", "sq", "mem"), timeout=240, keep_dir=None):
     """Returns {pass: {kernel: {...}}}; a pass that fails or times out is reported as {"error": ...}."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     res = {}

@@ -74,6 +74,12 @@ class RenderHIP:
         p = self._lib.crt_hip_framebuffer(self._ctx)
         return np.ctypeslib.as_array(p, shape=(self.height, self.width))
 
+    def device_framebuffer(self):
+        """(device pointer, pitch in bytes) of the row-major RGBA8 image in HBM: the display-interop hand-off."""
+        p, pitch = C.c_void_p(), C.c_size_t()
+        core.check(self._ctx, self._lib.crt_hip_device_framebuffer(self._ctx, C.byref(p), C.byref(pitch)), "device_framebuffer")
+        return p.value, pitch.value
+
     def frame_id(self) -> int:
         return self._lib.crt_hip_frame_id(self._ctx)
 
@@ -146,11 +152,12 @@ class PreparedScene:
     """Host half of set_scene (BVH build, texture linearisation), done once and uploaded to every
     GPU of the node: crt_hip_prepare_scene / save / load (include/crt_hip.h)."""
 
-    def __init__(self, scene: Scene = None, path: str = None, n_threads: int = 0):
+    def __init__(self, scene: Scene = None, path: str = None, n_threads: int = 0, build_device: int = -1):
+        """build_device >= 0: the BLAS of large meshes is built on that GPU (linear BVH) instead of by the host SAH builder."""
         self._lib = core.load()
         if scene is not None:
             packed = PackedScene(scene)
-            self.handle = self._lib.crt_hip_prepare_scene(packed.ptr(), n_threads)
+            self.handle = self._lib.crt_hip_prepare_scene_on(packed.ptr(), n_threads, build_device)
             self.samples_per_pixel = scene.samples_per_pixel
         else:
             self.handle = self._lib.crt_hip_load_prepared_scene(path.encode())

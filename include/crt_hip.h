@@ -169,6 +169,12 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *scene);
  * prepares and saves, the other ranks load -- same build, same machine, not an exchange format. */
 typedef struct crt_hip_prepared_scene crt_hip_prepared_scene;
 crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads);
+/* The same with the BLAS of every large mesh built ON HIP device `build_device` (linear BVH --
+ * Morton sort, binary radix tree, bottom-up boxes, collapse to the same 4-wide nodes; bvh_device.hip)
+ * instead of by the host SAH builder: set_scene of a 10 M-triangle scene in a fraction of the time, at
+ * a lower tree quality. build_device < 0: host build. crt_hip_set_scene takes this
+ * path when CRT_HIP_BUILD=device is set. */
+crt_hip_prepared_scene *crt_hip_prepare_scene_on(const crt_scene_desc *scene, int n_threads, int build_device);
 void crt_hip_free_prepared_scene(crt_hip_prepared_scene *prepared);
 int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *prepared);
 int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *prepared, const char *path);
@@ -193,6 +199,15 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir[3], con
 
 /* W*H RGBA8 (8-bit sRGB, A=255), row 0 = top: RenderBackend::img. */
 const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx);
+
+/* Display interop (the reference's GLNativeRenderer path, util/display/gldisplay.h:35-37,
+ * backends/optix/render_optix.cpp:104-121,410-426): the row-major RGBA8 image as it sits in HBM after
+ * crt_hip_render (world == 1) or crt_hip_assemble_tiles (world > 1), so that a display can copy it
+ * device-to-device into a registered GL texture (hipGraphicsGLRegisterImage + hipMemcpy2DToArray) and
+ * call render() with readback = 0 -- no host round trip. The pointer stays valid until the next
+ * crt_hip_initialize; the data is complete once the context's stream has been synchronised (render and
+ * assemble_tiles return synchronised). */
+int crt_hip_device_framebuffer(crt_hip_ctx *ctx, void **device_ptr, size_t *pitch_bytes);
 
 /* Parity/diagnostic reads (synchronise the stream). Row-major W*H. */
 int crt_hip_read_accum(crt_hip_ctx *ctx, float *rgb /* W*H*3 */);

@@ -104,3 +104,24 @@ def test_overlapped_launch_schedule_is_bit_identical(hip_lib, monkeypatch):
     a, b = out
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_device_framebuffer_is_the_image_without_a_host_round_trip(hip_lib):
+    """Display interop hand-off: with readback = False nothing reaches the host image, and the
+    device pointer holds exactly what readback = True would have delivered."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    sc = scenes.cornell(spp=2)
+    e, d, u, fovy = camera_of(sc)
+    r = RenderHIP()
+    r.initialize(200, 136)
+    r.set_scene(sc)
+    r.render(e, d, u, fovy, True, False)
+    assert not r.img.any(), "readback = False must not touch the host image"
+    ptr, pitch = r.device_framebuffer()
+    assert pitch == 200 * 4
+    dev = np.zeros((136, 200), np.uint32)
+    assert hip.hipMemcpy(dev.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(dev.nbytes), 2) == 0  # device to host
+    r.render(e, d, u, fovy, True, True)  # the same frame again, read back the reference's way
+    assert np.array_equal(dev, r.img) and (dev.view(np.uint8).reshape(136, 200, 4)[..., 3] == 255).all()
+    r.close()
