@@ -623,36 +623,46 @@ BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max
     if (n < 3) { // degenerate sizes: the SAH builder's single-node forms
         return build_bvh(boxes, n, max_leaf, 0, 0, false, max_top_nodes, 1);
     }
-    std::vector<std::pair<uint64_t, uint32_t>> ki(n);
-    for (size_t i = 0; i < n; ++i) {
-        ki[i] = {lbvh_key(boxes[i], out.bounds), (uint32_t)i};
-    }
-    std::stable_sort(ki.begin(), ki.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     std::vector<uint64_t> keys(n);
     std::vector<Aabb> pbox(n), ibox(n);
-    out.order.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        keys[i] = ki[i].first;
-        out.order[i] = ki[i].second;
-        pbox[i] = boxes[ki[i].second];
-    }
     std::vector<int32_t> left(n), right(n), lo(n), hi(n);
-    for (size_t i = 0; i + 1 < n; ++i) {
-        int a, b;
-        lbvh_node(keys.data(), (int)n, (int)i, left[i], right[i], a, b);
-        lo[i] = a;
-        hi[i] = b;
-    }
-    // boxes bottom-up: a node covers a narrower key range than its parent, so descending range size works
-    std::vector<uint32_t> by_size(n - 1);
-    for (uint32_t i = 0; i + 1 < n; ++i) {
-        by_size[i] = i;
-    }
-    std::sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return hi[a] - lo[a] < hi[b] - lo[b]; });
-    for (uint32_t k : by_size) {
-        box_reset(ibox[k]);
-        box_grow(ibox[k], left[k] >= 0 ? ibox[left[k]] : pbox[~left[k]]);
-        box_grow(ibox[k], right[k] >= 0 ? ibox[right[k]] : pbox[~right[k]]);
+    out.order.resize(n);
+    // the binary tree with either key normalisation; returns the summed half-area of its internal nodes
+    auto build_binary = [&](int mode) -> double {
+        std::vector<std::pair<uint64_t, uint32_t>> ki(n);
+        for (size_t i = 0; i < n; ++i) {
+            ki[i] = {lbvh_key(boxes[i], out.bounds, mode), (uint32_t)i};
+        }
+        std::stable_sort(ki.begin(), ki.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (size_t i = 0; i < n; ++i) {
+            keys[i] = ki[i].first;
+            out.order[i] = ki[i].second;
+            pbox[i] = boxes[ki[i].second];
+        }
+        for (size_t i = 0; i + 1 < n; ++i) {
+            int a, b;
+            lbvh_node(keys.data(), (int)n, (int)i, left[i], right[i], a, b);
+            lo[i] = a;
+            hi[i] = b;
+        }
+        // boxes bottom-up: a node covers a narrower key range than its parent, so ascending range size works
+        std::vector<uint32_t> by_size(n - 1);
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            by_size[i] = i;
+        }
+        std::sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return hi[a] - lo[a] < hi[b] - lo[b]; });
+        double cost = 0.0;
+        for (uint32_t k : by_size) {
+            box_reset(ibox[k]);
+            box_grow(ibox[k], left[k] >= 0 ? ibox[left[k]] : pbox[~left[k]]);
+            box_grow(ibox[k], right[k] >= 0 ? ibox[right[k]] : pbox[~right[k]]);
+            cost += (double)lbvh_half_area(ibox[k]);
+        }
+        return cost;
+    };
+    const double cost0 = build_binary(0), cost1 = build_binary(1);
+    if (cost0 <= cost1) {
+        build_binary(0);
     }
     const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
     std::vector<int32_t> frontier{0}, next;

@@ -126,14 +126,32 @@ __global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms,
     }
 }
 
-__global__ __launch_bounds__(256) void k_keys(uint32_t n, const Aabb *boxes, Aabb bounds, uint64_t *keys, uint32_t *idx)
+__global__ __launch_bounds__(256) void k_keys(uint32_t n, const Aabb *boxes, Aabb bounds, int mode, uint64_t *keys, uint32_t *idx)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) {
         return;
     }
-    keys[t] = lbvh_key(boxes[t], bounds);
+    keys[t] = lbvh_key(boxes[t], bounds, mode);
     idx[t] = t;
+}
+
+// summed half-area of the internal nodes (the SAH estimate of node visits), one partial sum per block
+__global__ __launch_bounds__(256) void k_cost(uint32_t n_internal, const Aabb *ibox, double *partial)
+{
+    __shared__ double s_sum[256];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    s_sum[threadIdx.x] = i < n_internal ? (double)lbvh_half_area(ibox[i]) : 0.0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s_sum[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sorted_boxes(uint32_t n, const Aabb *boxes, const uint32_t *idx, Aabb *pbox)
@@ -330,35 +348,55 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     out.bounds = bounds;
     const QFrame frame = make_frame(bounds);
 
-    // Morton keys, sort
-    Buf d_keys, d_keys2, d_idx, d_idx2, d_tmp;
-    d_keys.alloc((size_t)n * 8);
-    d_keys2.alloc((size_t)n * 8);
-    d_idx.alloc((size_t)n * 4);
-    d_idx2.alloc((size_t)n * 4);
-    k_keys<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), bounds, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
-    size_t tmp_bytes = 0;
-    BD_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                       d_idx2.as<uint32_t>(), n, 0, 63, s));
-    d_tmp.alloc(tmp_bytes);
-    BD_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                       d_idx2.as<uint32_t>(), n, 0, 63, s));
-    const uint64_t *keys = d_keys2.as<uint64_t>();
-    const uint32_t *idx = d_idx2.as<uint32_t>();
-
-    // binary radix tree + boxes
-    Buf d_pbox, d_ibox, d_left, d_right, d_lo, d_hi, d_pn, d_pl, d_arrived;
-    d_pbox.alloc((size_t)n * sizeof(Aabb));
-    d_ibox.alloc((size_t)n * sizeof(Aabb));
-    for (Buf *b : {&d_left, &d_right, &d_lo, &d_hi, &d_pn, &d_pl, &d_arrived}) {
+    // The binary radix tree, built with both key normalisations (lbvh.h); the one with the smaller summed
+    // surface area of its internal nodes is kept.
+    struct TreeBufs {
+        Buf keys, idx, pbox, ibox, left, right, lo, hi;
+    };
+    Buf d_keys_in, d_idx_in, d_tmp, d_pn, d_pl, d_arrived, d_partial;
+    d_keys_in.alloc((size_t)n * 8);
+    d_idx_in.alloc((size_t)n * 4);
+    for (Buf *b : {&d_pn, &d_pl, &d_arrived}) {
         b->alloc((size_t)n * 4);
     }
-    BD_CHECK(hipMemsetAsync(d_arrived.p, 0, (size_t)n * 4, s));
-    k_sorted_boxes<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), idx, d_pbox.as<Aabb>());
-    k_karras<<<grid_for(n), 256, 0, s>>>(n, keys, d_left.as<int32_t>(), d_right.as<int32_t>(), d_lo.as<int32_t>(), d_hi.as<int32_t>(),
-                                         d_pn.as<int32_t>(), d_pl.as<int32_t>());
-    k_refit<<<grid_for(n), 256, 0, s>>>(n, d_left.as<int32_t>(), d_right.as<int32_t>(), d_pn.as<int32_t>(), d_pl.as<int32_t>(),
-                                        d_pbox.as<Aabb>(), d_ibox.as<Aabb>(), d_arrived.as<uint32_t>());
+    const unsigned cost_blocks = grid_for(n - 1);
+    d_partial.alloc((size_t)cost_blocks * 8);
+    size_t tmp_bytes = 0;
+    TreeBufs trees[LBVH_KEY_MODES];
+    double cost[LBVH_KEY_MODES];
+    for (int mode = 0; mode < LBVH_KEY_MODES; ++mode) {
+        TreeBufs &tb = trees[mode];
+        tb.keys.alloc((size_t)n * 8);
+        tb.idx.alloc((size_t)n * 4);
+        tb.pbox.alloc((size_t)n * sizeof(Aabb));
+        tb.ibox.alloc((size_t)n * sizeof(Aabb));
+        for (Buf *b : {&tb.left, &tb.right, &tb.lo, &tb.hi}) {
+            b->alloc((size_t)n * 4);
+        }
+        k_keys<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), bounds, mode, d_keys_in.as<uint64_t>(), d_idx_in.as<uint32_t>());
+        if (!d_tmp.p) {
+            BD_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in.as<uint64_t>(), tb.keys.as<uint64_t>(),
+                                               d_idx_in.as<uint32_t>(), tb.idx.as<uint32_t>(), n, 0, 63, s));
+            d_tmp.alloc(tmp_bytes);
+        }
+        BD_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys_in.as<uint64_t>(), tb.keys.as<uint64_t>(), d_idx_in.as<uint32_t>(),
+                                           tb.idx.as<uint32_t>(), n, 0, 63, s));
+        BD_CHECK(hipMemsetAsync(d_arrived.p, 0, (size_t)n * 4, s));
+        k_sorted_boxes<<<grid_for(n), 256, 0, s>>>(n, d_boxes.as<Aabb>(), tb.idx.as<uint32_t>(), tb.pbox.as<Aabb>());
+        k_karras<<<grid_for(n), 256, 0, s>>>(n, tb.keys.as<uint64_t>(), tb.left.as<int32_t>(), tb.right.as<int32_t>(), tb.lo.as<int32_t>(),
+                                             tb.hi.as<int32_t>(), d_pn.as<int32_t>(), d_pl.as<int32_t>());
+        k_refit<<<grid_for(n), 256, 0, s>>>(n, tb.left.as<int32_t>(), tb.right.as<int32_t>(), d_pn.as<int32_t>(), d_pl.as<int32_t>(),
+                                            tb.pbox.as<Aabb>(), tb.ibox.as<Aabb>(), d_arrived.as<uint32_t>());
+        k_cost<<<cost_blocks, 256, 0, s>>>(n - 1, tb.ibox.as<Aabb>(), d_partial.as<double>());
+        std::vector<double> partial(cost_blocks);
+        BD_CHECK(hipMemcpy(partial.data(), d_partial.p, (size_t)cost_blocks * 8, hipMemcpyDeviceToHost));
+        cost[mode] = 0.0;
+        for (double v : partial) {
+            cost[mode] += v;
+        }
+    }
+    const TreeBufs &best = cost[0] <= cost[1] ? trees[0] : trees[1];
+    const uint32_t *idx = best.idx.as<uint32_t>();
 
     // collapse, level by level; node indices come out in BFS order
     Buf d_nodes, d_front_a, d_front_b, d_count;
@@ -366,8 +404,8 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     d_front_a.alloc((size_t)n * 4);
     d_front_b.alloc((size_t)n * 4);
     d_count.alloc(4);
-    const LbvhTree tree{d_left.as<int32_t>(), d_right.as<int32_t>(), d_lo.as<int32_t>(), d_hi.as<int32_t>(), d_ibox.as<Aabb>(),
-                        d_pbox.as<Aabb>()};
+    const LbvhTree tree{best.left.as<int32_t>(), best.right.as<int32_t>(), best.lo.as<int32_t>(), best.hi.as<int32_t>(),
+                        best.ibox.as<Aabb>(), best.pbox.as<Aabb>()};
     const int32_t root = 0;
     BD_CHECK(hipMemcpyAsync(d_front_a.p, &root, 4, hipMemcpyHostToDevice, s));
     uint32_t n_in = 1, level_base = 0, depth = 0;

@@ -11,6 +11,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -850,27 +851,49 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             const float x = srgb_to_linear(v / 255.f);
             lut[v] = (uint8_t)std::min(std::max(x * 255.f, 0.f), 255.f);
         }
-        for (uint32_t t = 0; t < s->n_textures; ++t) {
-            const crt_image_desc &im = s->textures[t];
-            texels.resize((texels.size() + 15) / 16 * 16);
-            TexRec r;
-            std::memset(&r, 0, sizeof(r));
-            r.width = im.width;
-            r.height = im.height;
-            r.channels = im.channels;
-            r.offset = texels.size();
-            const size_t npx = (size_t)im.width * im.height;
-            texels.insert(texels.end(), im.data, im.data + npx * im.channels);
-            if (im.color_space == CRT_COLORSPACE_SRGB) {
-                uint8_t *p = texels.data() + r.offset;
-                const int convert_channels = std::min(3, im.channels);
-                for (size_t px = 0; px < npx; ++px) {
-                    for (int c = 0; c < convert_channels; ++c) {
-                        p[px * im.channels + c] = lut[p[px * im.channels + c]];
+        // lay the textures out first, then copy + linearise them in parallel (1 GB of texels on a San-Miguel-class
+        // scene: 0.35 s on one core, and the only second-scale host phase left once the BVH comes from the device)
+        {
+            size_t total = 0;
+            for (uint32_t t = 0; t < s->n_textures; ++t) {
+                const crt_image_desc &im = s->textures[t];
+                total = (total + 15) / 16 * 16;
+                TexRec r;
+                std::memset(&r, 0, sizeof(r));
+                r.width = im.width;
+                r.height = im.height;
+                r.channels = im.channels;
+                r.offset = total;
+                tex[t] = r;
+                total += (size_t)im.width * im.height * im.channels;
+            }
+            texels.assign(total, 0);
+            std::atomic<uint32_t> next_tex{0};
+            auto work = [&]() {
+                for (uint32_t t = next_tex.fetch_add(1); t < s->n_textures; t = next_tex.fetch_add(1)) {
+                    const crt_image_desc &im = s->textures[t];
+                    const size_t npx = (size_t)im.width * im.height;
+                    uint8_t *p = texels.data() + tex[t].offset;
+                    std::memcpy(p, im.data, npx * im.channels);
+                    if (im.color_space == CRT_COLORSPACE_SRGB) {
+                        const int convert_channels = std::min(3, im.channels);
+                        for (size_t px = 0; px < npx; ++px) {
+                            for (int c = 0; c < convert_channels; ++c) {
+                                p[px * im.channels + c] = lut[p[px * im.channels + c]];
+                            }
+                        }
                     }
                 }
+            };
+            std::vector<std::thread> pool;
+            const int n_workers = std::max(1, std::min<int>(n_threads, (int)s->n_textures));
+            for (int w = 1; w < n_workers; ++w) {
+                pool.emplace_back(work);
             }
-            tex[t] = r;
+            work();
+            for (std::thread &th : pool) {
+                th.join();
+            }
         }
         std::vector<float> &materials = ps->materials;
         materials.assign((size_t)s->n_materials * 16, 0.f);

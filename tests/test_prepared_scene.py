@@ -120,3 +120,25 @@ def test_malformed_scenes_are_refused_not_crashed():
     for m in (null_instances, null_materials, null_lights, null_vertices, null_indices, null_material_ids,
               wrapped_mesh_range, bad_instance):
         refused(m)
+
+
+@pytest.mark.parametrize("name", ["grove_two_level", "sponza_small", "rungholt_small"])
+def test_linear_bvh_build_on_the_host(name, oracle, monkeypatch):
+    """The device builder's algorithm (lbvh.h: Morton keys with two normalisations, Karras' radix tree,
+    bottom-up boxes, area-greedy collapse to 4-wide nodes) run serially on the host: a correct tree
+    (walk == brute force) of bounded extra cost against the SAH tree."""
+    sc = SCENES[name]()
+    sah = PreparedScene(sc).bvh()
+    monkeypatch.setenv("CRT_BVH_BUILDER", "lbvh")
+    lin = PreparedScene(sc).bvh()
+    assert lin["tris"].shape == sah["tris"].shape
+    org, dirs = probe_rays(sc, 6000, seed=23)
+    c = oracle.OracleScene(sc).trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    w = oracle.walk_product_bvh(lin, org, dirs, 0.0, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w[k], c[k]), k
+    hit = c["inst"] >= 0
+    assert np.array_equal(w["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    assert w["max_stack"] <= lin["stack_need"]
+    w_sah = oracle.walk_product_bvh(sah, org, dirs, 0.0, 1e20, closest=True)
+    assert w["nodes"] <= 1.5 * w_sah["nodes"], "linear BVH much worse than expected against SAH"
