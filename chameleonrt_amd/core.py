@@ -116,6 +116,7 @@ def load():
     L.crt_hip_prepared_scene_set_spp.argtypes = [vp, C.c_uint32]
     L.crt_hip_prepared_scene_set_spp.restype = C.c_int
     L.crt_hip_lds_stack_entries.restype = C.c_uint32
+    L.crt_hip_lds_stack_entries.argtypes = [C.c_int]
     for fn in ("crt_hip_set_stream", "crt_hip_set_partition", "crt_hip_initialize", "crt_hip_set_scene",
                "crt_hip_render", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_tile_buffer",
                "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",

@@ -948,7 +948,8 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     sv.n_instances = ps.n_instances;
     // HBM part of the per-lane traversal stack: what the deepest path can need beyond the LDS part,
     // [wave of the persistent grid][depth][lane]
-    sv.spill_depth = std::max<uint32_t>(8u, ps.stack_need > traversal_lds_stack() ? ps.stack_need - traversal_lds_stack() : 0u);
+    const uint32_t lds_stack = traversal_lds_stack(ps.two_level != 0);
+    sv.spill_depth = std::max<uint32_t>(8u, ps.stack_need > lds_stack ? ps.stack_need - lds_stack : 0u);
     sv.spill_stride = traversal_grid_threads(ctx->n_cus);
     const size_t spill_words = (size_t)sv.spill_stride * sv.spill_depth;
     ctx->d_spill.alloc((ctx->overlap ? 2 : 1) * spill_words * sizeof(int32_t));
@@ -1103,7 +1104,7 @@ int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *ps, uint32_t samples_
 }
 
 int crt_hip_child_order(void) { return traversal_child_order(); }
-uint32_t crt_hip_lds_stack_entries(void) { return traversal_lds_stack(); }
+uint32_t crt_hip_lds_stack_entries(int two_level) { return traversal_lds_stack(two_level != 0); }
 
 int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *path)
 {
@@ -1638,7 +1639,7 @@ int crt_hip_bvh_layout(crt_hip_ctx *ctx, int32_t *root, uint32_t *n_top_nodes, u
             *stack_need = ctx->stack_need;
         }
         if (lds_stack) {
-            *lds_stack = traversal_lds_stack();
+            *lds_stack = traversal_lds_stack(ctx->sv.two_level != 0);
         }
         if (child_order) {
             *child_order = traversal_child_order();

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
 template <bool TWO_LEVEL> struct TraceLds {
     QNode top[MAX_TOP_NODES + 1];
-    int32_t stack[LDS_STACK][TRACE_BLOCK];
+    int32_t stack[lds_stack_of(TWO_LEVEL)][TRACE_BLOCK];
     // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
     float cold[TWO_LEVEL ? 10 : 1][TRACE_BLOCK];
 };
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
 {
     __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack st;
+    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
 {
     __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack st;
+    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
 {
     __shared__ TraceLds<TWO_LEVEL> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack st;
+    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -852,7 +852,7 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 
 // ---- launchers ---------------------------------------------------------------------------------
 uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
-uint32_t traversal_lds_stack() { return (uint32_t)LDS_STACK; }
+uint32_t traversal_lds_stack(bool two_level) { return (uint32_t)lds_stack_of(two_level); }
 int traversal_child_order() { return CRT_CHILD_ORDER; }
 
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }

@@ -18,10 +18,17 @@
 
 namespace crt {
 
+// Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
+// vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
+// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 10 for the two-level ones,
+// which also keep 10 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 8
+#define CRT_LDS_STACK 16
 #endif
-constexpr int LDS_STACK = CRT_LDS_STACK; // per-lane stack entries kept in LDS
+#ifndef CRT_LDS_STACK_TWO_LEVEL
+#define CRT_LDS_STACK_TWO_LEVEL 10
+#endif
+constexpr int lds_stack_of(bool two_level) { return two_level ? CRT_LDS_STACK_TWO_LEVEL : CRT_LDS_STACK; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
 // and compact per wave, so deep traversals stay within a few pages. Its depth is a property of the
 // scene (SceneView::spill_depth, sized at set_scene from the BVH's depth), not a compile-time limit.
@@ -41,7 +48,7 @@ struct RayHit {
 #define TV_LDS __attribute__((address_space(3)))
 #define TV_HBM __attribute__((address_space(1)))
 
-struct TraversalStack {
+template <int LDS_STACK> struct TraversalStack {
     TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
@@ -135,18 +142,20 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 // the inner-node phase goes on while n_inner / n_active >= CRT_INNER_NUM / CRT_INNER_DEN
 // (measured with the 4-wide tree: 1/3 is 4 % slower than 1/2 on C4, 2/3 is 3 % faster on C2 and
 // 0.4 % on C4: an inner step is the expensive one, so it should run with most lanes on board)
+// (re-measured with the all-loads-first leaf step: 1/2 is 2.3 % faster than 2/3 on the instanced C4 and equal on
+// C4F; 3/4 is 2-4 % slower on both)
 #ifndef CRT_INNER_NUM
-#define CRT_INNER_NUM 2
+#define CRT_INNER_NUM 1
 #endif
 #ifndef CRT_INNER_DEN
-#define CRT_INNER_DEN 3
+#define CRT_INNER_DEN 2
 #endif
-// Child visit order. 0: entered children fully sorted by entry distance (the validated default, and
-// the rule the oracle's walker mirrors). 1: nearest first, the rest stacked unsorted -- on the CPU
-// model (tools/traverse_sim.cpp, real rays) this visits 0-3 % more nodes and removes ~19 of the
-// ~170 VALU instructions of a step; NOT yet run on a GPU, the counters test expects rule 0.
+// Child visit order. 0: entered children fully sorted by entry distance. 1 (default): nearest first, the
+// rest stacked in slot order -- 0-3 % more node visits (tools/traverse_sim.cpp), no sorting network and no
+// slot -> reference selects: C4 -1.5 %, C4F -0.7 % frame time. The oracle's walker of the product's arrays
+// takes the rule as a parameter (crt_hip_bvh_layout reports the build's), so the counters tests hold for both.
 #ifndef CRT_CHILD_ORDER
-#define CRT_CHILD_ORDER 0
+#define CRT_CHILD_ORDER 1
 #endif
 // occlusion rays visit children nearest first too: unsorted (lowest slot first) is 9 % faster on C2
 // but 14 % slower on C4, where the nearer child is much more often the occluder
@@ -179,7 +188,7 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 //        rays of one hit are traced back to back by one lane, which costs nothing in a wave whose
 //        lanes are refilled independently.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
-CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack &st, uint32_t n,
+CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack<lds_stack_of(TWO_LEVEL)> &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,

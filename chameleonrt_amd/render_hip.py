@@ -181,7 +181,7 @@ class PreparedScene:
         assert self._lib.crt_hip_prepared_scene_copy(self.handle, vp(nodes), vp(tris), vp(insts)) == 0
         return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
                     frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
-                    child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(),
+                    child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(int(tl.value)),
                     build_ms=ms.value)
 
     def set_samples_per_pixel(self, spp: int):

@@ -188,7 +188,7 @@ int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *prepared, void *no
  * and weak-scaling legs; everything else in a prepared scene is immutable). */
 int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *prepared, uint32_t samples_per_pixel);
 int crt_hip_child_order(void); /* the build's CRT_CHILD_ORDER (see crt_hip_bvh_layout) */
-uint32_t crt_hip_lds_stack_entries(void); /* per-lane traversal-stack entries kept in LDS; deeper ones live in HBM */
+uint32_t crt_hip_lds_stack_entries(int two_level); /* per-lane traversal-stack entries kept in LDS (single- / two-level kernels); deeper ones live in HBM */
 crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
 
 /* One frame. fovy in degrees; camera_changed resets accumulation (frame_id = 0). When
