@@ -776,7 +776,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         int32_t root = 0;
         QFrame root_frame{};
         if (two_level) {
-            BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, MAX_TOP_NODES_HOST, 1);
+            BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, CRT_MAX_TOP_NODES_TWO_LEVEL, 1);
             tlas_depth = tlas.max_depth;
             root_frame = make_frame(tlas.bounds);
             for (const BvhNode &nd : tlas.nodes) {

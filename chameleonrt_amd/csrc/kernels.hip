@@ -193,7 +193,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
 template <bool TWO_LEVEL> struct TraceLds {
-    QNode top[MAX_TOP_NODES + 1];
+    QNode top[(TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : MAX_TOP_NODES) + 1];
     int32_t stack[lds_stack_of(TWO_LEVEL)][TRACE_BLOCK];
     // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
     float cold[TWO_LEVEL ? 10 : 1][TRACE_BLOCK];
@@ -202,7 +202,7 @@ template <bool TWO_LEVEL> struct TraceLds {
 template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, Lds &lds)
 {
     // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step.
-    const uint32_t n = min(sc.n_top_nodes, (uint32_t)MAX_TOP_NODES);
+    const uint32_t n = min(sc.n_top_nodes, (uint32_t)(sizeof(lds.top) / sizeof(QNode) - 1));
     const float4 *src = reinterpret_cast<const float4 *>(sc.nodes + sc.root);
     float4 *dst = reinterpret_cast<float4 *>(lds.top);
     for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x) {

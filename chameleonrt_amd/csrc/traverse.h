@@ -20,13 +20,13 @@ namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
 // vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 10 for the two-level ones,
+// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 15 for the two-level ones,
 // which also keep 10 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
 #define CRT_LDS_STACK 16
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
-#define CRT_LDS_STACK_TWO_LEVEL 10
+#define CRT_LDS_STACK_TWO_LEVEL 15
 #endif
 constexpr int lds_stack_of(bool two_level) { return two_level ? CRT_LDS_STACK_TWO_LEVEL : CRT_LDS_STACK; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave

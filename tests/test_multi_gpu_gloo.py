@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, q):
+def _worker(rank, world, port, w, h, q, async_op=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -36,7 +36,11 @@ def _worker(rank, world, port, w, h, q):
         gx, gy = tx * mg.TILE + xx, ty * mg.TILE + yy
         val = np.where((gx < w) & (gy < h), gy * w + gx + 1, 0).astype(np.uint32)
         buf[lt * mg.TILE ** 2:(lt + 1) * mg.TILE ** 2] = val.reshape(-1)
-    gathered = mg.gather_tile_buffers(torch.from_numpy(buf.view(np.int32)))
+    if async_op:  # what bench.py does: gather of frame f in flight while frame f+1 is traced, waited on before f+2
+        gathered, work = mg.gather_tile_buffers(torch.from_numpy(buf.view(np.int32)), async_op=True)
+        work.wait()
+    else:
+        gathered = mg.gather_tile_buffers(torch.from_numpy(buf.view(np.int32)))
     rays, ms = mg.reduce_ray_stats(1000 * (rank + 1), 5.0 + rank)
     if rank == 0:
         img = mg.assemble_numpy(gathered.numpy().view(np.uint32), w, h, world)
@@ -47,14 +51,15 @@ def _worker(rank, world, port, w, h, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("async_op", [False, True], ids=["blocking", "async"])
 @pytest.mark.parametrize("size", [(300, 200), (128, 64)])
-def test_gather_and_assemble_world2(size):
+def test_gather_and_assemble_world2(size, async_op):
     import torch.multiprocessing as mp
     w, h = size
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, q, async_op)) for r in range(2)]
     for p in procs:
         p.start()
     img, rays, ms = q.get(timeout=120)
