@@ -77,8 +77,9 @@ def wrap_device_buffer(ptr, nbytes):
 class FrameLoop:
     """render -> (N > 1) gather + assemble, with the gather of frame f overlapping frame f+1."""
 
-    def __init__(self, r, cam, dist, rank, world):
+    def __init__(self, r, cam, dist, rank, world, host_staged=False):
         self.r, self.cam, self.dist, self.rank, self.world = r, cam, dist, rank, world
+        self.host_staged = host_staged  # gloo (tests): the tile buffers travel through host memory
         from chameleonrt_amd import multi_gpu
         self.multi_gpu = multi_gpu
         self.views = {}
@@ -89,6 +90,8 @@ class FrameLoop:
             work, gathered = self.pending
             work.wait()
             if self.rank == 0:
+                if self.host_staged:
+                    gathered = gathered.cuda()
                 self.r.assemble_tiles(gathered.data_ptr(), self.world, readback=False)
             self.pending = None
 
@@ -101,7 +104,7 @@ class FrameLoop:
             view = self.views.get(ptr)
             if view is None:
                 view = self.views[ptr] = wrap_device_buffer(ptr, nbytes)
-            gathered, work = self.multi_gpu.gather_tile_buffers(view, async_op=True)
+            gathered, work = self.multi_gpu.gather_tile_buffers(view.cpu() if self.host_staged else view, async_op=True)
             self.pending = (work, gathered)
         return st
 
@@ -135,8 +138,9 @@ def timed_frames(loop, args, dist, first_frame):
     elapsed = time.perf_counter() - t_start
     total_rays = acc["rays"]
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        c = torch.tensor([float(acc["rays"])], dtype=torch.float64, device="cuda")
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        c = torch.tensor([float(acc["rays"])], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         elapsed, total_rays = float(t.item()), int(c.item())
@@ -160,12 +164,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # CRT_BENCH_SHARE_GPU=1 (tests only: a one-GPU box): every rank renders on device 0 and the collective goes over
+    # gloo with host staging -- RCCL refuses two ranks on one device. It exercises everything of the N > 1 path but
+    # the transport: one scene preparation per node, the tile partition, both scaling legs, gather and K8.
+    share_gpu = os.environ.get("CRT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun the process group is used even for N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     gen, kw, width, height, base_spp = scenes.WORKLOADS[args.workload]
     spp = base_spp * (world if args.scaling == "weak" else 1)
@@ -222,7 +235,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    loop = FrameLoop(r, (eye, cdir, up, fovy), dist, rank, world)
+    loop = FrameLoop(r, (eye, cdir, up, fovy), dist, rank, world, host_staged=share_gpu)
     elapsed, total_rays, acc = timed_frames(loop, args, dist, 0)
 
     out = None

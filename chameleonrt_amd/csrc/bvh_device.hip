@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, const TriRec *recs, co
             out[2 * c + 1] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi) + 1];
         }
     }
-    for (int c = 0; c < 6; ++c) {
-        tri_uvs[6 * (size_t)p + c] = out[c];
+    for (int c = 0; c < TRI_UV_STRIDE; ++c) {
+        tri_uvs[(size_t)TRI_UV_STRIDE * p + c] = c < 6 ? out[c] : 0.f;
     }
 }
 
@@ -429,16 +429,16 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     // triangles + vertex UVs in leaf order
     Buf d_tris, d_tuv;
     d_tris.alloc((size_t)n * sizeof(TriRec));
-    d_tuv.alloc((size_t)n * 6 * 4);
+    d_tuv.alloc((size_t)n * TRI_UV_STRIDE * 4);
     k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<TriRec>(), idx, d_geoms.as<GeomDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
                                        d_tris.as<TriRec>(), d_tuv.as<float>());
     BD_CHECK(hipGetLastError());
     out.nodes.resize(n_nodes);
     out.tris.resize(n);
-    out.tri_uvs.resize((size_t)n * 6);
+    out.tri_uvs.resize((size_t)n * TRI_UV_STRIDE);
     BD_CHECK(hipMemcpy(out.nodes.data(), d_nodes.p, (size_t)n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
     BD_CHECK(hipMemcpy(out.tris.data(), d_tris.p, (size_t)n * sizeof(TriRec), hipMemcpyDeviceToHost));
-    BD_CHECK(hipMemcpy(out.tri_uvs.data(), d_tuv.p, (size_t)n * 6 * 4, hipMemcpyDeviceToHost));
+    BD_CHECK(hipMemcpy(out.tri_uvs.data(), d_tuv.p, (size_t)n * TRI_UV_STRIDE * 4, hipMemcpyDeviceToHost));
     out.max_depth = depth;
     out.n_top = std::min(n_nodes, max_top_nodes);
     out.frame = frame;

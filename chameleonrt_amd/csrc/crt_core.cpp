@@ -596,7 +596,7 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
 struct crt_hip_prepared_scene {
     std::vector<QNode> nodes;
     std::vector<TriRec> tris;
-    std::vector<float> tri_uvs; // 6 per TriRec
+    std::vector<float> tri_uvs; // TRI_UV_STRIDE per TriRec
     std::vector<InstanceRec> insts;
     std::vector<uint32_t> material_ids;
     std::vector<float> materials, lights;
@@ -650,8 +650,15 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             const crt_mesh_desc &md = s->meshes[m];
             if (build_device >= 0) {
                 DeviceBuiltMesh db;
-                if (device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries, (uint32_t)max_leaf,
-                                      two_level ? 0 : MAX_TOP_NODES_HOST, db)) {
+                bool built_on_device = false;
+                try {
+                    built_on_device = device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries,
+                                                        (uint32_t)max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST, db);
+                } catch (const std::exception &e) { // e.g. out of device memory: the host builder still can
+                    std::fprintf(stderr, "[crt_hip] %s -- building mesh %u on the host instead\n", e.what(), m);
+                    (void)hipGetLastError();
+                }
+                if (built_on_device) {
                     const size_t tri_base = tris.size();
                     tris.insert(tris.end(), db.tris.begin(), db.tris.end());
                     tri_uvs.insert(tri_uvs.end(), db.tri_uvs.begin(), db.tri_uvs.end());
@@ -708,7 +715,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             // triangles in leaf order
             const size_t tri_base = tris.size();
             tris.resize(tri_base + recs.size());
-            tri_uvs.resize(6 * tris.size(), 0.f);
+            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
             for (size_t i = 0; i < recs.size(); ++i) {
                 const TriRec &r = recs[built[m].order[i]];
                 tris[tri_base + i] = r;
@@ -716,8 +723,8 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 if (gd.uvs) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
                     for (int c = 0; c < 3; ++c) {
                         const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
-                        tri_uvs[6 * (tri_base + i) + 2 * c] = gd.uvs[2 * (size_t)vi];
-                        tri_uvs[6 * (tri_base + i) + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
+                        tri_uvs[(size_t)TRI_UV_STRIDE * (tri_base + i) + 2 * c] = gd.uvs[2 * (size_t)vi];
+                        tri_uvs[(size_t)TRI_UV_STRIDE * (tri_base + i) + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
                     }
                 }
             }
@@ -863,7 +870,10 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 r.width = im.width;
                 r.height = im.height;
                 r.channels = im.channels;
-                r.offset = total;
+                if (total / 16 > 0xffffffffull) {
+                    throw std::runtime_error("more than 64 GB of texels");
+                }
+                r.offset16 = (uint32_t)(total / 16);
                 tex[t] = r;
                 total += (size_t)im.width * im.height * im.channels;
             }
@@ -873,7 +883,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 for (uint32_t t = next_tex.fetch_add(1); t < s->n_textures; t = next_tex.fetch_add(1)) {
                     const crt_image_desc &im = s->textures[t];
                     const size_t npx = (size_t)im.width * im.height;
-                    uint8_t *p = texels.data() + tex[t].offset;
+                    uint8_t *p = texels.data() + (size_t)tex[t].offset16 * 16;
                     std::memcpy(p, im.data, npx * im.channels);
                     if (im.color_space == CRT_COLORSPACE_SRGB) {
                         const int convert_channels = std::min(3, im.channels);
@@ -1151,7 +1161,7 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
     std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
     PrepHeader h{};
     bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == PREP_MAGIC && h.abi == CRT_HIP_ABI_VERSION;
-    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->tris, h.n_tris) && prep_get(f, ps->tri_uvs, 6 * h.n_tris) &&
+    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->tris, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * h.n_tris) &&
          prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
          prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
     std::fclose(f);

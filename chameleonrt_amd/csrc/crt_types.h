@@ -70,10 +70,9 @@ struct alignas(16) InstanceRec {
 static_assert(sizeof(InstanceRec) == 128, "InstanceRec must be 128 bytes");
 
 // ISPCTexture2D (backends/embree/texture2d.ih:6-11); texels live in one byte blob.
-struct alignas(16) TexRec {
-    int32_t width, height, channels, pad;
-    uint64_t offset; // byte offset of texel (0,0) in Scene::texels
-    uint64_t pad1;
+struct alignas(16) TexRec { // 16 bytes: one request fetches it
+    int32_t width, height, channels;
+    uint32_t offset16; // byte offset of texel (0,0) in Scene::texels, in units of 16 bytes
 };
 
 // ViewParams (backends/embree/embree_utils.h:137-140) + framebuffer geometry.
@@ -90,7 +89,7 @@ struct SceneView {
     const QNode *nodes;
     const TriRec *tris;
     const InstanceRec *instances;
-    const float *tri_uvs;         // 6 floats per TriRec (uv of v0, v1, v2), same order as `tris`
+    const float *tri_uvs;         // TRI_UV_STRIDE floats per TriRec (uv of v0, v1, v2, two of padding: 2 x dwordx4), same order as `tris`
     const uint32_t *material_ids; // per instance per geomID
     const float *materials;       // 16 floats per material (14 used, MaterialParams order)
     const TexRec *textures;
@@ -107,6 +106,7 @@ struct SceneView {
     uint32_t spill_depth;         // entries per lane in the slab (sized at set_scene from the depth of this scene's BVH)
 };
 
+constexpr int TRI_UV_STRIDE = 8;      // floats per triangle in SceneView::tri_uvs
 constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr float RAY_EPS = 0.0001f;    // EPSILON, backends/embree/util.ih:8

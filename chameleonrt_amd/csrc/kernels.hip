@@ -466,11 +466,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 { // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
                   // triangle at set_scene; all zeros for a geometry without UVs, which interpolates
                   // to the reference's uv = (0, 0)
-                    const float2 *tu = reinterpret_cast<const float2 *>(sc.tri_uvs + 6 * (size_t)tri);
-                    const float2 a = tu[0], b = tu[1], c = tu[2];
-                    uv = (1.f - bu - bv) * v2(a.x, a.y) + bu * v2(b.x, b.y) + bv * v2(c.x, c.y);
+                    const float4 *tu = reinterpret_cast<const float4 *>(sc.tri_uvs + TRI_UV_STRIDE * (size_t)tri);
+                    const float4 ab = tu[0], cz = tu[1]; // two 16-byte requests (the record is padded to 32 bytes)
+                    uv = (1.f - bu - bv) * v2(ab.x, ab.y) + bu * v2(ab.z, ab.w) + bv * v2(cz.x, cz.y);
                 }
-                { // normal = normalize(transpose(world_to_object) * normal), ispc:288-290
+                // normal = normalize(transpose(world_to_object) * normal), ispc:288-290. For the identity matrix the
+                // same expression is evaluated on literal 1s and 0s -- bit for bit what the loaded matrix gives,
+                // signed zeros and non-finite values included (no fast-math: x * 0 is not folded) -- which saves the
+                // three requests for the matrix on every hit of an OBJ scene and most hits of C4.
+                if (in.identity) {
+                    normal = unit(v3(1.f * normal.x + 0.f * normal.y + 0.f * normal.z,
+                                     0.f * normal.x + 1.f * normal.y + 0.f * normal.z,
+                                     0.f * normal.x + 0.f * normal.y + 1.f * normal.z));
+                } else {
                     const float *m = in.w2o;
                     normal = unit(v3(m[0] * normal.x + m[1] * normal.y + m[2] * normal.z,
                                      m[4] * normal.x + m[5] * normal.y + m[6] * normal.z,
@@ -486,7 +494,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 // -- sample_direct_light, ispc:105-181 --
                 uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
                 light_id = min(light_id, sc.n_lights - 1u);
-                const QuadLight light = load_light(sc.lights + 20 * (size_t)light_id);
+                // every OBJ / glTF scene has exactly one light (scene.cpp:218-227, 406-414): its 20 floats then sit at a
+                // wave-uniform address and are fetched once per wave by the scalar unit instead of 5 vector requests per lane
+                const QuadLight light = sc.n_lights == 1u ? load_light(sc.lights) : load_light(sc.lights + 20 * (size_t)light_id);
                 {
                     V2 ls;
                     ls.x = rng_nextf(rng);

@@ -157,11 +157,11 @@ CRT_DEV float rng_nextf(uint32_t &state) { return (float)rng_next(state) * 2.328
 // ---- textures: texture2d.ih:13-83, util/texture_channel_mask.h:16-23 ----------------------
 CRT_DEV float texel_channel(const SceneView &sc, const TexRec &t, int px, int py, int channel)
 {
-    return sc.texels[t.offset + ((size_t)py * t.width + px) * t.channels + channel] / 255.f;
+    return sc.texels[(size_t)t.offset16 * 16 + ((size_t)py * t.width + px) * t.channels + channel] / 255.f;
 }
 CRT_DEV V4 texel_rgba(const SceneView &sc, const TexRec &t, int px, int py)
 {
-    const uint8_t *p = sc.texels + t.offset + ((size_t)py * t.width + px) * t.channels;
+    const uint8_t *p = sc.texels + (size_t)t.offset16 * 16 + ((size_t)py * t.width + px) * t.channels;
     V4 c{0.f, 0.f, 0.f, 0.f};
     c.x = p[0] / 255.f;
     if (t.channels >= 2) {
@@ -214,6 +214,36 @@ CRT_DEV float sample_channel(const SceneView &sc, const TexRec &t, V2 uv, int ch
            s11 * b.tx * b.ty;
 }
 
+// The four bilinear taps of a 4-CHANNEL texture fetched as whole texels: one dword request per tap carries
+// every channel, where texel_rgba / texel_channel issue a byte request per channel and tap. unpack_material
+// keeps the taps of the texture it fetched last, so a material whose metallic and roughness are two channels
+// of one parameter map (the glTF convention, scene.cpp:383-397) pays for that texture once. Same values,
+// same expressions as sample_rgba / sample_channel: byte / 255.f, then the four weighted terms left to right.
+struct TexTaps {
+    uint32_t id; // texture the taps belong to, 0xffffffff = none
+    uint32_t t00, t10, t01, t11;
+    float tx, ty;
+};
+CRT_DEV void fetch_taps4(const SceneView &sc, const TexRec &t, uint32_t id, V2 uv, TexTaps &c)
+{
+    const BilinearTaps b = bilinear_taps(t, uv);
+    const uint32_t *texels = reinterpret_cast<const uint32_t *>(sc.texels + (size_t)t.offset16 * 16);
+    c.t00 = texels[(size_t)b.y0 * t.width + b.x0];
+    c.t10 = texels[(size_t)b.y0 * t.width + b.x1];
+    c.t01 = texels[(size_t)b.y1 * t.width + b.x0];
+    c.t11 = texels[(size_t)b.y1 * t.width + b.x1];
+    c.tx = b.tx;
+    c.ty = b.ty;
+    c.id = id;
+}
+CRT_DEV float taps_channel(const TexTaps &c, int channel)
+{
+    const int sh = 8 * channel;
+    const float s00 = (float)(int)((c.t00 >> sh) & 0xffu) / 255.f, s10 = (float)(int)((c.t10 >> sh) & 0xffu) / 255.f;
+    const float s01 = (float)(int)((c.t01 >> sh) & 0xffu) / 255.f, s11 = (float)(int)((c.t11 >> sh) & 0xffu) / 255.f;
+    return s00 * (1.f - c.tx) * (1.f - c.ty) + s10 * c.tx * (1.f - c.ty) + s01 * (1.f - c.tx) * c.ty + s11 * c.tx * c.ty;
+}
+
 // ---- Disney BSDF: disney_bsdf.ih:19-429 ---------------------------------------------------
 struct Surface { // DisneyMaterial after unpack_material
     V3 base_color;
@@ -222,35 +252,55 @@ struct Surface { // DisneyMaterial after unpack_material
 };
 
 // render_embree.ispc:66-77
-CRT_DEV float scalar_param(const SceneView &sc, float x, V2 uv)
+CRT_DEV float scalar_param(const SceneView &sc, float x, V2 uv, TexTaps &taps)
 {
     const uint32_t mask = __float_as_uint(x);
     if (mask & 0x80000000u) {
-        return sample_channel(sc, sc.textures[mask & 0x1fffffffu], uv, (int)((mask >> 29) & 0x3u));
+        const uint32_t id = mask & 0x1fffffffu;
+        const int channel = (int)((mask >> 29) & 0x3u);
+        if (id != taps.id) {
+            const TexRec &t = sc.textures[id];
+            if (t.channels != 4) {
+                return sample_channel(sc, t, uv, channel);
+            }
+            fetch_taps4(sc, t, id, uv, taps);
+        }
+        return taps_channel(taps, channel);
     }
     return x;
 }
 // render_embree.ispc:79-103
 CRT_DEV void unpack_material(const SceneView &sc, Surface &m, const float *p, V2 uv)
 {
+    TexTaps taps;
+    taps.id = 0xffffffffu;
+    taps.t00 = taps.t10 = taps.t01 = taps.t11 = 0u;
+    taps.tx = taps.ty = 0.f;
     const uint32_t mask = __float_as_uint(p[0]);
     if (mask & 0x80000000u) {
-        const V4 c = sample_rgba(sc, sc.textures[mask & 0x1fffffffu], uv);
-        m.base_color = v3(c.x, c.y, c.z);
+        const uint32_t id = mask & 0x1fffffffu;
+        const TexRec &t = sc.textures[id];
+        if (t.channels == 4) {
+            fetch_taps4(sc, t, id, uv, taps);
+            m.base_color = v3(taps_channel(taps, 0), taps_channel(taps, 1), taps_channel(taps, 2));
+        } else {
+            const V4 c = sample_rgba(sc, t, uv);
+            m.base_color = v3(c.x, c.y, c.z);
+        }
     } else {
         m.base_color = v3(p[0], p[1], p[2]);
     }
-    m.metallic = scalar_param(sc, p[3], uv);
-    m.specular = scalar_param(sc, p[4], uv);
-    m.roughness = scalar_param(sc, p[5], uv);
-    m.specular_tint = scalar_param(sc, p[6], uv);
-    m.anisotropy = scalar_param(sc, p[7], uv);
-    m.sheen = scalar_param(sc, p[8], uv);
-    m.sheen_tint = scalar_param(sc, p[9], uv);
-    m.clearcoat = scalar_param(sc, p[10], uv);
-    m.clearcoat_gloss = scalar_param(sc, p[11], uv);
-    m.ior = scalar_param(sc, p[12], uv);
-    m.specular_transmission = scalar_param(sc, p[13], uv);
+    m.metallic = scalar_param(sc, p[3], uv, taps);
+    m.specular = scalar_param(sc, p[4], uv, taps);
+    m.roughness = scalar_param(sc, p[5], uv, taps);
+    m.specular_tint = scalar_param(sc, p[6], uv, taps);
+    m.anisotropy = scalar_param(sc, p[7], uv, taps);
+    m.sheen = scalar_param(sc, p[8], uv, taps);
+    m.sheen_tint = scalar_param(sc, p[9], uv, taps);
+    m.clearcoat = scalar_param(sc, p[10], uv, taps);
+    m.clearcoat_gloss = scalar_param(sc, p[11], uv, taps);
+    m.ior = scalar_param(sc, p[12], uv, taps);
+    m.specular_transmission = scalar_param(sc, p[13], uv, taps);
 }
 
 CRT_DEV bool same_side(V3 w_o, V3 w_i, V3 n) { return dot3(w_o, n) * dot3(w_i, n) > 0.f; } // :38-40

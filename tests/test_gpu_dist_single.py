@@ -24,6 +24,26 @@ def test_bench_under_torchrun_single_rank():
     assert out["n_gpus"] == 1 and out["value"] > 0 and "RCCL gather" in out["config"]["parallelism"]
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path of bench.py with two ranks sharing this box's one GPU (CRT_BENCH_SHARE_GPU=1: gloo with host
+    staging instead of RCCL, which refuses two ranks per device): rank 0 prepares the scene once and the other rank
+    loads it from /dev/shm, each renders its half of the tiles, the gather of frame f overlaps frame f+1, rank 0
+    assembles; the strong-scaling headline and the weak-scaling figure come out of the same run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CRT_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--workload", "C1", "--cpu-seconds", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["spp_per_frame"] == 1 and out["weak_scaling"]["spp_per_frame"] == 2
+    assert out["weak_scaling"]["value"] > 0
+    # Cornell 512 x 512, 1 spp: every pixel-sample traces at least its primary ray, whatever the split
+    assert out["config"]["rays_per_step"] >= 512 * 512
+    assert "roofline" in out and out["roofline"]["traffic"] is None  # counter passes are a single-GPU leg
+
+
 def test_gathered_image_equals_direct_image(hip_lib):
     """world = 1 through the gather/assemble path gives the image render() itself produces."""
     import numpy as np

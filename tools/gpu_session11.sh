@@ -1,0 +1,11 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/s11; mkdir -p $OUT
+( timeout -k 5 900 python -m pytest tests/test_gpu_kat.py tests/test_gpu_image.py tests/test_gpu_scale.py -m gpu -q -x ) > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+for W in C4 C4F C2; do
+  for V in prod oldtex; do
+    echo "== $W $V";
+    if [ $V = prod ]; then timeout 300 python tools/gpu_frames.py $W 2 6; else CRT_HIP_LIB=chameleonrt_amd/variants/libcrt_$V.so timeout 300 python tools/gpu_frames.py $W 2 6; fi
+  done
+done > $OUT/ab.log 2>&1
+grep -E "^==|frame [5]" $OUT/ab.log
