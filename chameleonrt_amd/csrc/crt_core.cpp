@@ -762,13 +762,36 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 wb.hi[a] = -INFINITY;
             }
             const float *m = id.transform;
-            for (int c = 0; c < 8; ++c) {
-                const float p[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1],
-                                    (c & 4) ? mb.hi[2] : mb.lo[2]};
-                for (int a = 0; a < 3; ++a) {
-                    const float w = r.identity ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
-                    wb.lo[a] = std::min(wb.lo[a], w);
-                    wb.hi[a] = std::max(wb.hi[a], w);
+            const crt_mesh_desc &imd = s->meshes[pm.mesh_id];
+            uint64_t mesh_verts = 0;
+            for (uint32_t k = 0; k < imd.n_geometries; ++k) {
+                mesh_verts += s->geometries[imd.first_geometry + k].n_vertices;
+            }
+            if (!r.identity && mesh_verts <= (1u << 20)) {
+                // The world box of the transformed VERTICES, not of the transformed corners of the object-space box:
+                // for a rotated instance the latter is up to 40 % wider on each axis, and every ray that enters an
+                // instance box pays a transform, a frame change and a walk from the BLAS root. (Instanced meshes are
+                // small; a mesh of more than a million vertices keeps the corner box.)
+                for (uint32_t k = 0; k < imd.n_geometries; ++k) {
+                    const crt_geometry_desc &gd = s->geometries[imd.first_geometry + k];
+                    for (uint64_t v = 0; v < gd.n_vertices; ++v) {
+                        const float *p = gd.vertices + 3 * v;
+                        for (int a = 0; a < 3; ++a) {
+                            const float w = m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
+                            wb.lo[a] = std::min(wb.lo[a], w);
+                            wb.hi[a] = std::max(wb.hi[a], w);
+                        }
+                    }
+                }
+            } else {
+                for (int c = 0; c < 8; ++c) {
+                    const float p[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1],
+                                        (c & 4) ? mb.hi[2] : mb.lo[2]};
+                    for (int a = 0; a < 3; ++a) {
+                        const float w = r.identity ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
+                        wb.lo[a] = std::min(wb.lo[a], w);
+                        wb.hi[a] = std::max(wb.hi[a], w);
+                    }
                 }
             }
             // pad: the BLAS is walked with a transformed (rounded) ray
