@@ -745,8 +745,14 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             const crt_parameterized_mesh_desc &pm = s->parameterized_meshes[id.parameterized_mesh_id];
             InstanceRec r;
             std::memset(&r, 0, sizeof(r));
-            if (!invert4x4(id.transform, r.w2o)) {
+            float inv[16];
+            if (!invert4x4(id.transform, inv)) {
                 throw std::runtime_error("singular instance transform");
+            }
+            for (int c = 0; c < 4; ++c) { // keep the affine 3x4 part (the last row of an instance transform is 0 0 0 1)
+                for (int rr = 0; rr < 3; ++rr) {
+                    r.w2o[c * 3 + rr] = inv[c * 4 + rr];
+                }
             }
             r.identity = is_identity(id.transform) ? 1u : 0u;
             r.geom_base = s->meshes[pm.mesh_id].first_geometry;

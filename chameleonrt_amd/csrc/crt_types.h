@@ -57,15 +57,17 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
-// One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 128 B.
+// One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 128 B. What a ray needs when it enters the
+// instance sits in the first 80 bytes, laid out for five 16-byte requests: the affine part of
+// world_to_object (three requests), then BLAS root, identity flag and the BLAS's frame (two).
 struct alignas(16) InstanceRec {
-    float w2o[16];      // world_to_object, column-major like glm (m[c*4+r])
+    float w2o[12];      // world_to_object without its constant last row: column c, row r at w2o[c*3 + r]
     int32_t blas_root;  // node index of the mesh's BLAS root
-    uint32_t geom_base; // global geometry index of the mesh's geometry 0
-    uint32_t mat_base;  // offset into Scene::material_ids for this instance's geomID 0
     uint32_t identity;  // 1 if the transform is bit-exactly the identity (ray not transformed)
     QFrame frame;       // fixed-point frame of the mesh's BLAS
-    uint32_t pad[6];
+    uint32_t geom_base; // global geometry index of the mesh's geometry 0
+    uint32_t mat_base;  // offset into Scene::material_ids for this instance's geomID 0
+    uint32_t pad[10];
 };
 static_assert(sizeof(InstanceRec) == 128, "InstanceRec must be 128 bytes");
 

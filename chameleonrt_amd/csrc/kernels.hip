@@ -479,10 +479,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                                      0.f * normal.x + 1.f * normal.y + 0.f * normal.z,
                                      0.f * normal.x + 0.f * normal.y + 1.f * normal.z));
                 } else {
-                    const float *m = in.w2o;
+                    const float *m = in.w2o; // 3x4: column c, row r at m[c*3 + r]
                     normal = unit(v3(m[0] * normal.x + m[1] * normal.y + m[2] * normal.z,
-                                     m[4] * normal.x + m[5] * normal.y + m[6] * normal.z,
-                                     m[8] * normal.x + m[9] * normal.y + m[10] * normal.z));
+                                     m[3] * normal.x + m[4] * normal.y + m[5] * normal.z,
+                                     m[6] * normal.x + m[7] * normal.y + m[8] * normal.z));
                 }
                 unpack_material(sc, mat, sc.materials + 16 * (size_t)mat_id, uv);
                 if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299

@@ -74,15 +74,17 @@ template <int LDS_STACK> struct TraversalStack {
     }
 };
 
-CRT_DEV V3 xfm_point(const float *m, V3 p) // column-major affine, rows evaluated left to right
+// m: InstanceRec::w2o, the 3x4 affine part of the column-major matrix (column c, row r at m[c*3 + r]);
+// rows evaluated left to right, as mat4.ih / the oracle evaluate the 4x4 product
+CRT_DEV V3 xfm_point(const float *m, V3 p)
 {
-    return v3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-              m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+    return v3(m[0] * p.x + m[3] * p.y + m[6] * p.z + m[9], m[1] * p.x + m[4] * p.y + m[7] * p.z + m[10],
+              m[2] * p.x + m[5] * p.y + m[8] * p.z + m[11]);
 }
 CRT_DEV V3 xfm_vector(const float *m, V3 v)
 {
-    return v3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
-              m[2] * v.x + m[6] * v.y + m[10] * v.z);
+    return v3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+              m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
 
 CRT_DEV float box_dir(float x) { return fabsf(x) < 1e-18f ? copysignf(1e-18f, x) : x; }

@@ -255,8 +255,8 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris);
  * children fully sorted by entry distance, 1 = nearest first, rest in slot order). */
 int crt_hip_bvh_layout(crt_hip_ctx *ctx, int32_t *root, uint32_t *n_top_nodes, uint32_t *stack_need,
                        uint32_t *lds_stack, int32_t *child_order);
-/* n_instances 128-byte instance records (world_to_object[16], blas_root, geom_base, mat_base,
- * identity, frame[6], pad[6]) as the two-level traversal reads them. */
+/* n_instances 128-byte instance records (affine world_to_object[12], blas_root, identity, frame[6],
+ * geom_base, mat_base, pad[10]) as the two-level traversal reads them. */
 int crt_hip_bvh_copy_instances(crt_hip_ctx *ctx, void *instances);
 
 #ifdef __cplusplus

@@ -1797,7 +1797,7 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 // (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked farthest first. child_order 1: the child with
 // the smallest key first, the others stacked in slot order, highest slot deepest.
 // Two-level scenes (instances != NULL): a TLAS leaf names an instance (128-byte product record:
-// world_to_object[16], blas_root, geom_base, mat_base, identity, frame[6], pad); the ray is moved into
+// world_to_object[12] (affine part), blas_root, identity, frame[6], geom_base, mat_base, pad); the ray is moved into
 // the instance's space (t preserved), a sentinel is stacked, the BLAS is walked in its own fixed-point
 // frame; popping the sentinel restores the world ray. TLAS leaves are not counted as node visits.
 namespace {
@@ -1813,12 +1813,24 @@ struct FTri {
     uint32_t geom, prim, pad;
 };
 struct FInst {
-    float w2o[16];
+    float w2o[12]; // affine 3x4 part of world_to_object: column c, row r at [c*3 + r]
     int32_t blas_root;
-    uint32_t geom_base, mat_base, identity;
+    uint32_t identity;
     float frame[6];
-    uint32_t pad[6];
+    uint32_t geom_base, mat_base;
+    uint32_t pad[10];
 };
+// the product's xfm_point / xfm_vector on that layout: each row evaluated ((a + b) + c) (+ d)
+inline f3 fxfm_point(const float *m, f3 p)
+{
+    return mk3(m[0] * p.x + m[3] * p.y + m[6] * p.z + m[9], m[1] * p.x + m[4] * p.y + m[7] * p.z + m[10],
+               m[2] * p.x + m[5] * p.y + m[8] * p.z + m[11]);
+}
+inline f3 fxfm_vector(const float *m, f3 v)
+{
+    return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+               m[2] * v.x + m[5] * v.y + m[8] * v.z);
+}
 static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48 && sizeof(FInst) == 128, "product BVH record sizes");
 constexpr int32_t F_SENTINEL = (int32_t)0x80000000;
 inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, float &tn)
@@ -1866,8 +1878,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
             int32_t cur_inst = 0;
             bool in_blas = !two_level;
             if (!two_level && insts != nullptr && !insts[0].identity) {
-                o = xfm_point(insts[0].w2o, worg);
-                d = xfm_vector(insts[0].w2o, wdir);
+                o = fxfm_point(insts[0].w2o, worg);
+                d = fxfm_vector(insts[0].w2o, wdir);
             }
             set_frame(root_frame);
             float best = tmax[i];
@@ -1927,8 +1939,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                         const FInst &in = insts[first];
                         cur_inst = (int32_t)first;
                         if (!in.identity) {
-                            o = xfm_point(in.w2o, worg);
-                            d = xfm_vector(in.w2o, wdir);
+                            o = fxfm_point(in.w2o, worg);
+                            d = fxfm_vector(in.w2o, wdir);
                         }
                         set_frame(in.frame);
                         in_blas = true;
