@@ -165,7 +165,7 @@ struct crt_hip_ctx {
     int device = 0;
     uint32_t flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    // Occlusion rays of bounce b and closest-hit rays of bounce b+1 are independent: with overlap on,
+    // Occlusion rays of bounce b and closest-hit rays of bounce b+1 are independent: with overlap on (the default),
     // the occlusion launch goes to aux_stream so that its waves fill the CUs the other launch's tail
     // leaves idle (and vice versa). It needs its own traversal-stack spill slab.
     hipStream_t aux_stream = nullptr;
@@ -487,6 +487,7 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         c->n_cus = prop.multiProcessorCount;
         c->name = std::string("HIP wavefront path tracer (") + prop.name + ", " + prop.gcnArchName + ")";
         HIP_CHECK(hipStreamCreate(&c->own_stream));
+        c->overlap = true; // CRT_HIP_OVERLAP=0: strictly serial launches
         if (const char *e = std::getenv("CRT_HIP_OVERLAP")) {
             c->overlap = std::atoi(e) != 0;
         }
@@ -1261,23 +1262,25 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             int kind;
         };
         std::vector<Span> spans;
-        auto mark = [&](int kind) {
+        // event pairs around each launch, recorded on the stream the launch goes to: with the overlapped
+        // schedule the occlusion launches' spans live on the auxiliary stream and run concurrently with the
+        // closest-hit spans of the next bounce (so the per-kind sums may add up to more than the frame time)
+        auto mark = [&](int kind, hipStream_t on) {
             if (timing) {
                 hipEvent_t e0 = get_event(ctx, ev), e1 = get_event(ctx, ev + 1);
                 (void)e1;
-                HIP_CHECK(hipEventRecord(e0, ctx->stream));
+                HIP_CHECK(hipEventRecord(e0, on));
                 spans.push_back(Span{ev, ev + 1, kind});
                 ev += 2;
             }
         };
-        auto mark_end = [&]() {
+        auto mark_end = [&](hipStream_t on) {
             if (timing) {
-                HIP_CHECK(hipEventRecord(get_event(ctx, spans.back().b), ctx->stream));
+                HIP_CHECK(hipEventRecord(get_event(ctx, spans.back().b), on));
             }
         };
 
-        // per-kernel-kind event spans need the serial schedule
-        const bool overlap = ctx->overlap && !timing;
+        const bool overlap = ctx->overlap;
         LaunchCfg aux_cfg = cfg;
         aux_cfg.stream = ctx->aux_stream;
         SceneView aux_sv = ctx->sv;
@@ -1294,40 +1297,44 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             if (cfg.counters) { // atomicMin targets start at all-ones
                 HIP_CHECK(hipMemsetAsync(d_pc->t_start, 0xff, 2 * MAX_PATH_DEPTH * sizeof(unsigned long long), ctx->stream));
             }
-            mark(2);
+            mark(2, ctx->stream);
             launch_raygen(cfg, vp, d_tiles, (uint32_t)slot0, n_paths, ctx->q[0], ctx->radiance, d_pc);
-            mark_end();
+            mark_end(ctx->stream);
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 if (!overlap || b == 0) {
-                    mark(0);
+                    mark(0, ctx->stream);
                     launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
-                    mark_end();
+                    mark_end(ctx->stream);
                 }
-                mark(2);
+                mark(2, ctx->stream);
                 launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
                              ctx->radiance, d_pc, b);
-                mark_end();
+                mark_end(ctx->stream);
                 if (overlap) {
                     // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the main stream } -> shade(b+1)
                     HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
                     HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+                    mark(1, ctx->aux_stream);
                     launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
+                    mark_end(ctx->aux_stream);
                     HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
                     if (b + 1 < MAX_PATH_DEPTH) {
+                        mark(0, ctx->stream);
                         launch_trace_closest(cfg, ctx->sv, ctx->q[(b + 1) & 1], ctx->hits, d_pc, b + 1);
+                        mark_end(ctx->stream);
                     }
                     HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 } else {
-                    mark(1);
+                    mark(1, ctx->stream);
                     launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
-                    mark_end();
+                    mark_end(ctx->stream);
                 }
             }
-            mark(2);
+            mark(2, ctx->stream);
             launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
                               ctx->d_tile_fb[ctx->frame_id & 1u].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
                               ctx->d_ray_counts.as<uint32_t>());
-            mark_end();
+            mark_end(ctx->stream);
             HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost,
                                      ctx->stream));
         }

@@ -22,7 +22,9 @@ else:
     t = time.time(); sc, w, h, spp = scenes.make_workload(which, **over); print("scene gen", time.time() - t, "s", sc.total_tris(), "tris")
     if wd:
         sc = sc.white_diffuse()
-r = RenderHIP(flags=flags); r.initialize(w, h)
+part = os.environ.get("CRT_PART")  # "rank/world": render only that share of the tiles (predicts strong scaling)
+rank, world = (int(x) for x in part.split("/")) if part else (0, 1)
+r = RenderHIP(flags=flags, rank=rank, world=world); r.initialize(w, h)
 t = time.time(); r.set_scene(sc); print("set_scene", time.time() - t, "s")
 cam = sc.cameras[0]; e, d, u = look_at(cam.position, cam.center, cam.up)
 for f in range(nframes):
