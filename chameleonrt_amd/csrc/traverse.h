@@ -174,6 +174,12 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 #ifndef CRT_LEAF_V2
 #define CRT_LEAF_V2 1
 #endif
+// two-level scenes: 0 = instances are entered in the leaf phase; 1 = in the inner-node phase (see there) -- measured
+// 16 % SLOWER on the instanced C4 (123.2 vs 105.9 ms): the entry's transform and frame change then sit in the hot
+// loop that most iterations run, for the few lanes that need them
+#ifndef CRT_ENTRY_IN_INNER
+#define CRT_ENTRY_IN_INNER 0
+#endif
 constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
 
 CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -392,12 +398,27 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
 
         // ---- inner-node phase: step while at least 2/3 of the active lanes are on an inner node
         for (;;) {
-            const bool inner = ray >= 0 && cur >= 0;
+            // (two level, CRT_ENTRY_IN_INNER = 1, a measured loss) a lane whose next reference is a TLAS leaf enters its
+            // instance in THIS phase, sharing the wave's wait with the other lanes' node fetches
+            const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur < 0 && cur != CUR_DONE && !in_blas;
+            const bool inner = (ray >= 0 && cur >= 0) || enter;
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
             if (n_inner == 0 || CRT_INNER_DEN * n_inner < CRT_INNER_NUM * n_active) {
                 break;
             }
-            if (inner) {
+            if (enter) {
+                const uint32_t first = (~(uint32_t)cur) >> 3;
+                const InstanceRec &in = sc.instances[first];
+                cur_inst = (int32_t)first;
+                if (!in.identity) {
+                    o = xfm_point(in.w2o, world_org());
+                    d = xfm_vector(in.w2o, world_dir());
+                }
+                set_frame(in.frame);
+                in_blas = true;
+                st.push(STACK_SENTINEL);
+                cur = in.blas_root;
+            } else if (inner) {
                 // one 16-byte quarter per child: {x: lo|hi, y: lo|hi, z: lo|hi, ref}
                 tv_u4 k0, k1, k2, k3;
                 if (cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
