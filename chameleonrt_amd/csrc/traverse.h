@@ -181,6 +181,7 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 #define CRT_ENTRY_IN_INNER 0
 #endif
 constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
+constexpr int32_t CUR_EXIT = (int32_t)0x80000003; // two level: the lane popped the sentinel and has to leave its instance
 
 CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
@@ -324,22 +325,18 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         cur = sc.root;
     };
 
-    // take the next reference off the stack (or finish); handles the instance-exit sentinel
+    // Take the next reference off the stack (or finish). Popping the instance-exit sentinel only MARKS the lane
+    // (CUR_EXIT): restoring the world-space ray and its frame (three reciprocals, a dozen multiplies, six LDS reads)
+    // is done by the leaf phase, like entering an instance, so that the inner-node loop -- which most iterations
+    // run -- carries no code for the few lanes that change level.
     auto pop_next = [&]() {
-        for (;;) {
-            if (st.sp == 0) {
-                cur = CUR_DONE;
-                return;
-            }
-            cur = st.pop();
-            if (TWO_LEVEL && cur == STACK_SENTINEL) {
-                o = world_org();
-                d = world_dir();
-                set_frame(sc.root_frame);
-                in_blas = false;
-                continue;
-            }
+        if (st.sp == 0) {
+            cur = CUR_DONE;
             return;
+        }
+        cur = st.pop();
+        if (TWO_LEVEL && cur == STACK_SENTINEL) {
+            cur = CUR_EXIT;
         }
     };
 
@@ -517,7 +514,13 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
             const uint32_t x = ~(uint32_t)cur;
             const uint32_t first = x >> 3;
-            if (TWO_LEVEL && !in_blas) {
+            if (TWO_LEVEL && cur == CUR_EXIT) { // leave the instance: back to the world-space ray and the TLAS's frame
+                o = world_org();
+                d = world_dir();
+                set_frame(sc.root_frame);
+                in_blas = false;
+                pop_next();
+            } else if (TWO_LEVEL && !in_blas) {
                 const InstanceRec &in = sc.instances[first];
                 cur_inst = (int32_t)first;
                 if (!in.identity) {
@@ -597,14 +600,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     cur = CUR_DONE;
                 } else {
                     --st.sp; // consume the entry read above
-                    cur = next_ref;
-                    if (TWO_LEVEL && cur == STACK_SENTINEL) {
-                        o = world_org();
-                        d = world_dir();
-                        set_frame(sc.root_frame);
-                        in_blas = false;
-                        pop_next();
-                    }
+                    cur = TWO_LEVEL && next_ref == STACK_SENTINEL ? CUR_EXIT : next_ref;
                 }
 #else
                 for (uint32_t k = first; k < first + count; ++k) {
