@@ -512,26 +512,33 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
         const uint32_t pf_leaf_lanes = COUNTERS ? (uint32_t)__popcll(__ballot(ray >= 0 && cur < 0 && cur != CUR_DONE)) : 0u;
         if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
-            const uint32_t x = ~(uint32_t)cur;
-            const uint32_t first = x >> 3;
-            if (TWO_LEVEL && cur == CUR_EXIT) { // leave the instance: back to the world-space ray and the TLAS's frame
-                o = world_org();
-                d = world_dir();
-                set_frame(sc.root_frame);
+            bool entered = false;
+            if (TWO_LEVEL && cur == CUR_EXIT) {
+                // Leave the instance. If the next reference is another instance (rays through a layer of instanced
+                // shrubs go from one straight into the next), it is entered below in the same step and the TLAS's
+                // frame is never needed; otherwise back to the world-space ray in that frame.
                 in_blas = false;
                 pop_next();
-            } else if (TWO_LEVEL && !in_blas) {
+                if (!(cur < 0 && cur != CUR_DONE)) {
+                    o = world_org();
+                    d = world_dir();
+                    set_frame(sc.root_frame);
+                }
+                entered = true; // this lane's step is used up unless it enters an instance now
+            }
+            const uint32_t x = ~(uint32_t)cur;
+            const uint32_t first = x >> 3;
+            if (TWO_LEVEL && !in_blas && cur < 0 && cur != CUR_DONE) {
                 const InstanceRec &in = sc.instances[first];
                 cur_inst = (int32_t)first;
-                if (!in.identity) {
-                    o = xfm_point(in.w2o, world_org());
-                    d = xfm_vector(in.w2o, world_dir());
-                }
+                const V3 wo = world_org(), wd = world_dir();
+                o = in.identity ? wo : xfm_point(in.w2o, wo);
+                d = in.identity ? wd : xfm_vector(in.w2o, wd);
                 set_frame(in.frame);
                 in_blas = true;
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
-            } else {
+            } else if (!entered) {
                 const uint32_t count = (x & 7u) + 1u;
                 bool occluded = false;
 #if CRT_LEAF_V2
