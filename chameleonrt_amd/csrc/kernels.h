@@ -12,12 +12,12 @@ namespace crt {
 #ifndef CRT_MAX_TOP_NODES
 #define CRT_MAX_TOP_NODES 85
 #endif
-// two-level scenes: top levels of the TLAS staged in LDS. Only the root and its children: the LDS of the two-level
-// kernels also holds the cold ray state and a traversal stack that runs much deeper than in a single tree (26
-// entries on the instanced C4), and LDS spent on stack entries pays more than LDS spent on node copies
-// (85 nodes + 10 entries -> 5 nodes + 15 entries: C4 -2 % frame time)
+// two-level scenes: top levels of the TLAS staged in LDS: none. The LDS of the two-level kernels also holds the cold
+// ray state and a traversal stack that runs much deeper than in a single tree (26 entries on the instanced C4), and
+// LDS spent on stack entries pays more than LDS spent on node copies (85 nodes + 10 entries -> 5 nodes + 15 entries:
+// C4 -2 % frame time; 5 -> 0 nodes, which also takes the LDS-or-HBM branch out of the inner loop: -0.8 %)
 #ifndef CRT_MAX_TOP_NODES_TWO_LEVEL
-#define CRT_MAX_TOP_NODES_TWO_LEVEL 5
+#define CRT_MAX_TOP_NODES_TWO_LEVEL 0
 #endif
 
 struct LaunchCfg {

@@ -418,7 +418,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             } else if (inner) {
                 // one 16-byte quarter per child: {x: lo|hi, y: lo|hi, z: lo|hi, ref}
                 tv_u4 k0, k1, k2, k3;
-                if (cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
+                if ((TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : CRT_MAX_TOP_NODES) > 0 && cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
                     const TV_LDS tv_u4 *p = (const TV_LDS tv_u4 *)(top + (cur - top_lo));
                     k0 = p[0];
                     k1 = p[1];
