@@ -270,8 +270,12 @@ void setup_queues(crt_hip_ctx *c)
 {
     const uint64_t total_slots = (uint64_t)c->n_local_tiles * TILE_PIXELS;
     uint64_t cap = std::min<uint64_t>(default_capacity(), total_slots * c->spp);
+    cap = std::min<uint64_t>(cap, 1ull << PATH_ID_BITS); // a path's index shares its queue word with its ray count (crt_types.h)
     const uint64_t slots_per_pass = std::max<uint64_t>(64, (cap / c->spp) / 64 * 64);
     cap = slots_per_pass * c->spp;
+    if (cap > (1ull << PATH_ID_BITS)) {
+        throw std::runtime_error("samples_per_pixel too large: 64 pixels x spp paths must fit one pass of 2^27 paths");
+    }
     c->capacity = cap;
     const size_t n_fields = 2 * 11 + 9 + 12 + 18 + 4;
     c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
@@ -879,7 +883,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 if (im.width <= 0 || im.height <= 0 || im.channels < 1 || im.channels > 4 || !im.data) {
                     throw std::runtime_error("bad texture");
                 }
-                total = (total + 15) / 16 * 16 + (size_t)im.width * im.height * im.channels;
+                total = (total + 15) / 16 * 16 + (size_t)tex_tiled_texels(im.width, im.height) * im.channels;
             }
             texels.reserve(total + 16);
         }
@@ -905,21 +909,29 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 }
                 r.offset16 = (uint32_t)(total / 16);
                 tex[t] = r;
-                total += (size_t)im.width * im.height * im.channels;
+                if (tex_tiled_texels(im.width, im.height) > 0xffffffffull) {
+                    throw std::runtime_error("texture too large");
+                }
+                total += (size_t)tex_tiled_texels(im.width, im.height) * im.channels;
             }
             texels.assign(total, 0);
             std::atomic<uint32_t> next_tex{0};
             auto work = [&]() {
                 for (uint32_t t = next_tex.fetch_add(1); t < s->n_textures; t = next_tex.fetch_add(1)) {
                     const crt_image_desc &im = s->textures[t];
-                    const size_t npx = (size_t)im.width * im.height;
+                    // rows of texels -> 8 x 4 tiles (crt_types.h tex_slot), linearising the colour channels on the way
                     uint8_t *p = texels.data() + (size_t)tex[t].offset16 * 16;
-                    std::memcpy(p, im.data, npx * im.channels);
-                    if (im.color_space == CRT_COLORSPACE_SRGB) {
-                        const int convert_channels = std::min(3, im.channels);
-                        for (size_t px = 0; px < npx; ++px) {
-                            for (int c = 0; c < convert_channels; ++c) {
-                                p[px * im.channels + c] = lut[p[px * im.channels + c]];
+                    const uint8_t *src = static_cast<const uint8_t *>(im.data);
+                    const int convert_channels = im.color_space == CRT_COLORSPACE_SRGB ? std::min(3, im.channels) : 0;
+                    const uint32_t tiles_x = tex_tiles_x(im.width);
+                    for (int32_t y = 0; y < im.height; ++y) {
+                        const uint32_t row = tex_row_part(tiles_x, y);
+                        const uint8_t *s_row = src + (size_t)y * im.width * im.channels;
+                        for (int32_t x = 0; x < im.width; ++x) {
+                            uint8_t *d = p + (size_t)(row + tex_col_part(x)) * im.channels;
+                            for (int c = 0; c < im.channels; ++c) {
+                                const uint8_t v = s_row[(size_t)x * im.channels + c];
+                                d[c] = c < convert_channels ? lut[v] : v;
                             }
                         }
                     }
@@ -1005,7 +1017,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 // Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
 // path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
 namespace {
-constexpr uint64_t PREP_MAGIC = 0x3130505250545243ull; // "CRTPRP01"
+constexpr uint64_t PREP_MAGIC = 0x3230505250545243ull; // "CRTPRP02" (02: tiled texels)
 struct PrepHeader {
     uint64_t magic, abi;
     uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;

@@ -74,8 +74,34 @@ static_assert(sizeof(InstanceRec) == 128, "InstanceRec must be 128 bytes");
 // ISPCTexture2D (backends/embree/texture2d.ih:6-11); texels live in one byte blob.
 struct alignas(16) TexRec { // 16 bytes: one request fetches it
     int32_t width, height, channels;
-    uint32_t offset16; // byte offset of texel (0,0) in Scene::texels, in units of 16 bytes
+    uint32_t offset16; // byte offset of the texture in Scene::texels, in units of 16 bytes
 };
+// Texels are stored in tiles of 8 x 4: with 4 channels (every texture the reference's importers load, stb_image is
+// asked for 4) a tile is one 128-byte cache line, and the 2 x 2 footprint of a bilinear lookup lies in 1.4 lines on
+// average where rows of texels put it in 2.06 (incoherent lookups pay per LINE, tools/line_microbench.hip). Slot of
+// texel (x, y), in texels; the texture occupies tex_tiled_texels() slots (edge tiles are padded, never addressed).
+#if defined(__HIPCC__)
+#define CRT_TYPES_HD __host__ __device__ inline
+#else
+#define CRT_TYPES_HD inline
+#endif
+constexpr int TEX_TILE_W_LOG2 = 3, TEX_TILE_H_LOG2 = 2;
+CRT_TYPES_HD uint32_t tex_tiles_x(int32_t width) { return ((uint32_t)width + (1u << TEX_TILE_W_LOG2) - 1u) >> TEX_TILE_W_LOG2; }
+CRT_TYPES_HD uint32_t tex_row_part(uint32_t tiles_x, int32_t y)
+{
+    return ((((uint32_t)y >> TEX_TILE_H_LOG2) * tiles_x) << (TEX_TILE_W_LOG2 + TEX_TILE_H_LOG2)) |
+           (((uint32_t)y & ((1u << TEX_TILE_H_LOG2) - 1u)) << TEX_TILE_W_LOG2);
+}
+CRT_TYPES_HD uint32_t tex_col_part(int32_t x)
+{
+    return (((uint32_t)x >> TEX_TILE_W_LOG2) << (TEX_TILE_W_LOG2 + TEX_TILE_H_LOG2)) | ((uint32_t)x & ((1u << TEX_TILE_W_LOG2) - 1u));
+}
+CRT_TYPES_HD uint32_t tex_slot(int32_t width, int32_t x, int32_t y) { return tex_row_part(tex_tiles_x(width), y) + tex_col_part(x); }
+CRT_TYPES_HD uint64_t tex_tiled_texels(int32_t width, int32_t height)
+{
+    const uint64_t tiles_y = ((uint64_t)height + (1u << TEX_TILE_H_LOG2) - 1u) >> TEX_TILE_H_LOG2;
+    return ((uint64_t)tex_tiles_x(width) * tiles_y) << (TEX_TILE_W_LOG2 + TEX_TILE_H_LOG2);
+}
 
 // ViewParams (backends/embree/embree_utils.h:137-140) + framebuffer geometry.
 struct ViewParams {
@@ -113,6 +139,12 @@ constexpr int TILE = 64;              // the reference's tile edge (render_embre
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr float RAY_EPS = 0.0001f;    // EPSILON, backends/embree/util.ih:8
 constexpr int MAX_PATH_DEPTH = 5;     // backends/embree/util.ih:10
+// PathQueue::path: the path's index within its pass (bits 0..26) and, above it, the rays the path has traced on
+// earlier bounces (at most 3 per bounce: closest hit + up to two occlusion rays); k_shade adds them to
+// radiance[path].w when the path ends.
+constexpr int PATH_ID_BITS = 27;
+constexpr uint32_t PATH_ID_MASK = (1u << PATH_ID_BITS) - 1u;
+static_assert(3 * MAX_PATH_DEPTH < (1 << (32 - PATH_ID_BITS)), "ray count of a path must fit above its index");
 constexpr float RAY_TFAR = 1e20f;     // set_ray_hit, backends/embree/util.ih:118
 
 } // namespace crt

@@ -436,23 +436,28 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         V3 hit_p = v3(0.f), normal = v3(0.f), w_o = v3(0.f), tp_in = v3(0.f);
         V3 light_dir = v3(0.f), w_i_b = v3(0.f), c_a = v3(0.f), c_b = v3(0.f);
         float light_dist = 0.f, light_dist_b = 0.f;
-        uint32_t path = 0, rng = 0;
+        uint32_t path = 0, rng = 0, n_rays = 0;
         Surface mat;
         if (valid) {
             const V3 o = v3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
             const V3 d = v3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
-            path = qin.path[i];
+            // The rays a path has traced so far (REPORT_RAY_STATS) ride in the top bits of its queue word and reach
+            // radiance[path].w once, when the path ends -- not with a 16-byte read-modify-write per bounce.
+            const uint32_t word = qin.path[i];
+            path = word & PATH_ID_MASK;
+            n_rays = (word >> PATH_ID_BITS) + 1u; // + the closest-hit ray (ispc:246-248)
             rng = qin.rng[i];
             tp_in = v3(qin.tp[0][i], qin.tp[1][i], qin.tp[2][i]);
             const int32_t tri = hits.tri[i];
-            float4 L = radiance[path];
-            L.w += 1.f; // the closest-hit ray (REPORT_RAY_STATS, ispc:246-248)
             if (tri < 0) {
                 // ispc:258-262
+                float4 L = radiance[path];
+                L.w += (float)n_rays;
                 const V3 m = tp_in * miss_color(d);
                 L.x = L.x + m.x;
                 L.y = L.y + m.y;
                 L.z = L.z + m.z;
+                radiance[path] = L;
             } else {
                 is_hit = true;
                 const float t = hits.t[i], bu = hits.u[i], bv = hits.v[i];
@@ -532,16 +537,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                         }
                     }
                 }
-                L.w += has_b ? 2.f : 1.f; // the occlusion rays (ispc:145-147, 171-173)
+                n_rays += has_b ? 2u : 1u; // the occlusion rays (ispc:145-147, 171-173)
                 // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
                 // non-finite throughput (the reference's glass pdfs can be negative or overflow)
-                // turns the pixel into NaN there, so it must here too. +0 for every finite path.
+                // turns the pixel into NaN there, so it must here too. For a finite throughput the
+                // term is a zero whose addition changes no bit of L (L is never -0), so only the
+                // non-finite case touches the radiance here.
                 const V3 poison = tp_in * 0.f;
-                L.x = L.x + poison.x;
-                L.y = L.y + poison.y;
-                L.z = L.z + poison.z;
+                if (!(poison.x == 0.f && poison.y == 0.f && poison.z == 0.f)) {
+                    float4 L = radiance[path];
+                    L.x = L.x + poison.x;
+                    L.y = L.y + poison.y;
+                    L.z = L.z + poison.z;
+                    radiance[path] = L;
+                }
             }
-            radiance[path] = L;
         }
 
         // Phase 2 (wave-uniform): stage the occlusion rays.
@@ -607,6 +617,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             }
         }
 
+        if (is_hit && !alive) { // the path ends on this surface: hand in its ray count
+            radiance[path].w += (float)n_rays;
+        }
+
         // Phase 4 (wave-uniform): stage the continuation rays, flush full staging buffers.
         const uint32_t ln = wave_append_lds(&stage.n_next, alive);
         if (alive) {
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             stage.next[3][ln] = __float_as_uint(w_i.x);
             stage.next[4][ln] = __float_as_uint(w_i.y);
             stage.next[5][ln] = __float_as_uint(w_i.z);
-            stage.next[6][ln] = path;
+            stage.next[6][ln] = path | (n_rays << PATH_ID_BITS);
             stage.next[7][ln] = rng;
             stage.next[8][ln] = __float_as_uint(tp.x);
             stage.next[9][ln] = __float_as_uint(tp.y);

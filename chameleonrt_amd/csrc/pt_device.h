@@ -157,11 +157,11 @@ CRT_DEV float rng_nextf(uint32_t &state) { return (float)rng_next(state) * 2.328
 // ---- textures: texture2d.ih:13-83, util/texture_channel_mask.h:16-23 ----------------------
 CRT_DEV float texel_channel(const SceneView &sc, const TexRec &t, int px, int py, int channel)
 {
-    return sc.texels[(size_t)t.offset16 * 16 + ((size_t)py * t.width + px) * t.channels + channel] / 255.f;
+    return sc.texels[(size_t)t.offset16 * 16 + (size_t)tex_slot(t.width, px, py) * t.channels + channel] / 255.f;
 }
 CRT_DEV V4 texel_rgba(const SceneView &sc, const TexRec &t, int px, int py)
 {
-    const uint8_t *p = sc.texels + (size_t)t.offset16 * 16 + ((size_t)py * t.width + px) * t.channels;
+    const uint8_t *p = sc.texels + (size_t)t.offset16 * 16 + (size_t)tex_slot(t.width, px, py) * t.channels;
     V4 c{0.f, 0.f, 0.f, 0.f};
     c.x = p[0] / 255.f;
     if (t.channels >= 2) {
@@ -228,10 +228,13 @@ CRT_DEV void fetch_taps4(const SceneView &sc, const TexRec &t, uint32_t id, V2 u
 {
     const BilinearTaps b = bilinear_taps(t, uv);
     const uint32_t *texels = reinterpret_cast<const uint32_t *>(sc.texels + (size_t)t.offset16 * 16);
-    c.t00 = texels[(size_t)b.y0 * t.width + b.x0];
-    c.t10 = texels[(size_t)b.y0 * t.width + b.x1];
-    c.t01 = texels[(size_t)b.y1 * t.width + b.x0];
-    c.t11 = texels[(size_t)b.y1 * t.width + b.x1];
+    const uint32_t tiles_x = tex_tiles_x(t.width);
+    const uint32_t r0 = tex_row_part(tiles_x, b.y0), r1 = tex_row_part(tiles_x, b.y1);
+    const uint32_t c0 = tex_col_part(b.x0), c1 = tex_col_part(b.x1);
+    c.t00 = texels[r0 + c0];
+    c.t10 = texels[r0 + c1];
+    c.t01 = texels[r1 + c0];
+    c.t11 = texels[r1 + c1];
     c.tx = b.tx;
     c.ty = b.ty;
     c.id = id;

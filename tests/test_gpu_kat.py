@@ -74,6 +74,34 @@ def test_texture(pair):
     assert np.array_equal(g.view(np.uint32), c.view(np.uint32)), "bilinear fetch is + - * / floor: bit-exact"
 
 
+def test_textures_of_awkward_sizes(oracle, hip_lib):
+    """Texels are stored in 8 x 4 tiles (crt_types.h tex_slot): sizes that are no multiple of the tile, non-square,
+    narrower / lower than one tile, every channel count -- through the generic lookup (KAT_TEXTURE) and through the
+    whole-texel path of unpack_material (4-channel textures), bit for bit against the oracle, which reads rows."""
+    from chameleonrt_amd.scene import Image, LINEAR, SRGB
+    sc = scenes.instanced_grove()
+    rng = np.random.default_rng(5)
+    sizes = [(13, 7), (5, 9), (20, 33)]  # (width, height), replacing the grove's 4-, 3- and 4-channel textures
+    assert [t.channels for t in sc.textures] == [4, 3, 4]
+    for k, (w, h) in enumerate(sizes):
+        old = sc.textures[k]
+        sc.textures[k] = Image(w, h, old.channels, rng.integers(0, 256, size=(h, w, old.channels), dtype=np.uint8),
+                               old.color_space)
+    for w, h, ch in [(1, 1, 1), (9, 4, 2), (3, 70, 1), (130, 2, 4)]:
+        sc.textures.append(Image(w, h, ch, rng.integers(0, 256, size=(h, w, ch), dtype=np.uint8), SRGB if ch > 2 else LINEAR))
+    r = RenderHIP()
+    r.initialize(64, 64)
+    r.set_scene(sc)
+    o = oracle.OracleScene(sc)
+    rec = K.texture_records(40000, len(sc.textures), seed=21)
+    g, c = r.kat(K.KAT_TEXTURE, rec, 5), o.kat(K.KAT_TEXTURE, rec, 5)
+    assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
+    rec = K.unpack_records(20000, len(sc.materials), seed=22)
+    g, c = r.kat(K.KAT_UNPACK_MATERIAL, rec, 14), o.kat(K.KAT_UNPACK_MATERIAL, rec, 14)
+    assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
+    r.close()
+
+
 def test_unpack_material(pair):
     r, o, sc = pair
     rec = K.unpack_records(5000, len(sc.materials))
