@@ -26,6 +26,7 @@ EXPORTS = [
     "crt_hip_device_framebuffer", "crt_hip_read_accum", "crt_hip_read_ray_counts", "crt_hip_frame_id", "crt_hip_tile_buffer",
     "crt_hip_assemble_tiles", "crt_hip_trace_rays", "crt_hip_kat", "crt_hip_bvh_info",
     "crt_hip_bvh_copy", "crt_hip_bvh_layout", "crt_hip_bvh_copy_instances", "crt_hip_prepare_scene",
+    "crt_hip_prepared_scene_world_instance", "crt_hip_world_instance",
     "crt_hip_prepare_scene_on", "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
     "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp",
@@ -98,6 +99,10 @@ def load():
     L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p, fp]
     L.crt_hip_bvh_copy.argtypes = [vp, vp, vp]
     L.crt_hip_bvh_layout.argtypes = [vp, i32p, u32p, u32p, u32p, i32p]
+    L.crt_hip_prepared_scene_world_instance.argtypes = [vp]
+    L.crt_hip_prepared_scene_world_instance.restype = C.c_int32
+    L.crt_hip_world_instance.argtypes = [vp]
+    L.crt_hip_world_instance.restype = C.c_int32
     L.crt_hip_bvh_copy_instances.argtypes = [vp, vp]
     L.crt_hip_prepare_scene.restype = vp
     L.crt_hip_prepare_scene.argtypes = [C.POINTER(SceneDesc), C.c_int]

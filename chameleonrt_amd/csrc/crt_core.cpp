@@ -20,6 +20,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <queue>
 #include <vector>
 
 #include "../../include/crt_hip.h"
@@ -610,6 +611,7 @@ struct crt_hip_prepared_scene {
     QFrame root_frame{};
     int32_t root = 0;
     uint32_t two_level = 0, n_top = 0, n_lights = 0, n_instances = 0, spp = 1, stack_need = 0;
+    int32_t world_inst = -1; // instance grafted into the top-level tree (prepare_scene), or -1
     double build_ms = 0.0;
 };
 
@@ -651,6 +653,51 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
         const char *builder_env = std::getenv("CRT_BVH_BUILDER"); // "lbvh": the device algorithm, run on the host
         const bool host_lbvh = builder_env && std::strcmp(builder_env, "lbvh") == 0;
+        // The static part of an instanced scene -- an identity instance whose mesh nothing else uses: the building
+        // of a San-Miguel-like scene with its instanced plants -- is not entered like an instance. Its BLAS is
+        // opened from the root down to a CUT of subtrees about as large as the other instances, the top-level tree is
+        // built over those subtrees AND the other instances' boxes, and a cut subtree is referenced by a plain
+        // child reference (its nodes are quantised in the top-level frame; an identity instance is traversed with
+        // the world-space ray anyway, so the hits are the same bit for bit). A ray then no longer walks a TLAS down
+        // to an instance box that covers the whole scene, enters it and starts again at the BLAS root: it walks
+        // one tree in which the plants sit where they stand, and the entry / exit steps of the big instance are gone.
+        // (Host-built meshes only: with CRT_HIP_BUILD=device every mesh keeps its BLAS and its own frame.)
+        int32_t world_inst = -1;
+        uint32_t world_mesh = 0xffffffffu;
+        if (two_level && build_device < 0 && max_leaf <= 7 && !std::getenv("CRT_HIP_NO_GRAFT")) {
+            std::vector<uint32_t> mesh_refs(s->n_meshes, 0);
+            for (uint32_t i = 0; i < s->n_instances; ++i) {
+                ++mesh_refs[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
+            }
+            uint64_t most = 0;
+            for (uint32_t i = 0; i < s->n_instances; ++i) {
+                const uint32_t m = s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id;
+                if (mesh_refs[m] != 1 || !is_identity(s->instances[i].transform)) {
+                    continue;
+                }
+                uint64_t n_tris_m = 0;
+                for (uint32_t k = 0; k < s->meshes[m].n_geometries; ++k) {
+                    n_tris_m += s->geometries[s->meshes[m].first_geometry + k].n_triangles;
+                }
+                if (n_tris_m > most) {
+                    most = n_tris_m;
+                    world_inst = (int32_t)i;
+                    world_mesh = m;
+                }
+            }
+        }
+        // triangle record + the uvs of its three vertices (uv_buf[indices.x|y|z], render_embree.ispc:278-283) at position `at`
+        auto place_tri = [&](const crt_mesh_desc &md, const TriRec &r, size_t at) {
+            tris[at] = r;
+            const crt_geometry_desc &gd = s->geometries[md.first_geometry + r.geom];
+            if (gd.uvs) {
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
+                    tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c] = gd.uvs[2 * (size_t)vi];
+                    tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
+                }
+            }
+        };
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
             const crt_mesh_desc &md = s->meshes[m];
             if (build_device >= 0) {
@@ -722,16 +769,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             tris.resize(tri_base + recs.size());
             tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
             for (size_t i = 0; i < recs.size(); ++i) {
-                const TriRec &r = recs[built[m].order[i]];
-                tris[tri_base + i] = r;
-                const crt_geometry_desc &gd = s->geometries[md.first_geometry + r.geom];
-                if (gd.uvs) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
-                    for (int c = 0; c < 3; ++c) {
-                        const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
-                        tri_uvs[(size_t)TRI_UV_STRIDE * (tri_base + i) + 2 * c] = gd.uvs[2 * (size_t)vi];
-                        tri_uvs[(size_t)TRI_UV_STRIDE * (tri_base + i) + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
-                    }
-                }
+                place_tri(md, recs[built[m].order[i]], tri_base + i);
             }
             blas_bounds[m] = built[m].bounds;
             blas_frame[m] = make_frame(built[m].bounds);
@@ -817,11 +855,107 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         int32_t root = 0;
         QFrame root_frame{};
         if (two_level) {
-            BuiltBvh tlas = build_bvh(inst_boxes.data(), inst_boxes.size(), 1, 0, 0, true, CRT_MAX_TOP_NODES_TWO_LEVEL, 1);
+            // items of the top-level tree: the cut through the grafted mesh's BLAS (if any), then one box per other instance
+            std::vector<Aabb> items;
+            std::vector<int32_t> item_ref; // what the leaf of an item becomes: a reference local to the grafted BLAS, or an instance leaf
+            std::vector<uint8_t> item_is_cut;
+            if (world_inst >= 0) {
+                const std::vector<BvhNode> &wn = built[world_mesh].nodes;
+                double inst_area = 0.0; // mean half surface area of the other instances' boxes
+                for (uint32_t i = 0; i < s->n_instances; ++i) {
+                    if ((int32_t)i != world_inst) {
+                        const Aabb &b = inst_boxes[i];
+                        const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
+                        inst_area += (dx * dy + dy * dz + dz * dx) / (double)(s->n_instances - 1);
+                    }
+                }
+                struct CutEntry {
+                    double area;
+                    Aabb box;
+                    int32_t ref;
+                    bool operator<(const CutEntry &o) const { return area < o.area; }
+                };
+                std::priority_queue<CutEntry> open; // inner nodes that may still be opened, largest first
+                std::vector<CutEntry> cut;
+                auto add_children = [&](int32_t node) {
+                    const BvhNode &nd = wn[(size_t)node];
+                    for (int k = 0; k < BVH_WIDTH; ++k) {
+                        if (nd.c[k] == EMPTY_CHILD) {
+                            continue;
+                        }
+                        CutEntry e;
+                        for (int a = 0; a < 3; ++a) {
+                            e.box.lo[a] = nd.lo[k][a];
+                            e.box.hi[a] = nd.hi[k][a];
+                        }
+                        const double dx = (double)e.box.hi[0] - e.box.lo[0], dy = (double)e.box.hi[1] - e.box.lo[1],
+                                     dz = (double)e.box.hi[2] - e.box.lo[2];
+                        e.area = dx * dy + dy * dz + dz * dx;
+                        e.ref = nd.c[k];
+                        if (e.ref >= 0) {
+                            open.push(e);
+                        } else {
+                            cut.push_back(e); // a triangle leaf directly under an opened node
+                        }
+                    }
+                };
+                add_children(0);
+                const size_t cap = 4 * (size_t)s->n_instances + 64;
+                while (!open.empty() && open.top().area > inst_area && cut.size() + open.size() + BVH_WIDTH <= cap) {
+                    const CutEntry e = open.top();
+                    open.pop();
+                    add_children(e.ref);
+                }
+                for (; !open.empty(); open.pop()) {
+                    cut.push_back(open.top());
+                }
+                for (const CutEntry &e : cut) {
+                    items.push_back(e.box);
+                    item_ref.push_back(e.ref);
+                    item_is_cut.push_back(1);
+                }
+            }
+            for (uint32_t i = 0; i < s->n_instances; ++i) {
+                if ((int32_t)i != world_inst) {
+                    items.push_back(inst_boxes[i]);
+                    item_ref.push_back(instance_leaf_ref(i));
+                    item_is_cut.push_back(0);
+                }
+            }
+            if (s->n_instances >= (1u << 28) - 1u) {
+                throw std::runtime_error("too many instances for the 28-bit leaf reference");
+            }
+            BuiltBvh tlas = build_bvh(items.data(), items.size(), 1, 0, 0, true, CRT_MAX_TOP_NODES_TWO_LEVEL, 1);
             tlas_depth = tlas.max_depth;
             root_frame = make_frame(tlas.bounds);
-            for (const BvhNode &nd : tlas.nodes) {
+            // where the grafted BLAS will lie: the per-mesh loop below appends the meshes in order behind the top-level nodes
+            int32_t world_node_base = (int32_t)tlas.nodes.size();
+            for (uint32_t m = 0; world_inst >= 0 && m < world_mesh; ++m) {
+                world_node_base += (int32_t)(built[m].nodes.size() + built_q[m].size());
+            }
+            const uint32_t world_tri_base = world_inst >= 0 ? (uint32_t)blas_root[world_mesh] : 0u;
+            for (BvhNode nd : tlas.nodes) {
+                for (int k = 0; k < BVH_WIDTH; ++k) {
+                    const int32_t c = nd.c[k];
+                    if (c >= 0 || c == EMPTY_CHILD) {
+                        continue;
+                    }
+                    const uint32_t id = (~(uint32_t)c) >> 3;
+                    int32_t ref = item_ref[id];
+                    if (item_is_cut[id]) { // local to the grafted BLAS -> global
+                        if (ref >= 0) {
+                            ref += world_node_base;
+                        } else {
+                            const uint32_t x = ~(uint32_t)ref;
+                            ref = (int32_t)~((((x >> 3) + world_tri_base) << 3) | (x & 7u));
+                        }
+                    }
+                    nd.c[k] = ref;
+                }
                 nodes.push_back(quantise(nd, root_frame));
+            }
+            if (world_inst >= 0) {
+                blas_frame[world_mesh] = root_frame; // its nodes are reached from the top-level tree without a frame change
             }
             n_top = tlas.n_top;
         }
@@ -864,6 +998,10 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         for (InstanceRec &r : insts) {
             r.blas_root = blas_root[r.blas_root];
         }
+        if (world_inst >= 0) {
+            insts[(size_t)world_inst].blas_root = 0; // never entered: its subtrees hang in the top-level tree (node 0 = its root)
+        }
+        ps->world_inst = world_inst;
         if (!two_level) {
             const uint32_t mesh0 = s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id;
             root = insts[0].blas_root;
@@ -1008,6 +1146,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     sv.stack_spill = ctx->d_spill.as<int32_t>();
     sv.root = ps.root;
     sv.two_level = ps.two_level;
+    sv.world_inst = ps.world_inst;
     sv.n_top_nodes = ps.n_top;
     ctx->has_scene = true;
 }
@@ -1017,13 +1156,14 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 // Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
 // path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
 namespace {
-constexpr uint64_t PREP_MAGIC = 0x3230505250545243ull; // "CRTPRP02" (02: tiled texels)
+constexpr uint64_t PREP_MAGIC = 0x3330505250545243ull; // "CRTPRP03" (02: tiled texels; 03: grafted world instance)
 struct PrepHeader {
     uint64_t magic, abi;
     uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;
     QFrame root_frame;
     int32_t root;
-    uint32_t two_level, n_top, n_lights, n_instances, spp, stack_need, pad;
+    uint32_t two_level, n_top, n_lights, n_instances, spp, stack_need;
+    int32_t world_inst;
 };
 template <typename T> bool prep_put(FILE *f, const std::vector<T> &v) { return v.empty() || std::fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
 template <typename T> bool prep_get(FILE *f, std::vector<T> &v, uint64_t n)
@@ -1091,6 +1231,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         return CRT_HIP_OK;
     });
 }
+
+int32_t crt_hip_prepared_scene_world_instance(const crt_hip_prepared_scene *ps) { return ps ? ps->world_inst : -1; }
+int32_t crt_hip_world_instance(crt_hip_ctx *ctx) { return ctx && ctx->has_scene ? ctx->sv.world_inst : -1; }
 
 int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *ps, uint64_t *n_nodes, uint64_t *n_tris,
                                 uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
@@ -1186,6 +1329,7 @@ int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *pa
     h.n_instances = ps->n_instances;
     h.spp = ps->spp;
     h.stack_need = ps->stack_need;
+    h.world_inst = ps->world_inst;
     const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && prep_put(f, ps->nodes) && prep_put(f, ps->tris) && prep_put(f, ps->tri_uvs) &&
                     prep_put(f, ps->insts) && prep_put(f, ps->material_ids) && prep_put(f, ps->materials) && prep_put(f, ps->lights) &&
                     prep_put(f, ps->tex) && prep_put(f, ps->texels);
@@ -1219,6 +1363,7 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
     ps->n_instances = h.n_instances;
     ps->spp = h.spp;
     ps->stack_need = h.stack_need;
+    ps->world_inst = h.world_inst;
     return ps.release();
 }
 

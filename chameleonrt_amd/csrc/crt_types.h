@@ -9,7 +9,10 @@ namespace crt {
 // Child reference c: c >= 0 -> inner node index (global, into Scene::nodes)
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
 //                              BLAS: triangles [first, first+count) of Scene::tris
-//                              TLAS: instance `first` (count is 1)
+//                              top-level tree of a scene with more than one instance: count == 8 (a value no
+//                              triangle leaf has: the builder makes leaves of <= 7) marks an INSTANCE leaf, instance
+//                              `first`; any other count is a triangle leaf of the instance that was grafted into the
+//                              top-level tree (SceneView::world_inst, crt_core.cpp), tested with the world-space ray
 //                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children (builder output only)
 // The BVH is 4-wide: one fetch decides four children, which about halves the chain of dependent
 // node fetches of a ray and the per-node bookkeeping (DESIGN.md "Traversal"; what bounds the kernel
@@ -17,6 +20,15 @@ namespace crt {
 // boxes of all children); the traversal kernels read the 64-byte quantised form below.
 constexpr int BVH_WIDTH = 4;
 constexpr int32_t EMPTY_CHILD = (int32_t)0x80000002;
+#if defined(__HIPCC__)
+#define CRT_TYPES_HD __host__ __device__ inline
+#else
+#define CRT_TYPES_HD inline
+#endif
+// (none of EMPTY_CHILD and the traversal's CUR_DONE / CUR_EXIT markers has its low three bits clear; the stack
+// sentinel 0x80000000 would be instance 2^28 - 1, which check_scene refuses)
+CRT_TYPES_HD int32_t instance_leaf_ref(uint32_t instance) { return (int32_t)~((instance << 3) | 7u); }
+CRT_TYPES_HD bool is_instance_leaf(int32_t ref) { return ref < 0 && (ref & 7) == 0; }
 struct alignas(16) BvhNode {
     float lo[BVH_WIDTH][3], hi[BVH_WIDTH][3];
     int32_t c[BVH_WIDTH];
@@ -80,11 +92,6 @@ struct alignas(16) TexRec { // 16 bytes: one request fetches it
 // asked for 4) a tile is one 128-byte cache line, and the 2 x 2 footprint of a bilinear lookup lies in 1.4 lines on
 // average where rows of texels put it in 2.06 (incoherent lookups pay per LINE, tools/line_microbench.hip). Slot of
 // texel (x, y), in texels; the texture occupies tex_tiled_texels() slots (edge tiles are padded, never addressed).
-#if defined(__HIPCC__)
-#define CRT_TYPES_HD __host__ __device__ inline
-#else
-#define CRT_TYPES_HD inline
-#endif
 constexpr int TEX_TILE_W_LOG2 = 3, TEX_TILE_H_LOG2 = 2;
 CRT_TYPES_HD uint32_t tex_tiles_x(int32_t width) { return ((uint32_t)width + (1u << TEX_TILE_W_LOG2) - 1u) >> TEX_TILE_W_LOG2; }
 CRT_TYPES_HD uint32_t tex_row_part(uint32_t tiles_x, int32_t y)
@@ -128,6 +135,7 @@ struct SceneView {
     QFrame root_frame;            // frame of the BVH `root` belongs to
     int32_t root;                 // TLAS root (two-level) or the single BLAS root
     uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly
+    int32_t world_inst;           // two level: the instance whose triangles sit in the top-level tree itself, or -1
     uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
     int32_t *stack_spill;         // traversal-stack overflow slab, [wave of the persistent grid][depth][lane]
     uint32_t spill_stride;        // threads the slab was sized for

@@ -276,7 +276,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         const uint32_t bp = TWO_LEVEL ? __float_as_uint(st.cold[9 * st.stride]) : best_prim;
         return geom != bg ? geom < bg : prim < bp;
     };
-    int32_t cur_inst = 0;
+    int32_t cur_inst = TWO_LEVEL ? sc.world_inst : 0;
     bool in_blas = !TWO_LEVEL;
     st.sp = 0;
     uint32_t stage = 0, carry = 0; // multi-ray items (Source::retire)
@@ -307,7 +307,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         const V3 org = world_org(), dir = world_dir();
         o = org;
         d = dir;
-        cur_inst = 0;
+        cur_inst = TWO_LEVEL ? sc.world_inst : 0; // triangles of the top-level tree belong to the grafted instance
         in_blas = !TWO_LEVEL;
         if (!TWO_LEVEL) {
             const InstanceRec &in = sc.instances[0];
@@ -397,7 +397,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         for (;;) {
             // (two level, CRT_ENTRY_IN_INNER = 1, a measured loss) a lane whose next reference is a TLAS leaf enters its
             // instance in THIS phase, sharing the wave's wait with the other lanes' node fetches
-            const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur < 0 && cur != CUR_DONE && !in_blas;
+            const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur != CUR_DONE && !in_blas && is_instance_leaf(cur);
             const bool inner = (ray >= 0 && cur >= 0) || enter;
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
             if (n_inner == 0 || CRT_INNER_DEN * n_inner < CRT_INNER_NUM * n_active) {
@@ -518,8 +518,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 // shrubs go from one straight into the next), it is entered below in the same step and the TLAS's
                 // frame is never needed; otherwise back to the world-space ray in that frame.
                 in_blas = false;
+                cur_inst = sc.world_inst;
                 pop_next();
-                if (!(cur < 0 && cur != CUR_DONE)) {
+                if (!(cur != CUR_DONE && is_instance_leaf(cur))) {
                     o = world_org();
                     d = world_dir();
                     set_frame(sc.root_frame);
@@ -528,7 +529,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
             const uint32_t x = ~(uint32_t)cur;
             const uint32_t first = x >> 3;
-            if (TWO_LEVEL && !in_blas && cur < 0 && cur != CUR_DONE) {
+            // top level: a leaf is an instance (count field 7) or, in a scene whose static mesh was grafted into the
+            // top-level tree (crt_core.cpp), triangles of that mesh, tested right here with the world-space ray
+            if (TWO_LEVEL && !in_blas && cur != CUR_DONE && is_instance_leaf(cur)) {
                 const InstanceRec &in = sc.instances[first];
                 cur_inst = (int32_t)first;
                 const V3 wo = world_org(), wd = world_dir();
@@ -538,7 +541,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 in_blas = true;
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
-            } else if (!entered) {
+            } else if (!entered && cur < 0 && cur != CUR_DONE) {
                 const uint32_t count = (x & 7u) + 1u;
                 bool occluded = false;
 #if CRT_LEAF_V2

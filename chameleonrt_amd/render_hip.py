@@ -135,7 +135,8 @@ class RenderHIP:
                    "bvh_copy_instances")
         return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
                     frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
-                    lds_stack=lds.value, child_order=child_order.value)
+                    lds_stack=lds.value, child_order=child_order.value,
+                    world_inst=self._lib.crt_hip_world_instance(self._ctx))
 
     # ---- multi-GPU tile assembly ---------------------------------------------------------
     def tile_buffer(self):
@@ -182,7 +183,7 @@ class PreparedScene:
         return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
                     frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
                     child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(int(tl.value)),
-                    build_ms=ms.value)
+                    build_ms=ms.value, world_inst=self._lib.crt_hip_prepared_scene_world_instance(self.handle))
 
     def set_samples_per_pixel(self, spp: int):
         assert self._lib.crt_hip_prepared_scene_set_spp(self.handle, spp) == 0

@@ -188,6 +188,12 @@ int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *prepared, void *no
  * and weak-scaling legs; everything else in a prepared scene is immutable). */
 int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *prepared, uint32_t samples_per_pixel);
 int crt_hip_child_order(void); /* the build's CRT_CHILD_ORDER (see crt_hip_bvh_layout) */
+/* Scenes with more than one instance: the index of the instance whose triangles were made leaves of the
+ * top-level tree itself (an identity instance whose mesh no other instance uses -- the static part of the
+ * scene; DESIGN.md "Traversal"), or -1. In the top-level tree a leaf whose 3-bit count field is 7 is an
+ * instance, any other leaf holds triangles of that instance. */
+int32_t crt_hip_prepared_scene_world_instance(const crt_hip_prepared_scene *prepared);
+int32_t crt_hip_world_instance(crt_hip_ctx *ctx); /* the same of the scene the context holds */
 uint32_t crt_hip_lds_stack_entries(int two_level); /* per-lane traversal-stack entries kept in LDS (single- / two-level kernels); deeper ones live in HBM */
 crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
 

@@ -1799,7 +1799,9 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 // Two-level scenes (instances != NULL): a TLAS leaf names an instance (128-byte product record:
 // world_to_object[12] (affine part), blas_root, identity, frame[6], geom_base, mat_base, pad); the ray is moved into
 // the instance's space (t preserved), a sentinel is stacked, the BLAS is walked in its own fixed-point
-// frame; popping the sentinel restores the world ray. TLAS leaves are not counted as node visits.
+// frame; popping the sentinel restores the world ray. TLAS leaves are not counted as node visits. A top-level
+// leaf is an instance iff its count field is 7; other top-level leaves are triangles of instance `world_inst`
+// (an identity instance grafted into the top-level tree), tested with the world ray.
 namespace {
 struct FChild {
     uint16_t q[3][2]; // per axis {lo, hi}; an unused slot is stored inverted (lo > hi)
@@ -1846,7 +1848,7 @@ inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, f
 } // namespace
 
 extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const void *instances_,
-                                    uint64_t n_instances, int32_t root, const float root_frame[6], int child_order,
+                                    uint64_t n_instances, int32_t world_inst, int32_t root, const float root_frame[6], int child_order,
                                     uint64_t n, const float *org, const float *dir, const float *tmin,
                                     const float *tmax, int closest, uint64_t *nodes_visited, uint64_t *tris_tested,
                                     uint32_t *max_stack, float *out_t, int32_t *out_inst, int32_t *out_geom,
@@ -1935,7 +1937,15 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                 } else {
                     const uint32_t x = ~(uint32_t)cur;
                     const uint32_t first = x >> 3, count = (x & 7u) + 1u;
-                    if (two_level && !in_blas) {
+                    // top level: count field 7 marks an instance; any other leaf holds triangles of the instance that
+                    // was grafted into the top-level tree (world_inst), tested with the world-space ray
+                    if (two_level && !in_blas && (x & 7u) != 7u) {
+                        if (world_inst < 0) {
+                            bad_t[tid] = 1;
+                        }
+                        cur_inst = world_inst;
+                    }
+                    if (two_level && !in_blas && (x & 7u) == 7u) {
                         const FInst &in = insts[first];
                         cur_inst = (int32_t)first;
                         if (!in.identity) {

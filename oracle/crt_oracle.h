@@ -89,7 +89,7 @@ int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], fl
  * n_instances <= 1: single-level walk from `root` (instance 0's transform applied if it is given and
  * not the identity). Outputs other than the two counters may be NULL. */
 int orc_walk_foreign_bvh(const void *nodes, const void *tris, const void *instances, uint64_t n_instances,
-                         int32_t root, const float root_frame[6], int child_order, uint64_t n, const float *org,
+                         int32_t world_inst, int32_t root, const float root_frame[6], int child_order, uint64_t n, const float *org,
                          const float *dir, const float *tmin, const float *tmax, int closest,
                          uint64_t *nodes_visited, uint64_t *tris_tested, uint32_t *max_stack, float *out_t,
                          int32_t *out_inst, int32_t *out_geom, int32_t *out_prim);

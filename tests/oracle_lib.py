@@ -45,7 +45,7 @@ def lib():
         L.orc_num_tiles.argtypes = [vp]
         L.orc_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                      i32p, i32p, i32p, C.POINTER(OrcStats)]
-        L.orc_walk_foreign_bvh.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32, fp, C.c_int, C.c_uint64, fp, fp, fp, fp,
+        L.orc_walk_foreign_bvh.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32, C.c_int32, fp, C.c_int, C.c_uint64, fp, fp, fp, fp,
                                            C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint32), fp, i32p, i32p, i32p]
         L.orc_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
@@ -105,7 +105,7 @@ def walk_product_bvh(bvh, org, dirs, tmin, tmax, closest=True):
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = lib().orc_walk_foreign_bvh(vp(bvh["nodes"]), vp(bvh["tris"]), vp(bvh["instances"]), bvh["n_instances"],
-                                    bvh["root"], _fp(bvh["frame"]), bvh["child_order"], n, _fp(org), _fp(dirs),
+                                    bvh.get("world_inst", -1), bvh["root"], _fp(bvh["frame"]), bvh["child_order"], n, _fp(org), _fp(dirs),
                                     _fp(tmin), _fp(tmax), int(closest), C.byref(nv), C.byref(tt), C.byref(ms),
                                     _fp(t), ip(inst), ip(geom), ip(prim))
     assert rc == 0

@@ -62,6 +62,67 @@ def test_instanced_scene_layout(prepared):
     assert bvh["child_order"] in (0, 1)
 
 
+@pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
+def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkeypatch):
+    """An identity instance whose mesh nothing else uses (the ground of the grove, the courtyard of the
+    San-Miguel-like scene) is not entered like an instance: its BLAS is cut open and the subtrees hang in the
+    top-level tree next to the other instances (crt_core.cpp prepare_scene, crt_types.h). Top-level leaves are
+    instances iff their count field is 7, none of them names the grafted instance; the hits are those of the
+    ungrafted build (CRT_HIP_NO_GRAFT), which the other tests of this file compare with brute force, bit for bit;
+    rays need fewer instance entries, seen here as fewer node visits for rays that start on surfaces."""
+    sc = SCENES[name]()
+    ps = PreparedScene(sc)
+    bvh = ps.bvh()
+    ps.close()
+    monkeypatch.setenv("CRT_HIP_NO_GRAFT", "1")
+    ps = PreparedScene(sc)
+    plain = ps.bvh()
+    ps.close()
+    assert plain["world_inst"] == -1 and bvh["world_inst"] == 0 and bvh["two_level"]
+    nodes = bvh["nodes"].reshape(-1, 4, 4)
+    refs = nodes[:, :, 3].astype(np.uint32).view(np.int32)
+    used = (nodes[:, :, 0] & 0xFFFF) <= (nodes[:, :, 0] >> 16)
+    # walk the top level: everything reachable from the root without passing an instance leaf
+    seen_inst, stack, top_tri_leaves, visited = set(), [bvh["root"]], 0, set()
+    while stack:
+        n = stack.pop()
+        if n in visited:
+            continue
+        visited.add(n)
+        for k in range(4):
+            if not used[n, k]:
+                continue
+            r = int(refs[n, k])
+            if r >= 0:
+                stack.append(r)
+            elif (~r & 7) == 7:
+                seen_inst.add((~r & 0xFFFFFFFF) >> 3)
+            else:
+                top_tri_leaves += 1
+    assert seen_inst == set(range(1, len(sc.instances))), "every other instance is a leaf of the top-level tree, the grafted one is not"
+    assert top_tri_leaves > 0
+    org, dirs = probe_rays(sc, 6000, seed=5)
+    a = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    b = oracle.walk_product_bvh(plain, org, dirs, 0.0, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(a[k], b[k]), k
+    hit = a["inst"] >= 0
+    assert (a["inst"][hit] == 0).any() and (a["inst"][hit] > 0).any()
+    assert np.array_equal(a["t"][hit].view(np.uint32), b["t"][hit].view(np.uint32))
+    # rays leaving surfaces (what four of five bounces and every occlusion ray are)
+    p = (org[hit] + dirs[hit] * a["t"][hit, None]).astype(np.float32)
+    d2 = np.random.default_rng(8).normal(size=p.shape).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    a2 = oracle.walk_product_bvh(bvh, p, d2, 1e-3, 1e20, closest=True)
+    b2 = oracle.walk_product_bvh(plain, p, d2, 1e-3, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(a2[k], b2[k]), k
+    # (the grove's grafted ground is two triangles: nothing to gain there, nothing to lose either)
+    assert a2["nodes"] <= 1.02 * b2["nodes"]
+    if name == "sanmiguel_small_instanced":
+        assert a2["nodes"] < b2["nodes"]
+
+
 def test_save_load_round_trip(prepared, tmp_path):
     _, bvh, _, ps = prepared
     path = str(tmp_path / "prepared.bin")
