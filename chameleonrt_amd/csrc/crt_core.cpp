@@ -900,6 +900,8 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                     }
                 };
                 add_children(0);
+                // (how far to open: a cut of 1x, 4x, 16x, 64x the instance count was priced with the oracle's walker on a
+                // reduced C4 -- 4x is the flat optimum for camera, bounce and occlusion rays alike)
                 const size_t cap = 4 * (size_t)s->n_instances + 64;
                 while (!open.empty() && open.top().area > inst_area && cut.size() + open.size() + BVH_WIDTH <= cap) {
                     const CutEntry e = open.top();
@@ -951,6 +953,27 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                         }
                     }
                     nd.c[k] = ref;
+                }
+                if (!std::getenv("CRT_HIP_NO_SLOT_ORDER")) {
+                    // Slot order is the order occlusion rays try the children in, and the order in which the children a
+                    // closest-hit ray does not take first are stacked: subtrees and triangles of the static mesh before
+                    // instances, so that a ray has found what the cheap part of the node holds (an occluder; a nearer hit
+                    // that culls the instance's box) before it pays for entering an instance.
+                    BvhNode ord = nd;
+                    int at = 0;
+                    for (int pass = 0; pass < 3; ++pass) {
+                        for (int k = 0; k < BVH_WIDTH; ++k) {
+                            const int kind = nd.c[k] == EMPTY_CHILD ? 2 : (is_instance_leaf(nd.c[k]) ? 1 : 0);
+                            if (kind == pass) {
+                                for (int a = 0; a < 3; ++a) {
+                                    ord.lo[at][a] = nd.lo[k][a];
+                                    ord.hi[at][a] = nd.hi[k][a];
+                                }
+                                ord.c[at++] = nd.c[k];
+                            }
+                        }
+                    }
+                    nd = ord;
                 }
                 nodes.push_back(quantise(nd, root_frame));
             }
