@@ -802,7 +802,18 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             r.mat_base = (uint32_t)material_ids.size();
             r.blas_root = (int32_t)pm.mesh_id; // temporarily: mesh id
             r.frame = blas_frame[pm.mesh_id];
-            material_ids.insert(material_ids.end(), pm.material_ids, pm.material_ids + pm.n_material_ids);
+            for (uint32_t k = 0; k < pm.n_material_ids; ++k) {
+                // bit 31: some parameter of the material is a texture handle (render_embree.ispc:66-103 tests the same
+                // sign bit per parameter) -- k_shade fetches the hit's uv record only then
+                const uint32_t id = pm.material_ids[k];
+                bool textured = false;
+                for (int f = 0; f < 14; ++f) {
+                    uint32_t bits;
+                    std::memcpy(&bits, s->materials + 16 * (size_t)id + f, 4);
+                    textured = textured || (bits & 0x80000000u) != 0u;
+                }
+                material_ids.push_back(id | (textured ? MATERIAL_TEXTURED : 0u));
+            }
             insts[i] = r;
             const Aabb &mb = blas_bounds[pm.mesh_id];
             Aabb wb;
@@ -1179,7 +1190,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 // Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
 // path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
 namespace {
-constexpr uint64_t PREP_MAGIC = 0x3330505250545243ull; // "CRTPRP03" (02: tiled texels; 03: grafted world instance)
+constexpr uint64_t PREP_MAGIC = 0x3430505250545243ull; // "CRTPRP04" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids)
 struct PrepHeader {
     uint64_t magic, abi;
     uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;

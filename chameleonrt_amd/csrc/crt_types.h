@@ -125,7 +125,7 @@ struct SceneView {
     const TriRec *tris;
     const InstanceRec *instances;
     const float *tri_uvs;         // TRI_UV_STRIDE floats per TriRec (uv of v0, v1, v2, two of padding: 2 x dwordx4), same order as `tris`
-    const uint32_t *material_ids; // per instance per geomID
+    const uint32_t *material_ids; // per instance per geomID; bit 31 (MATERIAL_TEXTURED): the material reads a texture
     const float *materials;       // 16 floats per material (14 used, MaterialParams order)
     const TexRec *textures;
     const uint8_t *texels;
@@ -142,6 +142,7 @@ struct SceneView {
     uint32_t spill_depth;         // entries per lane in the slab (sized at set_scene from the depth of this scene's BVH)
 };
 
+constexpr uint32_t MATERIAL_TEXTURED = 0x80000000u; // flag on the entries of SceneView::material_ids (and HitBuf::mat)
 constexpr int TRI_UV_STRIDE = 8;      // floats per triangle in SceneView::tri_uvs
 constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)
 constexpr int TILE_PIXELS = TILE * TILE;

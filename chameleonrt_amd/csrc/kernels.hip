@@ -462,15 +462,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 is_hit = true;
                 const float t = hits.t[i], bu = hits.u[i], bv = hits.v[i];
                 const InstanceRec &in = sc.instances[hits.inst[i]];
-                const uint32_t mat_id = hits.mat[i];
+                const uint32_t mat_word = hits.mat[i];
+                const uint32_t mat_id = mat_word & ~MATERIAL_TEXTURED;
                 w_o = -d;
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
                 // hit.Ng = cross(e2, e1), instance-local, unnormalised (written by K2)
                 normal = unit(v3(hits.ng[0][i], hits.ng[1][i], hits.ng[2][i]));
-                V2 uv;
-                { // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
-                  // triangle at set_scene; all zeros for a geometry without UVs, which interpolates
-                  // to the reference's uv = (0, 0)
+                V2 uv = v2(0.f, 0.f);
+                if (mat_word & MATERIAL_TEXTURED) { // (a material without textures never looks at uv: no record fetched)
+                    // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
+                    // triangle at set_scene; all zeros for a geometry without UVs, which interpolates
+                    // to the reference's uv = (0, 0)
                     const float4 *tu = reinterpret_cast<const float4 *>(sc.tri_uvs + TRI_UV_STRIDE * (size_t)tri);
                     const float4 ab = tu[0], cz = tu[1]; // two 16-byte requests (the record is padded to 32 bytes)
                     uv = (1.f - bu - bv) * v2(ab.x, ab.y) + bu * v2(ab.z, ab.w) + bv * v2(cz.x, cz.y);

@@ -131,7 +131,7 @@ def test_save_load_round_trip(prepared, tmp_path):
     b2 = back.bvh()
     for k in ("nodes", "tris", "instances", "frame"):
         assert np.array_equal(bvh[k], b2[k]), k
-    for k in ("root", "n_top_nodes", "stack_need", "n_instances", "two_level"):
+    for k in ("root", "n_top_nodes", "stack_need", "n_instances", "two_level", "world_inst"):
         assert bvh[k] == b2[k], k
     back.close()
     with open(path, "r+b") as f:  # a damaged header must be refused, not crash
