@@ -28,6 +28,7 @@
 #include "bvh_device.h"
 #include "crt_types.h"
 #include "kernels.h"
+#include "lbvh.h"
 #include "wavefront.h"
 
 using namespace crt;
@@ -661,10 +662,11 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         // the world-space ray anyway, so the hits are the same bit for bit). A ray then no longer walks a TLAS down
         // to an instance box that covers the whole scene, enters it and starts again at the BLAS root: it walks
         // one tree in which the plants sit where they stand, and the entry / exit steps of the big instance are gone.
-        // (Host-built meshes only: with CRT_HIP_BUILD=device every mesh keeps its BLAS and its own frame.)
+        // A mesh that was built on the device arrives quantised in its own frame: its boxes are read back from the
+        // 16-bit form for the cut, and its nodes re-quantised (outward again) into the top-level frame.
         int32_t world_inst = -1;
         uint32_t world_mesh = 0xffffffffu;
-        if (two_level && build_device < 0 && max_leaf <= 7 && !std::getenv("CRT_HIP_NO_GRAFT")) {
+        if (two_level && max_leaf <= 7 && !std::getenv("CRT_HIP_NO_GRAFT")) {
             std::vector<uint32_t> mesh_refs(s->n_meshes, 0);
             for (uint32_t i = 0; i < s->n_instances; ++i) {
                 ++mesh_refs[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
@@ -870,8 +872,26 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             std::vector<Aabb> items;
             std::vector<int32_t> item_ref; // what the leaf of an item becomes: a reference local to the grafted BLAS, or an instance leaf
             std::vector<uint8_t> item_is_cut;
+            if (world_inst >= 0 && std::getenv("CRT_HIP_GRAFT_QNODES") && built_q[world_mesh].empty()) {
+                // (test hook: hand the host-built mesh over in the quantised form a device build delivers, so the CPU
+                // tests reach the read-back / re-quantise path below without a GPU)
+                for (const BvhNode &nd : built[world_mesh].nodes) {
+                    built_q[world_mesh].push_back(quantise(nd, blas_frame[world_mesh]));
+                }
+                built[world_mesh].nodes.clear();
+            }
+            const QFrame world_frame_in = world_inst >= 0 ? blas_frame[world_mesh] : QFrame{}; // the frame its quantised nodes are in
+            auto dequantised = [&](const QChild &c) {
+                Aabb b;
+                for (int a = 0; a < 3; ++a) {
+                    b.lo[a] = world_frame_in.base[a] + (float)c.q[a][0] * world_frame_in.step[a];
+                    b.hi[a] = world_frame_in.base[a] + (float)c.q[a][1] * world_frame_in.step[a];
+                }
+                return b;
+            };
             if (world_inst >= 0) {
                 const std::vector<BvhNode> &wn = built[world_mesh].nodes;
+                const std::vector<QNode> &wq = built_q[world_mesh];
                 double inst_area = 0.0; // mean half surface area of the other instances' boxes
                 for (uint32_t i = 0; i < s->n_instances; ++i) {
                     if ((int32_t)i != world_inst) {
@@ -889,20 +909,29 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 std::priority_queue<CutEntry> open; // inner nodes that may still be opened, largest first
                 std::vector<CutEntry> cut;
                 auto add_children = [&](int32_t node) {
-                    const BvhNode &nd = wn[(size_t)node];
                     for (int k = 0; k < BVH_WIDTH; ++k) {
-                        if (nd.c[k] == EMPTY_CHILD) {
-                            continue;
-                        }
                         CutEntry e;
-                        for (int a = 0; a < 3; ++a) {
-                            e.box.lo[a] = nd.lo[k][a];
-                            e.box.hi[a] = nd.hi[k][a];
+                        if (!wq.empty()) {
+                            const QChild &c = wq[(size_t)node].child[k];
+                            if (c.q[0][0] > c.q[0][1]) { // unused slot
+                                continue;
+                            }
+                            e.box = dequantised(c);
+                            e.ref = c.ref;
+                        } else {
+                            const BvhNode &nd = wn[(size_t)node];
+                            if (nd.c[k] == EMPTY_CHILD) {
+                                continue;
+                            }
+                            for (int a = 0; a < 3; ++a) {
+                                e.box.lo[a] = nd.lo[k][a];
+                                e.box.hi[a] = nd.hi[k][a];
+                            }
+                            e.ref = nd.c[k];
                         }
                         const double dx = (double)e.box.hi[0] - e.box.lo[0], dy = (double)e.box.hi[1] - e.box.lo[1],
                                      dz = (double)e.box.hi[2] - e.box.lo[2];
                         e.area = dx * dy + dy * dz + dz * dx;
-                        e.ref = nd.c[k];
                         if (e.ref >= 0) {
                             open.push(e);
                         } else {
@@ -990,6 +1019,14 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             }
             if (world_inst >= 0) {
                 blas_frame[world_mesh] = root_frame; // its nodes are reached from the top-level tree without a frame change
+                for (QNode &q : built_q[world_mesh]) { // device-built: from its own frame into that one, outward again
+                    for (int k = 0; k < BVH_WIDTH; ++k) {
+                        QChild &c = q.child[k];
+                        if (c.q[0][0] <= c.q[0][1]) {
+                            lbvh_quantise_child(c, dequantised(c), c.ref, root_frame);
+                        }
+                    }
+                }
             }
             n_top = tlas.n_top;
         }

@@ -78,6 +78,15 @@ def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkey
     ps = PreparedScene(sc)
     plain = ps.bvh()
     ps.close()
+    monkeypatch.delenv("CRT_HIP_NO_GRAFT")
+    # a mesh built on the device arrives quantised in its own frame; the hook hands the host-built mesh over in
+    # that form, so the read-back of its boxes and the re-quantisation into the top-level frame run here too
+    monkeypatch.setenv("CRT_HIP_GRAFT_QNODES", "1")
+    ps = PreparedScene(sc)
+    via_q = ps.bvh()
+    ps.close()
+    monkeypatch.delenv("CRT_HIP_GRAFT_QNODES")
+    assert via_q["world_inst"] == 0 and via_q["nodes"].shape == bvh["nodes"].shape
     assert plain["world_inst"] == -1 and bvh["world_inst"] == 0 and bvh["two_level"]
     nodes = bvh["nodes"].reshape(-1, 4, 4)
     refs = nodes[:, :, 3].astype(np.uint32).view(np.int32)
@@ -109,6 +118,11 @@ def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkey
     hit = a["inst"] >= 0
     assert (a["inst"][hit] == 0).any() and (a["inst"][hit] > 0).any()
     assert np.array_equal(a["t"][hit].view(np.uint32), b["t"][hit].view(np.uint32))
+    q = oracle.walk_product_bvh(via_q, org, dirs, 0.0, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(q[k], b[k]), k
+    assert np.array_equal(q["t"][hit].view(np.uint32), b["t"][hit].view(np.uint32))
+    assert a["nodes"] <= q["nodes"] <= 1.05 * a["nodes"]  # boxes rounded outward a second time: a few more visits
     # rays leaving surfaces (what four of five bounces and every occlusion ray are)
     p = (org[hit] + dirs[hit] * a["t"][hit, None]).astype(np.float32)
     d2 = np.random.default_rng(8).normal(size=p.shape).astype(np.float32)
