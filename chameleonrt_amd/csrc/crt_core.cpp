@@ -160,6 +160,10 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
 }
 
 constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // kernels.h
+// Scenes with several instances whose triangles fit the budget get a world tree unless CRT_HIP_LEVELS says otherwise.
+#ifndef CRT_WORLD_TREE_DEFAULT
+#define CRT_WORLD_TREE_DEFAULT 0
+#endif
 
 } // namespace
 
@@ -618,6 +622,26 @@ struct crt_hip_prepared_scene {
 
 namespace {
 
+// World tree or two levels for a scene with several instances (crt_types.h LEVELS_WORLD_TREE)? Read per call, so a
+// process can prepare scenes both ways (tests).
+bool world_tree_wanted(uint64_t instanced_tris)
+{
+    const char *levels = std::getenv("CRT_HIP_LEVELS");
+    if (levels != nullptr && std::strcmp(levels, "two") == 0) {
+        return false;
+    }
+    if (instanced_tris >= (1u << 28)) { // the leaf reference has 28 bits
+        return false;
+    }
+    if (levels != nullptr && std::strcmp(levels, "world") == 0) {
+        return true;
+    }
+    // ~95 bytes per triangle (record, uv record, its share of the nodes): 2^27 triangles are 12.7 GB of a 288 GB part
+    const char *cap = std::getenv("CRT_HIP_WORLD_TREE_MAX_TRIS");
+    const uint64_t budget = cap != nullptr ? std::strtoull(cap, nullptr, 10) : (1ull << 27);
+    return CRT_WORLD_TREE_DEFAULT && instanced_tris <= budget;
+}
+
 // build_device >= 0: meshes large enough to be worth it get their BLAS from the device builder
 // (bvh_device.hip) on that HIP device; -1: the host SAH builder for everything.
 void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads, int build_device = -1)
@@ -640,7 +664,19 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         std::vector<TriRec> &tris = ps->tris;
         std::vector<float> &tri_uvs = ps->tri_uvs;
         // one BLAS per Mesh (embree_utils.cpp:63-76)
-        const bool two_level = s->n_instances > 1;
+        // Several instances: either a top-level tree over instances (two-level traversal, what Embree does:
+        // embree_utils.cpp:90-129), or -- when the instanced triangles fit a memory budget, which on a 288 GB part is
+        // nearly always -- ONE tree in world space over per-instance copies of the triangle records (crt_types.h
+        // LEVELS_WORLD_TREE). CRT_HIP_LEVELS=two|world overrides the choice.
+        uint64_t instanced_tris = 0;
+        for (uint32_t i = 0; i < s->n_instances; ++i) {
+            const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
+            for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                instanced_tris += s->geometries[md.first_geometry + k].n_triangles;
+            }
+        }
+        const bool world_tree = s->n_instances > 1 && world_tree_wanted(instanced_tris);
+        const bool two_level = s->n_instances > 1 && !world_tree;
         std::vector<QFrame> blas_frame(s->n_meshes);
         std::vector<int32_t> blas_root(s->n_meshes);
         std::vector<Aabb> blas_bounds(s->n_meshes);
@@ -700,7 +736,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 }
             }
         };
-        for (uint32_t m = 0; m < s->n_meshes; ++m) {
+        for (uint32_t m = 0; m < s->n_meshes && !world_tree; ++m) {
             const crt_mesh_desc &md = s->meshes[m];
             if (build_device >= 0) {
                 DeviceBuiltMesh db;
@@ -817,6 +853,9 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
                 material_ids.push_back(id | (textured ? MATERIAL_TEXTURED : 0u));
             }
             insts[i] = r;
+            if (world_tree) {
+                continue; // no instance boxes: the tree is built over the triangles (below)
+            }
             const Aabb &mb = blas_bounds[pm.mesh_id];
             Aabb wb;
             for (int a = 0; a < 3; ++a) {
@@ -867,6 +906,95 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         uint32_t n_top = 0;
         int32_t root = 0;
         QFrame root_frame{};
+        if (world_tree) {
+            // One record + one world-space box per (instance, triangle). The record is the mesh's own (object space: the
+            // triangle test runs there, with the ray transformed like the reference transforms it, so t / u / v come out
+            // bit for bit as in the two-level walk); the box bounds the transformed vertices, padded like an instance box
+            // (the test ray is a rounded transform of the world ray) -- and quantisation rounds outward by >= 1 quantum
+            // of the scene's extent on top of that.
+            std::vector<TriRec> recs;
+            std::vector<Aabb> boxes;
+            recs.reserve(instanced_tris);
+            boxes.reserve(instanced_tris);
+            for (uint32_t i = 0; i < s->n_instances; ++i) {
+                const crt_instance_desc &id = s->instances[i];
+                const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
+                const float *m = id.transform;
+                const bool ident = insts[i].identity != 0u;
+                auto to_world = [&](const float *p, int a) {
+                    return ident ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
+                };
+                float pad = 0.f;
+                if (!ident) {
+                    Aabb wb;
+                    for (int a = 0; a < 3; ++a) {
+                        wb.lo[a] = INFINITY;
+                        wb.hi[a] = -INFINITY;
+                    }
+                    for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                        const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
+                        for (uint64_t v = 0; v < gd.n_vertices; ++v) {
+                            for (int a = 0; a < 3; ++a) {
+                                const float w = to_world(gd.vertices + 3 * v, a);
+                                wb.lo[a] = std::min(wb.lo[a], w);
+                                wb.hi[a] = std::max(wb.hi[a], w);
+                            }
+                        }
+                    }
+                    pad = 1e-5f * std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
+                    if (!(pad >= 0.f)) { // an instance without vertices that any triangle uses
+                        pad = 0.f;
+                    }
+                }
+                for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                    const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
+                    for (uint64_t t = 0; t < gd.n_triangles; ++t) {
+                        const float *v[3] = {gd.vertices + 3 * (size_t)gd.indices[3 * t], gd.vertices + 3 * (size_t)gd.indices[3 * t + 1],
+                                             gd.vertices + 3 * (size_t)gd.indices[3 * t + 2]};
+                        TriRec r;
+                        Aabb b;
+                        for (int a = 0; a < 3; ++a) {
+                            r.v0[a] = v[0][a];
+                            r.e1[a] = v[0][a] - v[1][a];
+                            r.e2[a] = v[2][a] - v[0][a];
+                            const float w0 = to_world(v[0], a), w1 = to_world(v[1], a), w2 = to_world(v[2], a);
+                            b.lo[a] = std::min(w0, std::min(w1, w2)) - pad;
+                            b.hi[a] = std::max(w0, std::max(w1, w2)) + pad;
+                        }
+                        r.geom = k;
+                        r.prim = (uint32_t)t;
+                        r.pad = (i << 1) | (ident ? 1u : 0u);
+                        recs.push_back(r);
+                        boxes.push_back(b);
+                    }
+                }
+            }
+            if (recs.empty()) {
+                throw std::runtime_error("scene without triangles");
+            }
+            const int wt_leaf = std::min(max_leaf, 2); // the kernels' world-tree leaf step handles one or two triangles
+            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), wt_leaf, MAX_TOP_NODES_HOST)
+                                      : build_bvh(boxes.data(), boxes.size(), wt_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
+            boxes = std::vector<Aabb>();
+            blas_depth = tree.max_depth;
+            tris.resize(recs.size());
+            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
+            for (size_t i = 0; i < recs.size(); ++i) {
+                const TriRec &r = recs[tree.order[i]];
+                const crt_instance_desc &id = s->instances[r.pad >> 1];
+                place_tri(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
+            }
+            root_frame = make_frame(tree.bounds);
+            nodes.reserve(tree.nodes.size());
+            for (const BvhNode &nd : tree.nodes) {
+                nodes.push_back(quantise(nd, root_frame));
+            }
+            n_top = tree.n_top;
+            root = 0;
+            for (InstanceRec &r : insts) {
+                r.frame = root_frame; // not read by the traversal of a world tree; blas_root stays a mesh id until the loop below
+            }
+        }
         if (two_level) {
             // items of the top-level tree: the cut through the grafted mesh's BLAS (if any), then one box per other instance
             std::vector<Aabb> items;
@@ -1067,13 +1195,13 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
             throw std::runtime_error("too many triangles for the 28-bit leaf reference");
         }
         for (InstanceRec &r : insts) {
-            r.blas_root = blas_root[r.blas_root];
+            r.blas_root = world_tree ? 0 : blas_root[r.blas_root];
         }
         if (world_inst >= 0) {
             insts[(size_t)world_inst].blas_root = 0; // never entered: its subtrees hang in the top-level tree (node 0 = its root)
         }
         ps->world_inst = world_inst;
-        if (!two_level) {
+        if (!two_level && !world_tree) {
             const uint32_t mesh0 = s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id;
             root = insts[0].blas_root;
             n_top = blas_top[mesh0];
@@ -1166,7 +1294,7 @@ void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_th
         phase("textures");
         ps->root_frame = root_frame;
         ps->root = root;
-        ps->two_level = two_level ? 1u : 0u;
+        ps->two_level = world_tree ? LEVELS_WORLD_TREE : two_level ? 1u : 0u;
         ps->n_top = n_top;
         ps->n_lights = s->n_lights;
         ps->n_instances = s->n_instances;
@@ -1209,7 +1337,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     sv.n_instances = ps.n_instances;
     // HBM part of the per-lane traversal stack: what the deepest path can need beyond the LDS part,
     // [wave of the persistent grid][depth][lane]
-    const uint32_t lds_stack = traversal_lds_stack(ps.two_level != 0);
+    const uint32_t lds_stack = traversal_lds_stack(ps.two_level);
     sv.spill_depth = std::max<uint32_t>(8u, ps.stack_need > lds_stack ? ps.stack_need - lds_stack : 0u);
     sv.spill_stride = traversal_grid_threads(ctx->n_cus);
     const size_t spill_words = (size_t)sv.spill_stride * sv.spill_depth;
@@ -1370,7 +1498,7 @@ int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *ps, uint32_t samples_
 }
 
 int crt_hip_child_order(void) { return traversal_child_order(); }
-uint32_t crt_hip_lds_stack_entries(int two_level) { return traversal_lds_stack(two_level != 0); }
+uint32_t crt_hip_lds_stack_entries(int two_level) { return traversal_lds_stack((uint32_t)two_level); }
 
 int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *path)
 {
@@ -1913,7 +2041,7 @@ int crt_hip_bvh_layout(crt_hip_ctx *ctx, int32_t *root, uint32_t *n_top_nodes, u
             *stack_need = ctx->stack_need;
         }
         if (lds_stack) {
-            *lds_stack = traversal_lds_stack(ctx->sv.two_level != 0);
+            *lds_stack = traversal_lds_stack(ctx->sv.two_level);
         }
         if (child_order) {
             *child_order = traversal_child_order();

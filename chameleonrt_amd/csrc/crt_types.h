@@ -65,7 +65,8 @@ static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 // Geometry in its Mesh), prim = Embree primID (triangle index in that Geometry).
 struct alignas(16) TriRec {
     float v0[3], e1[3], e2[3];
-    uint32_t geom, prim, pad;
+    uint32_t geom, prim;
+    uint32_t pad; // 0, except in a world tree (LEVELS_WORLD_TREE below): (instance << 1) | 1 if its transform is the identity
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
@@ -134,13 +135,23 @@ struct SceneView {
     uint32_t n_instances;
     QFrame root_frame;            // frame of the BVH `root` belongs to
     int32_t root;                 // TLAS root (two-level) or the single BLAS root
-    uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly
+    uint32_t two_level;           // 0: exactly one instance, traverse its BLAS directly; 1: top-level tree over instances;
+                                  // LEVELS_WORLD_TREE: one tree over the triangles of all instances, in world space
     int32_t world_inst;           // two level: the instance whose triangles sit in the top-level tree itself, or -1
     uint32_t n_top_nodes;         // nodes [root, root + n_top_nodes) are the BFS-ordered top levels
     int32_t *stack_spill;         // traversal-stack overflow slab, [wave of the persistent grid][depth][lane]
     uint32_t spill_stride;        // threads the slab was sized for
     uint32_t spill_depth;         // entries per lane in the slab (sized at set_scene from the depth of this scene's BVH)
 };
+
+// SceneView::two_level == LEVELS_WORLD_TREE ("world tree"): the scene has several instances, but memory is not what an
+// MI355X is short of (288 GB): every instance gets triangle records of its own -- still in ITS object space, with
+// TriRec::pad = (instance << 1) | identity -- and ONE tree is built over all of them from the boxes of their
+// transformed vertices. A ray walks that tree in world space from start to end (no instance entry, no second root,
+// no frame change, no exit) and is transformed into an instance's object space only to test a triangle of it, with
+// the two-level entry's expressions, so hits are bit-identical to the two-level walk and to the reference's
+// per-instance intersection. crt_core.cpp decides per scene (memory budget); traverse.h INST_TRIS.
+constexpr uint32_t LEVELS_WORLD_TREE = 2u;
 
 constexpr uint32_t MATERIAL_TEXTURED = 0x80000000u; // flag on the entries of SceneView::material_ids (and HitBuf::mat)
 constexpr int TRI_UV_STRIDE = 8;      // floats per triangle in SceneView::tri_uvs

@@ -28,7 +28,7 @@ struct LaunchCfg {
 
 // Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).
 uint32_t traversal_grid_threads(int n_cus);
-uint32_t traversal_lds_stack(bool two_level); // per-lane stack entries kept in LDS; deeper ones go to the HBM slab
+uint32_t traversal_lds_stack(uint32_t levels); // per-lane stack entries kept in LDS; deeper ones go to the HBM slab
 int traversal_child_order();    // the build's CRT_CHILD_ORDER (the oracle's BVH walker mirrors the rule)
 
 // K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.

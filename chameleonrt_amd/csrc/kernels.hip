@@ -192,11 +192,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 }
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
-template <bool TWO_LEVEL> struct TraceLds {
+template <bool TWO_LEVEL, bool INST_TRIS = false> struct TraceLds {
     QNode top[(TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : MAX_TOP_NODES) + 1];
-    int32_t stack[lds_stack_of(TWO_LEVEL)][TRACE_BLOCK];
+    int32_t stack[lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
     // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
-    float cold[TWO_LEVEL ? 10 : 1][TRACE_BLOCK];
+    // world tree: the ray in the object space of the instance whose triangle the lane tested last
+    float cold[lds_cold_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
 };
 
 template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, Lds &lds)
@@ -249,13 +250,13 @@ struct ClosestSource {
     }
 };
 
-template <bool TWO_LEVEL, bool COUNTERS>
+template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
-    __shared__ TraceLds<TWO_LEVEL> lds;
+    __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -265,9 +266,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0;
     const ClosestSource src{q, hits, sc.tris, sc.instances, sc.material_ids};
-    trace_wavefront<false, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src,
-                                                n_nodes, n_tris, &pc->max_ray_nodes, pc->worst_ray, &pc->t_start[bounce],
-                                                &pc->prof_cycles[0][0]);
+    trace_wavefront<false, TWO_LEVEL, COUNTERS, ClosestSource, INST_TRIS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce],
+                                                                          tnear, src, n_nodes, n_tris, &pc->max_ray_nodes,
+                                                                          pc->worst_ray, &pc->t_start[bounce], &pc->prof_cycles[0][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
@@ -332,13 +333,13 @@ struct ShadowSource {
     }
 };
 
-template <bool TWO_LEVEL, bool COUNTERS>
+template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
-    __shared__ TraceLds<TWO_LEVEL> lds;
+    __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -346,8 +347,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const ShadowSource src{sa, sb, radiance};
-    trace_wavefront<true, TWO_LEVEL, COUNTERS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS,
-                                               src, n_nodes, n_tris, nullptr, nullptr, nullptr, &pc->prof_cycles[1][0]);
+    trace_wavefront<true, TWO_LEVEL, COUNTERS, ShadowSource, INST_TRIS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce],
+                                                                        RAY_EPS, src, n_nodes, n_tris, nullptr, nullptr, nullptr,
+                                                                        &pc->prof_cycles[1][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
@@ -730,16 +732,16 @@ template <bool ANY_HIT> struct DiagSource {
 
 // counters: [0] nodes, [1] triangles, [2] low word = ray cursor. tmin must be uniform over the
 // batch (as it is inside a frame: 0 for primary rays, EPSILON afterwards).
-template <bool ANY_HIT, bool TWO_LEVEL>
+template <bool ANY_HIT, bool TWO_LEVEL, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32_t n, const float *org,
                                                             const float *dir, float tmin, const float *tmax,
                                                             float *out_t, float *out_u, float *out_v,
                                                             int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
                                                             unsigned long long *counters)
 {
-    __shared__ TraceLds<TWO_LEVEL> lds;
+    __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const QNode *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(TWO_LEVEL)> st;
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
@@ -747,8 +749,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0;
     const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
-    trace_wavefront<ANY_HIT, TWO_LEVEL, true>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]), tmin, src,
-                                              n_nodes, n_tris);
+    trace_wavefront<ANY_HIT, TWO_LEVEL, true, DiagSource<ANY_HIT>, INST_TRIS>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]),
+                                                                              tmin, src, n_nodes, n_tris);
     atomicAdd(&counters[0], (unsigned long long)n_nodes);
     atomicAdd(&counters[1], (unsigned long long)n_tris);
 }
@@ -878,7 +880,7 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 
 // ---- launchers ---------------------------------------------------------------------------------
 uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
-uint32_t traversal_lds_stack(bool two_level) { return (uint32_t)lds_stack_of(two_level); }
+uint32_t traversal_lds_stack(uint32_t levels) { return (uint32_t)lds_stack_of((int)levels); }
 int traversal_child_order() { return CRT_CHILD_ORDER; }
 
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
@@ -900,28 +902,30 @@ void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *t
     k_raygen<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(vp, tile_ids, slot0, n_paths, chunk, q, radiance, pc);
 }
 
-template <typename... Args> static void launch4(bool two_level, bool counters, void (*k00)(Args...),
-                                                void (*k01)(Args...), void (*k10)(Args...), void (*k11)(Args...),
-                                                int grid, hipStream_t stream, Args... args)
+// SceneView::two_level: 0 = one instance, 1 = two-level traversal, 2 = one tree in world space whose triangles carry
+// their instance (LEVELS_WORLD_TREE, crt_types.h)
+template <typename... Args> static void launch6(uint32_t levels, bool counters, void (*k00)(Args...), void (*k01)(Args...),
+                                                void (*k10)(Args...), void (*k11)(Args...), void (*k20)(Args...),
+                                                void (*k21)(Args...), int grid, hipStream_t stream, Args... args)
 {
-    auto k = two_level ? (counters ? k11 : k10) : (counters ? k01 : k00);
+    auto k = levels == LEVELS_WORLD_TREE ? (counters ? k21 : k20) : levels != 0 ? (counters ? k11 : k10) : (counters ? k01 : k00);
     k<<<grid, TRACE_BLOCK, 0, stream>>>(args...);
 }
 
 void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q, HitBuf hits, PassCounters *pc,
                           int bounce)
 {
-    launch4(sc.two_level != 0, cfg.counters, k_trace_closest<false, false>, k_trace_closest<false, true>,
-            k_trace_closest<true, false>, k_trace_closest<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, q,
-            hits, pc, bounce);
+    launch6(sc.two_level, cfg.counters, k_trace_closest<false, false>, k_trace_closest<false, true>, k_trace_closest<true, false>,
+            k_trace_closest<true, true>, k_trace_closest<false, false, true>, k_trace_closest<false, true, true>,
+            persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, q, hits, pc, bounce);
 }
 
 void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
                          float4 *radiance, PassCounters *pc, int bounce)
 {
-    launch4(sc.two_level != 0, cfg.counters, k_trace_shadow<false, false>, k_trace_shadow<false, true>,
-            k_trace_shadow<true, false>, k_trace_shadow<true, true>, persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa,
-            sb, radiance, pc, bounce);
+    launch6(sc.two_level, cfg.counters, k_trace_shadow<false, false>, k_trace_shadow<false, true>, k_trace_shadow<true, false>,
+            k_trace_shadow<true, true>, k_trace_shadow<false, false, true>, k_trace_shadow<false, true, true>,
+            persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa, sb, radiance, pc, bounce);
 }
 
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
@@ -953,27 +957,13 @@ void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, co
                        int32_t *out_inst, int32_t *out_geom, int32_t *out_prim, unsigned long long *counters)
 {
     const int grid = persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU);
-    if (closest) {
-        if (sc.two_level) {
-            k_trace_diag<false, true><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
-                                                                            out_v, out_inst, out_geom, out_prim,
-                                                                            counters);
-        } else {
-            k_trace_diag<false, false><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
-                                                                             out_v, out_inst, out_geom, out_prim,
-                                                                             counters);
-        }
-    } else {
-        if (sc.two_level) {
-            k_trace_diag<true, true><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
-                                                                           out_v, out_inst, out_geom, out_prim,
-                                                                           counters);
-        } else {
-            k_trace_diag<true, false><<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u,
-                                                                            out_v, out_inst, out_geom, out_prim,
-                                                                            counters);
-        }
-    }
+    auto k = closest ? (sc.two_level == LEVELS_WORLD_TREE ? k_trace_diag<false, false, true>
+                        : sc.two_level               ? k_trace_diag<false, true>
+                                                     : k_trace_diag<false, false>)
+                     : (sc.two_level == LEVELS_WORLD_TREE ? k_trace_diag<true, false, true>
+                        : sc.two_level               ? k_trace_diag<true, true>
+                                                     : k_trace_diag<true, false>);
+    k<<<grid, TRACE_BLOCK, 0, cfg.stream>>>(sc, n, org, dir, tmin, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim, counters);
 }
 
 int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,

@@ -28,7 +28,15 @@ namespace crt {
 #ifndef CRT_LDS_STACK_TWO_LEVEL
 #define CRT_LDS_STACK_TWO_LEVEL 15
 #endif
-constexpr int lds_stack_of(bool two_level) { return two_level ? CRT_LDS_STACK_TWO_LEVEL : CRT_LDS_STACK; }
+// the kernels of a world tree (INST_TRIS below) keep the world-space ray in LDS next to the stack, like the two-level
+// ones: six dwords per lane, paid for with two stack entries (26 KB per block)
+#ifndef CRT_LDS_STACK_WORLD_TREE
+#define CRT_LDS_STACK_WORLD_TREE 14
+#endif
+// levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
+constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
+constexpr int lds_cold_of(int levels) { return levels == 1 ? 10 : levels == 2 ? 6 : 1; } // dwords of cold per-ray state per lane in LDS
+constexpr int levels_of(bool two_level, bool inst_tris) { return two_level ? 1 : inst_tris ? 2 : 0; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
 // and compact per wave, so deep traversals stay within a few pages. Its depth is a property of the
 // scene (SceneView::spill_depth, sized at set_scene from the BVH's depth), not a compile-time limit.
@@ -196,8 +204,15 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 //        lane a follow-up ray of the same item (o, d, tfar, stage updated): the two NEE occlusion
 //        rays of one hit are traced back to back by one lane, which costs nothing in a wave whose
 //        lanes are refilled independently.
-template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source>
-CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack<lds_stack_of(TWO_LEVEL)> &st, uint32_t n,
+//
+// INST_TRIS (with TWO_LEVEL = false): the scene has several instances but ONE tree over all of them in world space
+// (crt_core.cpp "world tree": every instance's triangles have records of their own, boxes around the transformed
+// vertices). Boxes are walked with the world-space ray and never change frame; a triangle record's last word says
+// whose it is, (instance << 1) | identity, and the triangle is tested -- like the reference's Embree instance -- with
+// the ray transformed into that instance's object space (same expressions as the two-level entry, so the same bits),
+// which the lane keeps until a triangle of another instance comes along.
+template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source, bool INST_TRIS = false>
+CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
@@ -227,13 +242,13 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     // VGPRs fewer is the difference between 5 and 6 resident waves per SIMD for the two-level kernels.
     V3 org_r = v3(0.f), dir_r = v3(0.f);
     auto world_org = [&]() -> V3 {
-        return TWO_LEVEL ? v3(st.cold[0], st.cold[st.stride], st.cold[2 * st.stride]) : org_r;
+        return (TWO_LEVEL || INST_TRIS) ? v3(st.cold[0], st.cold[st.stride], st.cold[2 * st.stride]) : org_r;
     };
     auto world_dir = [&]() -> V3 {
-        return TWO_LEVEL ? v3(st.cold[3 * st.stride], st.cold[4 * st.stride], st.cold[5 * st.stride]) : dir_r;
+        return (TWO_LEVEL || INST_TRIS) ? v3(st.cold[3 * st.stride], st.cold[4 * st.stride], st.cold[5 * st.stride]) : dir_r;
     };
     auto set_world = [&](V3 wo, V3 wd) {
-        if (TWO_LEVEL) {
+        if (TWO_LEVEL || INST_TRIS) {
             st.cold[0] = wo.x;
             st.cold[st.stride] = wo.y;
             st.cold[2 * st.stride] = wo.z;
@@ -278,6 +293,12 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     };
     int32_t cur_inst = TWO_LEVEL ? sc.world_inst : 0;
     bool in_blas = !TWO_LEVEL;
+    static_assert(!(INST_TRIS && TWO_LEVEL), "per-triangle instances belong to the single tree in world space");
+    static_assert(!INST_TRIS || CRT_LEAF_V2, "per-triangle instances are implemented in the all-loads-first leaf step");
+    // INST_TRIS: like the two-level kernels, the lane keeps the world-space ray in its cold LDS slots 0..5 and (o, d) is
+    // the ray in the space of the triangle it tested last: xf_space = 1 for world space (every identity instance), else
+    // the tag (instance << 1) of a transformed instance. (Both rays in registers cost the kernels scratch spills.)
+    uint32_t xf_space = 1u;
     st.sp = 0;
     uint32_t stage = 0, carry = 0; // multi-ray items (Source::retire)
     // wave-uniform pool of ray indices
@@ -309,12 +330,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         d = dir;
         cur_inst = TWO_LEVEL ? sc.world_inst : 0; // triangles of the top-level tree belong to the grafted instance
         in_blas = !TWO_LEVEL;
-        if (!TWO_LEVEL) {
+        if (!TWO_LEVEL && !INST_TRIS) {
             const InstanceRec &in = sc.instances[0];
             if (!in.identity) {
                 o = xfm_point(in.w2o, org);
                 d = xfm_vector(in.w2o, dir);
             }
+        }
+        if (INST_TRIS) {
+            xf_space = 1u;
         }
         set_frame(sc.root_frame);
         hit.t = tfar;
@@ -554,7 +578,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 const float4 a0 = p[0], b0 = p[1], c0 = p[2];
                 // (two-level kernels hold more ray state: there the second triangle is fetched after the first
                 // has been tested, which keeps them at 6 waves per SIMD instead of 5)
-                constexpr bool PRELOAD_BOTH = !TWO_LEVEL;
+                constexpr bool PRELOAD_BOTH = !TWO_LEVEL && !INST_TRIS;
                 float4 a1 = a0, b1 = b0, c1 = c0;
                 if (PRELOAD_BOTH && count > 1u) {
                     a1 = p[3];
@@ -566,6 +590,23 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 auto test_one = [&](const float4 a, const float4 b, const float4 c, uint32_t k) {
                     if (COUNTERS) {
                         ++n_tris;
+                    }
+                    if (INST_TRIS) {
+                        const uint32_t tag = __float_as_uint(c.w); // TriRec::pad: (instance << 1) | identity
+                        cur_inst = (int32_t)(tag >> 1);
+                        const uint32_t space = (tag & 1u) != 0u ? 1u : tag;
+                        if (space != xf_space) {
+                            const V3 wo = world_org(), wd = world_dir();
+                            if (space == 1u) {
+                                o = wo;
+                                d = wd;
+                            } else { // the two-level entry's expressions: same bits as entering the instance
+                                const InstanceRec &in = sc.instances[tag >> 1];
+                                o = xfm_point(in.w2o, wo);
+                                d = xfm_vector(in.w2o, wd);
+                            }
+                            xf_space = space;
+                        }
                     }
                     float t, u, v;
                     if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
@@ -597,7 +638,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     }
                     test_one(a1, b1, c1, first + 1u);
                 }
-                for (uint32_t k = first + 2u; k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of > 2 (CRT_BVH_MAX_LEAF)
+                // (a world tree is built with leaves of <= 2, whatever CRT_BVH_MAX_LEAF says: one inlined copy less of the test)
+                for (uint32_t k = first + 2u; !INST_TRIS && k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of > 2 (CRT_BVH_MAX_LEAF)
                     const float4 *pk = reinterpret_cast<const float4 *>(sc.tris + k);
                     test_one(pk[0], pk[1], pk[2], k);
                 }

@@ -133,7 +133,7 @@ class RenderHIP:
         insts = np.zeros((ni.value, 32), np.uint32)  # 128-byte instance records
         core.check(self._ctx, self._lib.crt_hip_bvh_copy_instances(self._ctx, insts.ctypes.data_as(C.c_void_p)),
                    "bvh_copy_instances")
-        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
+        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=tl.value == 1, levels=tl.value,
                     frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
                     lds_stack=lds.value, child_order=child_order.value,
                     world_inst=self._lib.crt_hip_world_instance(self._ctx))
@@ -180,7 +180,7 @@ class PreparedScene:
         insts = np.zeros((ni.value, 32), np.uint32)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         assert self._lib.crt_hip_prepared_scene_copy(self.handle, vp(nodes), vp(tris), vp(insts)) == 0
-        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=bool(tl.value),
+        return dict(nodes=nodes, tris=tris, instances=insts, n_instances=ni.value, two_level=tl.value == 1, levels=tl.value,
                     frame=frame, root=root.value, n_top_nodes=n_top.value, stack_need=need.value,
                     child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(int(tl.value)),
                     build_ms=ms.value, world_inst=self._lib.crt_hip_prepared_scene_world_instance(self.handle))

@@ -179,7 +179,12 @@ void crt_hip_free_prepared_scene(crt_hip_prepared_scene *prepared);
 int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *prepared);
 int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *prepared, const char *path);
 /* Introspection of the host-built arrays (no device needed: the CPU tests check the builder and the
- * quantiser this way). Same records as crt_hip_bvh_info / _layout / _copy / _copy_instances below. */
+ * quantiser this way). Same records as crt_hip_bvh_info / _layout / _copy / _copy_instances below.
+ * two_level: 0 = one instance, its BLAS traversed directly; 1 = a top-level tree over the instances (what Embree
+ * builds, embree_utils.cpp:90-129); 2 = a "world tree": ONE tree in world space over per-instance copies of the
+ * triangle records, whose last word is (instance << 1) | identity -- a ray is transformed into an instance's object
+ * space only to test a triangle of it (same hits bit for bit; chosen when the instanced triangles fit a memory
+ * budget, CRT_HIP_LEVELS=two|world overrides; chameleonrt_amd/csrc/crt_types.h LEVELS_WORLD_TREE). */
 int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *prepared, uint64_t *n_nodes, uint64_t *n_tris,
                                 uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
                                 uint32_t *n_top_nodes, uint32_t *stack_need, double *build_ms);
@@ -194,7 +199,7 @@ int crt_hip_child_order(void); /* the build's CRT_CHILD_ORDER (see crt_hip_bvh_l
  * instance, any other leaf holds triangles of that instance. */
 int32_t crt_hip_prepared_scene_world_instance(const crt_hip_prepared_scene *prepared);
 int32_t crt_hip_world_instance(crt_hip_ctx *ctx); /* the same of the scene the context holds */
-uint32_t crt_hip_lds_stack_entries(int two_level); /* per-lane traversal-stack entries kept in LDS (single- / two-level kernels); deeper ones live in HBM */
+uint32_t crt_hip_lds_stack_entries(int two_level); /* per-lane traversal-stack entries kept in LDS by the kernels of that kind of scene (0 / 1 / 2 as above); deeper ones live in HBM */
 crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
 
 /* One frame. fovy in degrees; camera_changed resets accumulation (frame_id = 0). When

@@ -1852,18 +1852,21 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                                     uint64_t n, const float *org, const float *dir, const float *tmin,
                                     const float *tmax, int closest, uint64_t *nodes_visited, uint64_t *tris_tested,
                                     uint32_t *max_stack, float *out_t, int32_t *out_inst, int32_t *out_geom,
-                                    int32_t *out_prim)
+                                    int32_t *out_prim, uint64_t *inst_entries, int levels)
 {
     const FNode *nodes = static_cast<const FNode *>(nodes_);
     const FTri *tris = static_cast<const FTri *>(tris_);
     const FInst *insts = static_cast<const FInst *>(instances_);
-    const bool two_level = insts != nullptr && n_instances > 1;
+    // levels (the product's SceneView::two_level): 0 one instance, 1 top-level tree over instances, 2 one tree in world
+    // space whose triangle records carry (instance << 1) | identity in their last word; < 0: 0 or 1 by instance count
+    const bool world_tree = levels == 2 && insts != nullptr;
+    const bool two_level = !world_tree && (levels < 0 ? insts != nullptr && n_instances > 1 : levels == 1);
     const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0);
+    std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0), ne_t(nthreads, 0), nb_t(nthreads, 0);
     std::vector<uint32_t> ms_t(nthreads, 0);
     std::vector<int> bad_t(nthreads, 0);
     auto work = [&](int tid) {
-        uint64_t nv = 0, tt = 0;
+        uint64_t nv = 0, tt = 0, ne = 0, nb = 0;
         uint32_t ms = 0;
         std::vector<int32_t> stack(1024);
         for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
@@ -1878,8 +1881,10 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                 qb = mk3((fr[0] - o.x) * inv.x, (fr[1] - o.y) * inv.y, (fr[2] - o.z) * inv.z);
             };
             int32_t cur_inst = 0;
+            f3 xo = worg, xd = wdir;
+            uint32_t xf_tag = 0xffffffffu;
             bool in_blas = !two_level;
-            if (!two_level && insts != nullptr && !insts[0].identity) {
+            if (!two_level && !world_tree && insts != nullptr && !insts[0].identity) {
                 o = fxfm_point(insts[0].w2o, worg);
                 d = fxfm_vector(insts[0].w2o, wdir);
             }
@@ -1894,6 +1899,9 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                 if (cur >= 0) {
                     const FNode &nd = nodes[cur];
                     ++nv;
+                    if (two_level && in_blas) {
+                        ++nb;
+                    }
                     uint32_t keys[4];
                     int n_hit = 0;
                     for (uint32_t k = 0; k < 4; ++k) {
@@ -1948,6 +1956,7 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                     if (two_level && !in_blas && (x & 7u) == 7u) {
                         const FInst &in = insts[first];
                         cur_inst = (int32_t)first;
+                        ++ne;
                         if (!in.identity) {
                             o = fxfm_point(in.w2o, worg);
                             d = fxfm_vector(in.w2o, wdir);
@@ -1962,8 +1971,23 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                     for (uint32_t k = first; k < first + count; ++k) {
                         ++tt;
                         TriRec tr{tris[k].v0, tris[k].e1, tris[k].e2, tris[k].geom, tris[k].prim};
+                        f3 ro = o, rd = d;
+                        if (world_tree) { // the triangle's own instance; tested in its object space (traverse.h INST_TRIS)
+                            const uint32_t tag = tris[k].pad;
+                            cur_inst = (int32_t)(tag >> 1);
+                            if ((tag & 1u) == 0u) {
+                                if (tag != xf_tag) {
+                                    xo = fxfm_point(insts[tag >> 1].w2o, worg);
+                                    xd = fxfm_vector(insts[tag >> 1].w2o, wdir);
+                                    xf_tag = tag;
+                                    ++ne;
+                                }
+                                ro = xo;
+                                rd = xd;
+                            }
+                        }
                         float t, u, v;
-                        if (tri_test(tr, o, d, tmin[i], tmax[i], t, u, v)) {
+                        if (tri_test(tr, ro, rd, tmin[i], tmax[i], t, u, v)) {
                             if (!closest) {
                                 done = true;
                                 b_tri = 0;
@@ -2017,6 +2041,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         }
         nv_t[tid] = nv;
         tt_t[tid] = tt;
+        ne_t[tid] = ne;
+        nb_t[tid] = nb;
         ms_t[tid] = ms;
     };
     std::vector<std::thread> pool;
@@ -2027,12 +2053,13 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     for (std::thread &t : pool) {
         t.join();
     }
-    uint64_t nv = 0, tt = 0;
+    uint64_t nv = 0, tt = 0, ne = 0;
     uint32_t ms = 0;
     int bad = 0;
     for (int t = 0; t < nthreads; ++t) {
         nv += nv_t[t];
         tt += tt_t[t];
+        ne += ne_t[t];
         ms = std::max(ms, ms_t[t]);
         bad |= bad_t[t];
     }
@@ -2040,6 +2067,17 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     *tris_tested = tt;
     if (max_stack) {
         *max_stack = ms;
+    }
+    if (inst_entries) {
+        *inst_entries = ne;
+    }
+    if (std::getenv("ORC_WALK_SPLIT")) { // development aid (tools/tree_cost.py): node visits inside instances
+        uint64_t nb = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            nb += nb_t[t];
+        }
+        std::fprintf(stderr, "[orc] walk: %.2f node visits per ray inside instances, %.2f in the top-level tree\n", (double)nb / (double)n,
+                     (double)(nv - nb) / (double)n);
     }
     return bad ? -1 : 0;
 }

@@ -87,12 +87,15 @@ int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], fl
  * deepest traversal stack any ray needed, and optionally returns the hits (closest: t / inst / geom /
  * prim, miss = -1 ids and t = tmax; occlusion: out_t = 1 visible, 0 occluded). instances == NULL or
  * n_instances <= 1: single-level walk from `root` (instance 0's transform applied if it is given and
- * not the identity). Outputs other than the two counters may be NULL. */
+ * not the identity). levels = the product's SceneView::two_level (0 one instance, 1 two-level, 2 one tree in world
+ * space whose triangle records carry their instance; < 0: 0 or 1 by instance count). inst_entries: how many times a
+ * ray was transformed into an instance's space. Outputs other than the two counters may be NULL. */
 int orc_walk_foreign_bvh(const void *nodes, const void *tris, const void *instances, uint64_t n_instances,
                          int32_t world_inst, int32_t root, const float root_frame[6], int child_order, uint64_t n, const float *org,
                          const float *dir, const float *tmin, const float *tmax, int closest,
                          uint64_t *nodes_visited, uint64_t *tris_tested, uint32_t *max_stack, float *out_t,
-                         int32_t *out_inst, int32_t *out_geom, int32_t *out_prim);
+                         int32_t *out_inst, int32_t *out_geom, int32_t *out_prim, uint64_t *inst_entries,
+                         int levels);
 
 /* Shading-function KATs, record layouts in include/crt_kat.h. scene may be NULL for the
  * functions that need none. */

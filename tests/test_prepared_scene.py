@@ -63,6 +63,55 @@ def test_instanced_scene_layout(prepared):
 
 
 @pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
+def test_world_tree_of_an_instanced_scene(name, oracle, monkeypatch):
+    """CRT_HIP_LEVELS=world: ONE tree in world space over per-instance copies of the triangle records (crt_types.h
+    LEVELS_WORLD_TREE). Every (instance, triangle) pair has exactly one record, tagged (instance << 1) | identity;
+    the walk -- world-space ray for the boxes, the triangle's instance space for the test -- finds what brute force
+    over the instances finds, bit for bit (ids, t, occlusion), and so what the two-level walk finds, in fewer node
+    visits; leaves hold at most two triangles (the kernels' world-tree leaf step handles no more)."""
+    sc = SCENES[name]()
+    monkeypatch.setenv("CRT_HIP_LEVELS", "two")
+    ps = PreparedScene(sc)
+    two = ps.bvh()
+    ps.close()
+    monkeypatch.setenv("CRT_HIP_LEVELS", "world")
+    monkeypatch.setenv("CRT_BVH_MAX_LEAF", "4")  # read once per process; harmless if a test before this one fixed it at 2
+    ps = PreparedScene(sc)
+    bvh = ps.bvh()
+    ps.close()
+    assert two["levels"] == 1 and bvh["levels"] == 2 and not bvh["two_level"] and bvh["world_inst"] == -1
+    assert bvh["n_instances"] == len(sc.instances) and bvh["root"] == 0
+    tris_of = lambda i: sc.meshes[sc.parameterized_meshes[sc.instances[i].parameterized_mesh_id].mesh_id].num_tris()
+    assert bvh["tris"].shape[0] == sum(tris_of(i) for i in range(len(sc.instances)))
+    tag = bvh["tris"][:, 11].view(np.uint32)
+    per_inst = np.bincount(tag >> 1, minlength=len(sc.instances))
+    assert np.array_equal(per_inst, [tris_of(i) for i in range(len(sc.instances))])
+    ident = np.array([np.array_equal(np.asarray(it.transform, np.float32).reshape(4, 4), np.eye(4, dtype=np.float32))
+                      for it in sc.instances])
+    assert np.array_equal((tag & 1).astype(bool), ident[tag >> 1])
+    refs = bvh["nodes"].reshape(-1, 4, 4)[:, :, 3].astype(np.uint32).view(np.int32)
+    leaves = refs[refs < 0]
+    assert ((~leaves & 7) <= 1).all(), "leaves of one or two triangles"
+    o = oracle.OracleScene(sc)
+    org, dirs = probe_rays(sc, 8000, seed=33)
+    w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    t2 = oracle.walk_product_bvh(two, org, dirs, 0.0, 1e20, closest=True)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w[k], c[k]), k
+        assert np.array_equal(w[k], t2[k]), k
+    hit = c["inst"] >= 0
+    assert (c["inst"][hit] == 0).any() and (c["inst"][hit] > 0).any()
+    assert np.array_equal(w["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    assert w["max_stack"] <= bvh["stack_need"]
+    assert w["nodes"] < t2["nodes"], "no second descent per instance"
+    tmax = np.random.default_rng(34).random(len(org)).astype(np.float32) * 10
+    w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, tmax, closest=False)
+    c = o.trace(org, dirs, 1e-4, tmax, closest=False, brute_force=True)
+    assert np.array_equal(w["t"], c["t"])
+
+
+@pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
 def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkeypatch):
     """An identity instance whose mesh nothing else uses (the ground of the grove, the courtyard of the
     San-Miguel-like scene) is not entered like an instance: its BLAS is cut open and the subtrees hang in the
