@@ -50,6 +50,10 @@ def parse():
                          "own execution time, which the roofline needs); overlap: the occlusion launch of bounce b next to the "
                          "closest-hit launch of bounce b+1 on a second stream (the library's default; default here at N > 1, where "
                          "launch tails are a larger share of the frame)")
+    ap.add_argument("--levels", default=None, choices=["two", "world"],
+                    help="scenes with several instances: a top-level tree over the instances (two) or one tree in world space "
+                         "over per-instance triangle records (world); default: the library's choice (world while the instanced "
+                         "triangles fit its memory budget)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
@@ -188,6 +192,8 @@ def main():
     if args.schedule is None:
         args.schedule = "serial" if world == 1 else "overlap"
     os.environ["CRT_HIP_OVERLAP"] = "1" if args.schedule == "overlap" else "0"  # read when a context is created
+    if args.levels:
+        os.environ["CRT_HIP_LEVELS"] = args.levels  # read when a scene is prepared
     gen, kw, width, height, base_spp = scenes.WORKLOADS[args.workload]
     spp = base_spp * (world if args.scaling == "weak" else 1)
     # ---- scene: generated and prepared ONCE per node (rank 0), shared through /dev/shm ----------------
@@ -212,6 +218,7 @@ def main():
         ps = PreparedScene(scene, n_threads=usable_cores())
         t_prep = time.time() - t0
         eye, cdir, up, fovy = camera_of(scene)
+        bvh_levels = ps.levels()
         if world > 1 or not (args.no_pmc or args.no_roofline):
             ps.save(prepared_path)
             with open(meta_path, "w") as f:
@@ -258,6 +265,8 @@ def main():
                        "textures": len(scene.textures), "materials": len(scene.materials),
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
                        "schedule": args.schedule,
+                       "acceleration_structure": {0: "one BVH4 (single instance)", 1: "two-level: top-level BVH4 over instances + one BVH4 per mesh",
+                                                  2: "world tree: one BVH4 in world space over per-instance triangle records"}[bvh_levels],
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
                                       (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist else ""),
                        "scene_gen_s": round(t_gen, 2), "set_scene_host_s": round(t_prep, 2),

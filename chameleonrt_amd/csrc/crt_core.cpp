@@ -162,7 +162,7 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
 constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // kernels.h
 // Scenes with several instances whose triangles fit the budget get a world tree unless CRT_HIP_LEVELS says otherwise.
 #ifndef CRT_WORLD_TREE_DEFAULT
-#define CRT_WORLD_TREE_DEFAULT 0
+#define CRT_WORLD_TREE_DEFAULT 1
 #endif
 
 } // namespace

@@ -185,6 +185,12 @@ class PreparedScene:
                     child_order=self._lib.crt_hip_child_order(), lds_stack=self._lib.crt_hip_lds_stack_entries(int(tl.value)),
                     build_ms=ms.value, world_inst=self._lib.crt_hip_prepared_scene_world_instance(self.handle))
 
+    def levels(self) -> int:
+        """0: one instance; 1: two-level (top-level tree over instances); 2: world tree (include/crt_hip.h)."""
+        tl = C.c_int32()
+        assert self._lib.crt_hip_prepared_scene_info(self.handle, None, None, None, C.byref(tl), None, None, None, None, None) == 0
+        return tl.value
+
     def set_samples_per_pixel(self, spp: int):
         assert self._lib.crt_hip_prepared_scene_set_spp(self.handle, spp) == 0
         self.samples_per_pixel = spp

@@ -30,6 +30,7 @@ SCENES = {
 @pytest.mark.parametrize("name", list(SCENES))
 def test_device_built_bvh(name, oracle, hip_lib, monkeypatch):
     sc = SCENES[name]()
+    monkeypatch.setenv("CRT_HIP_LEVELS", "two")  # (a world tree over all instances is built on the host)
     t0 = time.time()
     dev = PreparedScene(sc, build_device=0)
     t_dev = time.time() - t0

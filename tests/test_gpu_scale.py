@@ -14,6 +14,8 @@ instances over several BLASes, multi-pass frames. Two kinds of test:
   built by independent code from the same scene: ids equal, t bit-identical. On the instanced C4 tree the
   deepest stack a probe ray needs must exceed the LDS part, i.e. the HBM slab is exercised.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -86,15 +88,22 @@ def test_multi_pass_frame_equals_single_pass(hip_lib, monkeypatch):
 FULL = {
     # textures do not take part in traversal: generated small so the test spends its time on the trees
     "C3_rungholt_full": lambda: scenes.make_workload("C3")[0],
-    "C4_sanmiguel_full": lambda: scenes.make_workload("C4", tex_size=32)[0],
+    "C4_sanmiguel_full": lambda: scenes.make_workload("C4", tex_size=32)[0],            # the library's choice: a world tree
+    "C4_sanmiguel_full_two_level": lambda: scenes.make_workload("C4", tex_size=32)[0],  # CRT_HIP_LEVELS=two
 }
 
 
 @pytest.fixture(scope="module", params=list(FULL))
 def full(request, oracle, hip_lib):
     sc = FULL[request.param]()
-    ps = PreparedScene(sc)
+    if request.param.endswith("two_level"):
+        os.environ["CRT_HIP_LEVELS"] = "two"
+    try:
+        ps = PreparedScene(sc)
+    finally:
+        os.environ.pop("CRT_HIP_LEVELS", None)
     bvh = ps.bvh()
+    assert bvh["levels"] == {"C3_rungholt_full": 0, "C4_sanmiguel_full": 2, "C4_sanmiguel_full_two_level": 1}[request.param]
     r = RenderHIP(flags=core.FLAG_COUNTERS)
     r.initialize(64, 64)
     r.set_prepared_scene(ps)
@@ -148,6 +157,6 @@ def test_full_tree_rays(full, oracle):
     assert deepest <= bvh["stack_need"]
     print(f"\n{sc.name}: deepest traversal stack {deepest}, {bvh['lds_stack']} entries in LDS, {bvh['stack_need']} provided for")
     if bvh["two_level"]:
-        # the two-level kernels keep 10 entries in LDS: the instanced C4 tree must go beyond them, i.e. exercise the
-        # HBM part of the stack (the single-level kernels keep 16, which the C3 tree may never exceed)
+        # the two-level kernels keep 15 entries in LDS: the instanced C4 tree must go beyond them, i.e. exercise the
+        # HBM part of the stack (the single-level kernels keep 16, those of a world tree 14, which their trees may never exceed)
         assert deepest > bvh["lds_stack"], f"deepest stack {deepest}: the HBM part of the traversal stack was never used"

@@ -4,6 +4,8 @@ The closest hit is defined as the lexicographic minimum of (t, inst, geom, prim)
 valid triangle hits, so the HIP kernel walking its own SAH BVH must return EXACTLY what the
 oracle gets by testing every triangle with no BVH at all: ids equal, t/u/v bit-identical.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -38,7 +40,13 @@ def pair(request, oracle, hip_lib):
     sc = SCENES[request.param]()
     r = RenderHIP(flags=core.FLAG_COUNTERS)
     r.initialize(64, 64)
-    r.set_scene(sc)
+    if request.param == "grove_two_level":  # the top-level tree over instances; the world tree: tests/test_gpu_world_tree.py
+        os.environ["CRT_HIP_LEVELS"] = "two"
+    try:
+        r.set_scene(sc)
+    finally:
+        os.environ.pop("CRT_HIP_LEVELS", None)
+    assert r.bvh()["levels"] == (1 if request.param == "grove_two_level" else 0)
     yield r, oracle.OracleScene(sc), sc
     r.close()
 

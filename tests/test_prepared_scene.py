@@ -28,6 +28,19 @@ SCENES = {
 }
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _two_level_structure():
+    """This module checks the top-level tree over instances (and its grafting); the world tree the library builds by
+    default for instanced scenes that fit its memory budget has its own tests below, which override this."""
+    old = os.environ.get("CRT_HIP_LEVELS")
+    os.environ["CRT_HIP_LEVELS"] = "two"
+    yield
+    if old is None:
+        os.environ.pop("CRT_HIP_LEVELS", None)
+    else:
+        os.environ["CRT_HIP_LEVELS"] = old
+
+
 @pytest.fixture(scope="module", params=list(SCENES))
 def prepared(request, oracle):
     sc = SCENES[request.param]()
@@ -60,6 +73,21 @@ def test_instanced_scene_layout(prepared):
     assert bvh["two_level"] == (len(sc.instances) > 1)
     assert bvh["tris"].shape[0] == sum(m.num_tris() for m in sc.meshes)  # one BLAS per Mesh, shared by its instances
     assert bvh["child_order"] in (0, 1)
+
+
+def test_world_tree_is_the_default_within_its_memory_budget(monkeypatch):
+    sc = SCENES["grove_two_level"]()
+    monkeypatch.delenv("CRT_HIP_LEVELS")
+    ps = PreparedScene(sc)
+    assert ps.levels() == 2
+    ps.close()
+    monkeypatch.setenv("CRT_HIP_WORLD_TREE_MAX_TRIS", str(sc.total_tris() - 1))
+    ps = PreparedScene(sc)
+    assert ps.levels() == 1
+    ps.close()
+    ps = PreparedScene(SCENES["cornell"]())
+    assert ps.levels() == 0
+    ps.close()
 
 
 @pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
