@@ -19,11 +19,22 @@
 namespace crt {
 namespace {
 
-constexpr int N_BINS = 16;
+// 64 bins per axis: with 16 a split plane of a large node can only fall every 1/16 of its centroid extent, which on the
+// San-Miguel-like scenes is two rows of shrubs or half an arcade -- priced with the oracle's walker of the product's
+// arrays (tools/tree_cost.py, cache-line visits per ray summed over camera, two bounce and occlusion ray sets):
+// 16 -> 32 -> 64 bins: C4 (world tree) 134.0 -> 121.8 -> 116.8, C4F 124.2 -> 119.7 -> 118.7, C2 and C3 unchanged
+// (+-0.5 %); 128 / 256 bins are no better (122.4 / 120.1: greedy top-down SAH is noisy at that level); build time +10 %.
+#ifndef CRT_BVH_BINS
+#define CRT_BVH_BINS 64
+#endif
+#ifndef CRT_BVH_SMALL_RANGE
+#define CRT_BVH_SMALL_RANGE 12
+#endif
+constexpr int MAX_BINS = CRT_BVH_BINS; // per axis; a builder may use fewer (Builder::n_bins)
 // SAH: cost of fetching+testing one node relative to one triangle (CRT_BVH_NODE_COST overrides, tuning)
 static const float NODE_COST = std::getenv("CRT_BVH_NODE_COST") ? (float)std::atof(std::getenv("CRT_BVH_NODE_COST")) : 1.0f;
 constexpr size_t PARALLEL_MIN = 1 << 15;
-constexpr uint32_t SMALL_RANGE = 12; // ranges up to this size get an exact sorted SAH sweep
+constexpr uint32_t SMALL_RANGE = CRT_BVH_SMALL_RANGE; // ranges up to this size get an exact sorted SAH sweep
 
 inline void box_reset(Aabb &b)
 {
@@ -65,14 +76,15 @@ struct Prim {
     uint32_t pad;
 };
 
-struct Bins { // N_BINS bins on each of the 3 axes, filled in one pass over the items
-    Aabb box[3][N_BINS];
-    uint32_t cnt[3][N_BINS];
+struct Bins { // n_bins bins on each of the 3 axes, filled in one pass over the items
+    Aabb box[3][MAX_BINS];
+    uint32_t cnt[3][MAX_BINS];
     Aabb bounds, cbounds;
+    int n_bins = MAX_BINS;
     void reset()
     {
         for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < N_BINS; ++b) {
+            for (int b = 0; b < n_bins; ++b) {
                 box_reset(box[a][b]);
                 cnt[a][b] = 0;
             }
@@ -81,7 +93,7 @@ struct Bins { // N_BINS bins on each of the 3 axes, filled in one pass over the 
     void merge(const Bins &o)
     {
         for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < N_BINS; ++b) {
+            for (int b = 0; b < n_bins; ++b) {
                 box_grow(box[a][b], o.box[a][b]);
                 cnt[a][b] += o.cnt[a][b];
             }
@@ -96,6 +108,7 @@ struct Builder {
     std::atomic<int> spare_threads{0};
     int max_leaf;
     int n_threads = 1;
+    int n_bins = MAX_BINS;
 
     int32_t alloc() { return next.fetch_add(1); }
 
@@ -140,7 +153,10 @@ struct Builder {
 
     void fill_bins(uint32_t first, uint32_t count, const Aabb &cb, const float scale[3], Bins &bins, int threads)
     {
+        const int N_BINS = n_bins;
+        bins.n_bins = N_BINS;
         auto scan = [&](uint32_t lo, uint32_t hi, Bins &out) {
+            out.n_bins = N_BINS;
             out.reset();
             for (uint32_t i = lo; i < hi; ++i) {
                 const Prim &p = prims[i];
@@ -179,6 +195,7 @@ struct Builder {
 
     int32_t build(uint32_t first, uint32_t count, uint32_t depth)
     {
+        const int N_BINS = n_bins;
         const int32_t me = alloc();
         tn[me].first = first;
         tn[me].count = count;
@@ -266,8 +283,8 @@ struct Builder {
             if (!(scale[axis] > 0.f)) {
                 continue;
             }
-            float r_area[N_BINS];
-            uint32_t r_cnt[N_BINS];
+            float r_area[MAX_BINS];
+            uint32_t r_cnt[MAX_BINS];
             Aabb acc;
             box_reset(acc);
             uint32_t cnt = 0;
@@ -409,6 +426,10 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     Builder b;
     b.max_leaf = max_leaf;
     b.n_threads = std::max(1, n_threads);
+    // (the top-level tree over instance boxes keeps 16 bins: with 64 the two-level C4 walks 13 % MORE lines per ray and
+    // renders 8 % slower -- greedy SAH over a few thousand overlapping boxes is that fickle; the finer bins pay for
+    // triangles, see CRT_BVH_BINS)
+    b.n_bins = leaf_holds_item_id ? std::min(16, MAX_BINS) : MAX_BINS;
     b.prims.resize(n);
     for (size_t i = 0; i < n; ++i) {
         Prim &p = b.prims[i];
@@ -464,6 +485,16 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     auto best_split = [&](int32_t t, int j, int &a_out) { return b.best_split(t, j, a_out); };
     if (is_inner(root)) {
         out.collapse_cost = (float)(b.tn[root].slot_cost[0] / std::max(half_area(root), 1e-300));
+        if (dbg && n > 100000) {
+            double leaf_area = 0.0; // expected triangle tests: summed area of the leaves x their triangle count
+            for (int32_t t = 0; t < n_tn; ++t) {
+                if (!is_inner(t)) {
+                    leaf_area += half_area(t) * (double)b.tn[t].count;
+                }
+            }
+            std::fprintf(stderr, "[crt_hip]   build_bvh SAH: %.2f node visits + %.2f triangle tests per ray that enters the root box (%d bins)\n",
+                         (double)out.collapse_cost, leaf_area / std::max(half_area(root), 1e-300), b.n_bins);
+        }
     }
     auto wide_children = [&](int32_t t) {
         Wide w;

@@ -37,3 +37,34 @@ def compare_images(gpu, cpu):
     good = ~bad & ~both_nf
     mean_rel = float(err[good].mean() / max(1e-12, np.abs(cpu[good]).mean()))
     return float(bad.mean()), mean_rel
+
+
+def awkward_instances():
+    """A small scene of awkward instances: a MIRRORED one (negative determinant), a strongly non-uniform scale, two
+    instances at exactly the same place (exact ties in t go to the lower instance id), an identity instance of a mesh
+    that transformed instances share, and one mesh under two ParameterizedMeshes with different material tables."""
+    from chameleonrt_amd.scene import Camera, Geometry, Instance, Mesh, ParameterizedMesh, Scene, disney_material, obj_default_light
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(300, 3)).astype(np.float32)
+    idx = rng.integers(0, 300, size=(400, 3)).astype(np.uint32)
+    blob = Mesh([Geometry(v, idx[:250], None), Geometry(v * np.float32(0.5), idx[250:], None)])
+    ground = Mesh([Geometry(np.array([[-9, -2, -9], [9, -2, -9], [9, -2, 9], [-9, -2, 9]], np.float32),
+                            np.array([[0, 1, 2], [0, 2, 3]], np.uint32), None)])
+
+    def trs(t, s, ry=0.0):
+        m = np.eye(4, dtype=np.float32)
+        c, si = np.cos(ry), np.sin(ry)
+        m[:3, :3] = np.array([[c, 0, si], [0, 1, 0], [-si, 0, c]], np.float32) @ np.diag(np.asarray(s, np.float32))
+        m[:3, 3] = t
+        return m.T.reshape(16).astype(np.float32)  # column-major
+
+    insts = [Instance(np.eye(4, dtype=np.float32).reshape(16), 0),        # ground, identity
+             Instance(np.eye(4, dtype=np.float32).reshape(16), 1),        # the blob itself, identity, mesh shared below
+             Instance(trs([4, 0, 0], [-1, 1, 1], 0.3), 1),                # mirrored
+             Instance(trs([-4, 0.5, 1], [0.2, 3.0, 0.7], 1.1), 2),        # non-uniform scale, the other material table
+             Instance(trs([0, 0, 5], [1, 1, 1], 0.7), 1),
+             Instance(trs([0, 0, 5], [1, 1, 1], 0.7), 2)]                 # coincides with the one before it
+    sc = Scene(meshes=[ground, blob], parameterized_meshes=[ParameterizedMesh(0, [0]), ParameterizedMesh(1, [0, 1]), ParameterizedMesh(1, [1, 0])],
+               instances=insts, materials=[disney_material(), disney_material()], lights=[obj_default_light()],
+               cameras=[Camera(np.array([0, 2, 14], np.float32), np.zeros(3, np.float32), np.array([0, 1, 0], np.float32), 50.0)])
+    return sc

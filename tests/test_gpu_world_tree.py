@@ -11,7 +11,7 @@ import pytest
 
 from chameleonrt_amd import core, scenes
 from chameleonrt_amd.render_hip import RenderHIP
-from tests.parity import camera_of, probe_rays
+from tests.parity import awkward_instances, camera_of, probe_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,8 @@ SCENES = {
     "grove": (lambda: scenes.instanced_grove(), 320, 200),
     "sanmiguel_small_instanced": (lambda: scenes.sanmiguel_like(detail=0.02, tex_size=64, n_trees=100, leaves_per_tree=300,
                                                                 n_instanced=64, glass=True, spp=2), 320, 180),
+    # mirrored / non-uniformly scaled / coinciding instances, a shared mesh under two material tables (tests/parity.py)
+    "awkward_instances": (awkward_instances, 256, 160),
 }
 
 
@@ -46,6 +48,8 @@ def test_world_tree_hits_counters_and_frames(name, oracle, hip_lib, monkeypatch)
         assert np.array_equal(g[k], c[k]), k
     hit = c["inst"] >= 0
     assert (c["inst"][hit] == 0).any() and (c["inst"][hit] > 0).any()
+    if name == "awkward_instances":
+        assert set(np.unique(c["inst"][hit])) == {0, 1, 2, 3, 4}  # of the coinciding pair (4, 5) the lower id wins every tie
     for k in ("t", "u", "v"):
         assert np.array_equal(g[k][hit].view(np.uint32), c[k][hit].view(np.uint32)), k
     wk = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)

@@ -16,7 +16,7 @@ import pytest
 from chameleonrt_amd import core, scenes
 from chameleonrt_amd.render_hip import PreparedScene
 from chameleonrt_amd.scene import PackedScene
-from tests.parity import probe_rays
+from tests.parity import awkward_instances, probe_rays
 
 SCENES = {
     "cornell": lambda: scenes.cornell(),
@@ -139,6 +139,40 @@ def test_world_tree_of_an_instanced_scene(name, oracle, monkeypatch):
     assert np.array_equal(w["t"], c["t"])
 
 
+def test_world_tree_edge_cases(oracle, monkeypatch, tmp_path):
+    """A world tree over awkward instances: a MIRRORED one (negative determinant: the object-space test sees a
+    left-handed ray frame), a strongly non-uniform scale, two instances at exactly the same place (exact ties in t
+    go to the lower instance id), an identity instance of a mesh that transformed instances share, and one mesh under
+    two ParameterizedMeshes. Hits equal brute force bit for bit; the prepared scene survives save / load."""
+    sc = awkward_instances()
+    monkeypatch.setenv("CRT_HIP_LEVELS", "world")
+    ps = PreparedScene(sc)
+    bvh = ps.bvh()
+    assert bvh["levels"] == 2 and bvh["tris"].shape[0] == 2 + 5 * 400
+    o = oracle.OracleScene(sc)
+    org, dirs = probe_rays(sc, 12000, seed=3, spread=0.5)
+    w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w[k], c[k]), k
+    hit = c["inst"] >= 0
+    assert set(np.unique(c["inst"][hit])) == {0, 1, 2, 3, 4}, "every instance is hit, the coinciding pair only through the lower id"
+    assert np.array_equal(w["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    tmax = np.random.default_rng(4).random(len(org)).astype(np.float32) * 12
+    w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, tmax, closest=False)
+    c = o.trace(org, dirs, 1e-4, tmax, closest=False, brute_force=True)
+    assert np.array_equal(w["t"], c["t"])
+    path = str(tmp_path / "world.bin")
+    ps.save(path)
+    back = PreparedScene(path=path)
+    b2 = back.bvh()
+    assert back.levels() == 2
+    for k in ("nodes", "tris", "instances", "frame"):
+        assert np.array_equal(bvh[k], b2[k]), k
+    back.close()
+    ps.close()
+
+
 @pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
 def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkeypatch):
     """An identity instance whose mesh nothing else uses (the ground of the grove, the courtyard of the
@@ -163,7 +197,8 @@ def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkey
     via_q = ps.bvh()
     ps.close()
     monkeypatch.delenv("CRT_HIP_GRAFT_QNODES")
-    assert via_q["world_inst"] == 0 and via_q["nodes"].shape == bvh["nodes"].shape
+    # (the top-level tree over read-back boxes, which are a quantum wider, may decide a split differently)
+    assert via_q["world_inst"] == 0 and abs(via_q["nodes"].shape[0] - bvh["nodes"].shape[0]) <= 0.01 * bvh["nodes"].shape[0]
     assert plain["world_inst"] == -1 and bvh["world_inst"] == 0 and bvh["two_level"]
     nodes = bvh["nodes"].reshape(-1, 4, 4)
     refs = nodes[:, :, 3].astype(np.uint32).view(np.int32)

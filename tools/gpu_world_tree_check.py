@@ -9,7 +9,7 @@ import numpy as np
 from chameleonrt_amd import core, scenes
 from chameleonrt_amd.render_hip import RenderHIP
 from tests import oracle_lib as oracle
-from tests.parity import camera_of, probe_rays
+from tests.parity import awkward_instances, camera_of, probe_rays
 
 OUT = open(os.path.join("gpurun_out", "world_tree_check.txt"), "a") if os.path.isdir("gpurun_out") else sys.stdout
 
@@ -72,6 +72,7 @@ def main():
     ok = check("grove", scenes.instanced_grove(), 320, 200)
     ok = check("sanmiguel_small_instanced", scenes.sanmiguel_like(detail=0.02, tex_size=64, n_trees=100, leaves_per_tree=300,
                                                                   n_instanced=64, glass=True, spp=2), 320, 180) and ok
+    ok = check("awkward_instances", awkward_instances(), 256, 160) and ok
     say("PARITY", "GREEN" if ok else "RED")
     which = sys.argv[1] if len(sys.argv) > 1 else "C4:tex_size=256"
     nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 6
