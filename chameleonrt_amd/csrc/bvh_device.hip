@@ -15,7 +15,7 @@
 //   7. k_emit       triangles and their vertex UVs in leaf (= sorted) order
 //
 // The result is copied back into the host-side prepared scene, so everything after the build (TLAS,
-// instance records, sharing between the GPUs of a node) is the one code path of crt_core.cpp.
+// instance records, sharing between the GPUs of a node) is the one code path of scene_prepare.cpp.
 #include <hip/hip_runtime.h>
 #include <string.h> // rocprim's texture_cache_iterator.hpp calls ::memset without including it
 

@@ -29,13 +29,13 @@
 #include "crt_types.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "scene_prepare.h"
 #include "wavefront.h"
 
 using namespace crt;
 
 namespace {
 
-thread_local std::string g_create_error;
 
 struct HipError {
     std::string msg;
@@ -85,67 +85,6 @@ template <typename T> void upload(DeviceBuffer &buf, const std::vector<T> &v, hi
     }
 }
 
-// util/util.cpp:102-108 (std::pow(float, double): evaluated in double)
-inline float srgb_to_linear(float x)
-{
-    if (x <= 0.04045f) {
-        return x / 12.92f;
-    }
-    return (float)std::pow((double)((x + 0.055f) / 1.055f), 2.4);
-}
-
-// 4x4 inverse by cofactor expansion: stands in for glm::inverse (embree_utils.cpp:97).
-bool invert4x4(const float m[16], float out[16])
-{
-    float inv[16];
-    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
-             m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
-             m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
-             m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
-              m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
-             m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
-             m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
-             m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
-              m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
-             m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
-             m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
-              m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
-              m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
-             m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
-             m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
-              m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
-              m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-    if (det == 0.f) {
-        return false;
-    }
-    const float r = 1.f / det;
-    for (int i = 0; i < 16; ++i) {
-        out[i] = inv[i] * r;
-    }
-    return true;
-}
-
-bool is_identity(const float m[16])
-{
-    static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    return std::memcmp(m, id, sizeof(id)) == 0;
-}
 
 struct Vec3 {
     float x, y, z;
@@ -159,11 +98,6 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
     return Vec3{v.x * c, v.y * c, v.z * c};
 }
 
-constexpr int MAX_TOP_NODES_HOST = CRT_MAX_TOP_NODES; // kernels.h
-// Scenes with several instances whose triangles fit the budget get a world tree unless CRT_HIP_LEVELS says otherwise.
-#ifndef CRT_WORLD_TREE_DEFAULT
-#define CRT_WORLD_TREE_DEFAULT 1
-#endif
 
 } // namespace
 
@@ -240,7 +174,7 @@ int fail(crt_hip_ctx *ctx, int code, const std::string &msg)
     if (ctx) {
         ctx->err = msg;
     } else {
-        g_create_error = msg;
+        set_global_error(msg);
     }
     return code;
 }
@@ -364,101 +298,6 @@ hipEvent_t get_event(crt_hip_ctx *c, size_t i)
     return c->events[i];
 }
 
-void check_scene(const crt_scene_desc *s)
-{
-    if (!s) {
-        throw std::runtime_error("scene is null");
-    }
-    if (s->n_instances == 0 || s->n_meshes == 0 || s->n_geometries == 0 || s->n_parameterized_meshes == 0) {
-        throw std::runtime_error("scene has no instances/meshes/geometries");
-    }
-    if (s->n_lights == 0) {
-        throw std::runtime_error("scene has no lights (the reference divides by num_lights)");
-    }
-    if (s->n_materials == 0) {
-        throw std::runtime_error("scene has no materials");
-    }
-    // every array with a non-zero count must be there: nothing may crash across the C ABI
-    if (!s->instances || !s->meshes || !s->geometries || !s->parameterized_meshes || !s->materials || !s->lights ||
-        (s->n_textures != 0 && !s->textures)) {
-        throw std::runtime_error("scene has a NULL array with a non-zero count");
-    }
-    for (uint32_t i = 0; i < s->n_instances; ++i) {
-        const uint32_t pm = s->instances[i].parameterized_mesh_id;
-        if (pm >= s->n_parameterized_meshes) {
-            throw std::runtime_error("instance references a missing parameterized mesh");
-        }
-        const crt_parameterized_mesh_desc &p = s->parameterized_meshes[pm];
-        if (p.mesh_id >= s->n_meshes || p.n_material_ids < s->meshes[p.mesh_id].n_geometries) {
-            throw std::runtime_error("parameterized mesh / material id count mismatch");
-        }
-        if (p.n_material_ids != 0 && !p.material_ids) {
-            throw std::runtime_error("parameterized mesh without its material id array");
-        }
-        for (uint32_t k = 0; k < p.n_material_ids; ++k) {
-            if (p.material_ids[k] >= s->n_materials) {
-                throw std::runtime_error("material id out of range");
-            }
-        }
-    }
-    for (uint32_t m = 0; m < s->n_meshes; ++m) {
-        if ((uint64_t)s->meshes[m].first_geometry + (uint64_t)s->meshes[m].n_geometries > (uint64_t)s->n_geometries) {
-            throw std::runtime_error("mesh geometry range out of bounds");
-        }
-    }
-    for (uint32_t g = 0; g < s->n_geometries; ++g) {
-        const crt_geometry_desc &gd = s->geometries[g];
-        if ((gd.n_vertices != 0 && !gd.vertices) || (gd.n_triangles != 0 && !gd.indices)) {
-            throw std::runtime_error("geometry without its vertex / index array");
-        }
-        if (gd.n_triangles >= (1ull << 32) || gd.n_vertices >= (1ull << 32)) {
-            throw std::runtime_error("geometry too large for 32-bit indices");
-        }
-        for (uint64_t t = 0; t < 3 * gd.n_triangles; ++t) {
-            if (gd.indices[t] >= gd.n_vertices) {
-                throw std::runtime_error("triangle index out of range");
-            }
-        }
-    }
-    for (uint32_t m = 0; m < s->n_materials; ++m) {
-        for (int k = 0; k < 14; ++k) {
-            if (k == 1 || k == 2) {
-                continue; // base_color.g/.b are never handles
-            }
-            uint32_t bits;
-            std::memcpy(&bits, &s->materials[16 * (size_t)m + k], 4);
-            if ((bits & 0x80000000u) && (bits & 0x1fffffffu) >= s->n_textures) {
-                throw std::runtime_error("material references a missing texture");
-            }
-        }
-    }
-}
-
-// Host cores this process may use: affinity mask, capped by the cgroup CPU quota (a container
-// with 16 of 128 cores must not start 128 build threads), overridable with CRT_HIP_BUILD_THREADS.
-int host_threads()
-{
-    if (const char *e = std::getenv("CRT_HIP_BUILD_THREADS")) {
-        const int v = std::atoi(e);
-        if (v > 0) {
-            return v;
-        }
-    }
-    int n = (int)std::max(1u, std::thread::hardware_concurrency());
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-        n = std::max(1, std::min(n, CPU_COUNT(&set)));
-    }
-    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char quota[32];
-        long long period = 0;
-        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
-            n = std::max(1, std::min(n, (int)(std::atoll(quota) / period)));
-        }
-        std::fclose(f);
-    }
-    return n;
-}
 
 } // namespace
 
@@ -480,11 +319,11 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
-        g_create_error = "no HIP device available (this backend has no CPU fallback)";
+        set_global_error("no HIP device available (this backend has no CPU fallback)");
         return nullptr;
     }
     if (device_id < 0 || device_id >= n) {
-        g_create_error = "device id out of range";
+        set_global_error("device id out of range");
         return nullptr;
     }
     std::unique_ptr<crt_hip_ctx> c(new crt_hip_ctx);
@@ -508,7 +347,7 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         }
         c->stream = c->own_stream;
     } catch (const HipError &err) {
-        g_create_error = err.msg;
+        set_global_error(err.msg);
         return nullptr;
     }
     return c.release();
@@ -523,7 +362,7 @@ void crt_hip_destroy(crt_hip_ctx *ctx)
     }
 }
 
-const char *crt_hip_last_error(const crt_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *crt_hip_last_error(const crt_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : global_error().c_str(); }
 const char *crt_hip_name(const crt_hip_ctx *ctx) { return ctx ? ctx->name.c_str() : ""; }
 uint32_t crt_hip_frame_id(const crt_hip_ctx *ctx) { return ctx ? ctx->frame_id : 0; }
 
@@ -598,710 +437,9 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
 
 } // extern "C"
 
-// ---- set_scene, host half: everything that does not need a device -------------------------------
-// RenderEmbree::set_scene (render_embree.cpp:58-133, embree_utils.cpp:9-136): one BLAS per Mesh, the
-// TLAS over the instances, sRGB -> linear textures in 8 bits, material and light tables -- as the flat
-// arrays the kernels read. Split from the upload so that the GPUs of one node share ONE build
-// (RenderHIP::set_scene prepares once and uploads to every context; bench.py's rank 0 prepares, saves
-// to /dev/shm and the other ranks load).
-struct crt_hip_prepared_scene {
-    std::vector<QNode> nodes;
-    std::vector<TriRec> tris;
-    std::vector<float> tri_uvs; // TRI_UV_STRIDE per TriRec
-    std::vector<InstanceRec> insts;
-    std::vector<uint32_t> material_ids;
-    std::vector<float> materials, lights;
-    std::vector<TexRec> tex;
-    std::vector<uint8_t> texels;
-    QFrame root_frame{};
-    int32_t root = 0;
-    uint32_t two_level = 0, n_top = 0, n_lights = 0, n_instances = 0, spp = 1, stack_need = 0;
-    int32_t world_inst = -1; // instance grafted into the top-level tree (prepare_scene), or -1
-    double build_ms = 0.0;
-};
-
 namespace {
 
-// World tree or two levels for a scene with several instances (crt_types.h LEVELS_WORLD_TREE)? Read per call, so a
-// process can prepare scenes both ways (tests).
-bool world_tree_wanted(uint64_t instanced_tris)
-{
-    const char *levels = std::getenv("CRT_HIP_LEVELS");
-    if (levels != nullptr && std::strcmp(levels, "two") == 0) {
-        return false;
-    }
-    if (instanced_tris >= (1u << 28)) { // the leaf reference has 28 bits
-        return false;
-    }
-    if (levels != nullptr && std::strcmp(levels, "world") == 0) {
-        return true;
-    }
-    // ~95 bytes per triangle (record, uv record, its share of the nodes): 2^27 triangles are 12.7 GB of a 288 GB part
-    const char *cap = std::getenv("CRT_HIP_WORLD_TREE_MAX_TRIS");
-    const uint64_t budget = cap != nullptr ? std::strtoull(cap, nullptr, 10) : (1ull << 27);
-    return CRT_WORLD_TREE_DEFAULT && instanced_tris <= budget;
-}
-
-// build_device >= 0: meshes large enough to be worth it get their BLAS from the device builder
-// (bvh_device.hip) on that HIP device; -1: the host SAH builder for everything.
-void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads, int build_device = -1)
-{
-        const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
-        auto t_phase = std::chrono::high_resolution_clock::now();
-        const auto t_begin = t_phase;
-        auto phase = [&](const char *what) {
-            const auto now = std::chrono::high_resolution_clock::now();
-            if (dbg) {
-                std::fprintf(stderr, "[crt_hip] set_scene %-22s %8.1f ms\n", what,
-                             std::chrono::duration<double, std::milli>(now - t_phase).count());
-            }
-            t_phase = now;
-        };
-        check_scene(s);
-        phase("validate");
-        ps->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
-        std::vector<QNode> &nodes = ps->nodes;
-        std::vector<TriRec> &tris = ps->tris;
-        std::vector<float> &tri_uvs = ps->tri_uvs;
-        // one BLAS per Mesh (embree_utils.cpp:63-76)
-        // Several instances: either a top-level tree over instances (two-level traversal, what Embree does:
-        // embree_utils.cpp:90-129), or -- when the instanced triangles fit a memory budget, which on a 288 GB part is
-        // nearly always -- ONE tree in world space over per-instance copies of the triangle records (crt_types.h
-        // LEVELS_WORLD_TREE). CRT_HIP_LEVELS=two|world overrides the choice.
-        uint64_t instanced_tris = 0;
-        for (uint32_t i = 0; i < s->n_instances; ++i) {
-            const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
-            for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                instanced_tris += s->geometries[md.first_geometry + k].n_triangles;
-            }
-        }
-        const bool world_tree = s->n_instances > 1 && world_tree_wanted(instanced_tris);
-        const bool two_level = s->n_instances > 1 && !world_tree;
-        std::vector<QFrame> blas_frame(s->n_meshes);
-        std::vector<int32_t> blas_root(s->n_meshes);
-        std::vector<Aabb> blas_bounds(s->n_meshes);
-        std::vector<uint32_t> blas_top(s->n_meshes);
-        // node 0.. are reserved for the TLAS when two_level so that the staged top levels are the TLAS's
-        std::vector<BuiltBvh> built(s->n_meshes);
-        std::vector<std::vector<QNode>> built_q(s->n_meshes); // device-built meshes: already quantised
-        uint32_t blas_depth = 0, tlas_depth = 0; // levels of the wide trees
-        // leaves of at most 2 triangles: with 4-wide nodes a leaf is one of four boxes tested per node
-        // fetch, so small leaves are cheap to reach, and every triangle test saved is 3 lane requests
-        static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
-        const char *builder_env = std::getenv("CRT_BVH_BUILDER"); // "lbvh": the device algorithm, run on the host
-        const bool host_lbvh = builder_env && std::strcmp(builder_env, "lbvh") == 0;
-        // The static part of an instanced scene -- an identity instance whose mesh nothing else uses: the building
-        // of a San-Miguel-like scene with its instanced plants -- is not entered like an instance. Its BLAS is
-        // opened from the root down to a CUT of subtrees about as large as the other instances, the top-level tree is
-        // built over those subtrees AND the other instances' boxes, and a cut subtree is referenced by a plain
-        // child reference (its nodes are quantised in the top-level frame; an identity instance is traversed with
-        // the world-space ray anyway, so the hits are the same bit for bit). A ray then no longer walks a TLAS down
-        // to an instance box that covers the whole scene, enters it and starts again at the BLAS root: it walks
-        // one tree in which the plants sit where they stand, and the entry / exit steps of the big instance are gone.
-        // A mesh that was built on the device arrives quantised in its own frame: its boxes are read back from the
-        // 16-bit form for the cut, and its nodes re-quantised (outward again) into the top-level frame.
-        int32_t world_inst = -1;
-        uint32_t world_mesh = 0xffffffffu;
-        if (two_level && max_leaf <= 7 && !std::getenv("CRT_HIP_NO_GRAFT")) {
-            std::vector<uint32_t> mesh_refs(s->n_meshes, 0);
-            for (uint32_t i = 0; i < s->n_instances; ++i) {
-                ++mesh_refs[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
-            }
-            uint64_t most = 0;
-            for (uint32_t i = 0; i < s->n_instances; ++i) {
-                const uint32_t m = s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id;
-                if (mesh_refs[m] != 1 || !is_identity(s->instances[i].transform)) {
-                    continue;
-                }
-                uint64_t n_tris_m = 0;
-                for (uint32_t k = 0; k < s->meshes[m].n_geometries; ++k) {
-                    n_tris_m += s->geometries[s->meshes[m].first_geometry + k].n_triangles;
-                }
-                if (n_tris_m > most) {
-                    most = n_tris_m;
-                    world_inst = (int32_t)i;
-                    world_mesh = m;
-                }
-            }
-        }
-        // triangle record + the uvs of its three vertices (uv_buf[indices.x|y|z], render_embree.ispc:278-283) at position `at`
-        auto place_tri = [&](const crt_mesh_desc &md, const TriRec &r, size_t at) {
-            tris[at] = r;
-            const crt_geometry_desc &gd = s->geometries[md.first_geometry + r.geom];
-            if (gd.uvs) {
-                for (int c = 0; c < 3; ++c) {
-                    const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
-                    tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c] = gd.uvs[2 * (size_t)vi];
-                    tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
-                }
-            }
-        };
-        for (uint32_t m = 0; m < s->n_meshes && !world_tree; ++m) {
-            const crt_mesh_desc &md = s->meshes[m];
-            if (build_device >= 0) {
-                DeviceBuiltMesh db;
-                bool built_on_device = false;
-                try {
-                    built_on_device = device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries,
-                                                        (uint32_t)max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST, db);
-                } catch (const std::exception &e) { // e.g. out of device memory: the host builder still can
-                    std::fprintf(stderr, "[crt_hip] %s -- building mesh %u on the host instead\n", e.what(), m);
-                    (void)hipGetLastError();
-                }
-                if (built_on_device) {
-                    const size_t tri_base = tris.size();
-                    tris.insert(tris.end(), db.tris.begin(), db.tris.end());
-                    tri_uvs.insert(tri_uvs.end(), db.tri_uvs.begin(), db.tri_uvs.end());
-                    built_q[m] = std::move(db.nodes);
-                    built[m].n_top = db.n_top;
-                    built[m].max_depth = db.max_depth;
-                    built[m].bounds = db.bounds;
-                    blas_depth = std::max(blas_depth, db.max_depth);
-                    blas_bounds[m] = db.bounds;
-                    blas_frame[m] = db.frame;
-                    blas_root[m] = (int32_t)tri_base;
-                    continue;
-                }
-            }
-            std::vector<TriRec> recs;
-            std::vector<Aabb> boxes;
-            {
-                uint64_t n_mesh_tris = 0; // reserve ONCE: growing per geometry re-copies everything each time
-                for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                    n_mesh_tris += s->geometries[md.first_geometry + k].n_triangles;
-                }
-                recs.reserve(n_mesh_tris);
-                boxes.reserve(n_mesh_tris);
-            }
-            for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                for (uint64_t t = 0; t < gd.n_triangles; ++t) {
-                    const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
-                    const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
-                    const float *v2 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 2];
-                    TriRec r;
-                    Aabb b;
-                    for (int a = 0; a < 3; ++a) {
-                        r.v0[a] = v0[a];
-                        r.e1[a] = v0[a] - v1[a];
-                        r.e2[a] = v2[a] - v0[a];
-                        b.lo[a] = std::min(v0[a], std::min(v1[a], v2[a]));
-                        b.hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
-                    }
-                    r.geom = k;
-                    r.prim = (uint32_t)t;
-                    r.pad = 0;
-                    recs.push_back(r);
-                    boxes.push_back(b);
-                }
-            }
-            if (recs.empty()) {
-                throw std::runtime_error("mesh without triangles");
-            }
-            built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
-                                 : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
-                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
-            blas_depth = std::max(blas_depth, built[m].max_depth);
-            // triangles in leaf order
-            const size_t tri_base = tris.size();
-            tris.resize(tri_base + recs.size());
-            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
-            for (size_t i = 0; i < recs.size(); ++i) {
-                place_tri(md, recs[built[m].order[i]], tri_base + i);
-            }
-            blas_bounds[m] = built[m].bounds;
-            blas_frame[m] = make_frame(built[m].bounds);
-            // re-base the node / leaf references later, once the TLAS size is known
-            blas_root[m] = (int32_t)tri_base; // temporarily: triangle base
-        }
-
-        phase("leaf-order triangles");
-        // instances + TLAS (embree_utils.cpp:90-104, 121-129)
-        std::vector<InstanceRec> &insts = ps->insts;
-        insts.assign(s->n_instances, InstanceRec{});
-        std::vector<uint32_t> &material_ids = ps->material_ids;
-        std::vector<Aabb> inst_boxes(s->n_instances);
-        for (uint32_t i = 0; i < s->n_instances; ++i) {
-            const crt_instance_desc &id = s->instances[i];
-            const crt_parameterized_mesh_desc &pm = s->parameterized_meshes[id.parameterized_mesh_id];
-            InstanceRec r;
-            std::memset(&r, 0, sizeof(r));
-            float inv[16];
-            if (!invert4x4(id.transform, inv)) {
-                throw std::runtime_error("singular instance transform");
-            }
-            for (int c = 0; c < 4; ++c) { // keep the affine 3x4 part (the last row of an instance transform is 0 0 0 1)
-                for (int rr = 0; rr < 3; ++rr) {
-                    r.w2o[c * 3 + rr] = inv[c * 4 + rr];
-                }
-            }
-            r.identity = is_identity(id.transform) ? 1u : 0u;
-            r.geom_base = s->meshes[pm.mesh_id].first_geometry;
-            r.mat_base = (uint32_t)material_ids.size();
-            r.blas_root = (int32_t)pm.mesh_id; // temporarily: mesh id
-            r.frame = blas_frame[pm.mesh_id];
-            for (uint32_t k = 0; k < pm.n_material_ids; ++k) {
-                // bit 31: some parameter of the material is a texture handle (render_embree.ispc:66-103 tests the same
-                // sign bit per parameter) -- k_shade fetches the hit's uv record only then
-                const uint32_t id = pm.material_ids[k];
-                bool textured = false;
-                for (int f = 0; f < 14; ++f) {
-                    uint32_t bits;
-                    std::memcpy(&bits, s->materials + 16 * (size_t)id + f, 4);
-                    textured = textured || (bits & 0x80000000u) != 0u;
-                }
-                material_ids.push_back(id | (textured ? MATERIAL_TEXTURED : 0u));
-            }
-            insts[i] = r;
-            if (world_tree) {
-                continue; // no instance boxes: the tree is built over the triangles (below)
-            }
-            const Aabb &mb = blas_bounds[pm.mesh_id];
-            Aabb wb;
-            for (int a = 0; a < 3; ++a) {
-                wb.lo[a] = INFINITY;
-                wb.hi[a] = -INFINITY;
-            }
-            const float *m = id.transform;
-            const crt_mesh_desc &imd = s->meshes[pm.mesh_id];
-            uint64_t mesh_verts = 0;
-            for (uint32_t k = 0; k < imd.n_geometries; ++k) {
-                mesh_verts += s->geometries[imd.first_geometry + k].n_vertices;
-            }
-            if (!r.identity && mesh_verts <= (1u << 20)) {
-                // The world box of the transformed VERTICES, not of the transformed corners of the object-space box:
-                // for a rotated instance the latter is up to 40 % wider on each axis, and every ray that enters an
-                // instance box pays a transform, a frame change and a walk from the BLAS root. (Instanced meshes are
-                // small; a mesh of more than a million vertices keeps the corner box.)
-                for (uint32_t k = 0; k < imd.n_geometries; ++k) {
-                    const crt_geometry_desc &gd = s->geometries[imd.first_geometry + k];
-                    for (uint64_t v = 0; v < gd.n_vertices; ++v) {
-                        const float *p = gd.vertices + 3 * v;
-                        for (int a = 0; a < 3; ++a) {
-                            const float w = m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
-                            wb.lo[a] = std::min(wb.lo[a], w);
-                            wb.hi[a] = std::max(wb.hi[a], w);
-                        }
-                    }
-                }
-            } else {
-                for (int c = 0; c < 8; ++c) {
-                    const float p[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1],
-                                        (c & 4) ? mb.hi[2] : mb.lo[2]};
-                    for (int a = 0; a < 3; ++a) {
-                        const float w = r.identity ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
-                        wb.lo[a] = std::min(wb.lo[a], w);
-                        wb.hi[a] = std::max(wb.hi[a], w);
-                    }
-                }
-            }
-            // pad: the BLAS is walked with a transformed (rounded) ray
-            const float ext = std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
-            for (int a = 0; a < 3; ++a) {
-                wb.lo[a] -= 1e-5f * ext;
-                wb.hi[a] += 1e-5f * ext;
-            }
-            inst_boxes[i] = wb;
-        }
-        uint32_t n_top = 0;
-        int32_t root = 0;
-        QFrame root_frame{};
-        if (world_tree) {
-            // One record + one world-space box per (instance, triangle). The record is the mesh's own (object space: the
-            // triangle test runs there, with the ray transformed like the reference transforms it, so t / u / v come out
-            // bit for bit as in the two-level walk); the box bounds the transformed vertices, padded like an instance box
-            // (the test ray is a rounded transform of the world ray) -- and quantisation rounds outward by >= 1 quantum
-            // of the scene's extent on top of that.
-            std::vector<TriRec> recs;
-            std::vector<Aabb> boxes;
-            recs.reserve(instanced_tris);
-            boxes.reserve(instanced_tris);
-            for (uint32_t i = 0; i < s->n_instances; ++i) {
-                const crt_instance_desc &id = s->instances[i];
-                const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
-                const float *m = id.transform;
-                const bool ident = insts[i].identity != 0u;
-                auto to_world = [&](const float *p, int a) {
-                    return ident ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
-                };
-                float pad = 0.f;
-                if (!ident) {
-                    Aabb wb;
-                    for (int a = 0; a < 3; ++a) {
-                        wb.lo[a] = INFINITY;
-                        wb.hi[a] = -INFINITY;
-                    }
-                    for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                        const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                        for (uint64_t v = 0; v < gd.n_vertices; ++v) {
-                            for (int a = 0; a < 3; ++a) {
-                                const float w = to_world(gd.vertices + 3 * v, a);
-                                wb.lo[a] = std::min(wb.lo[a], w);
-                                wb.hi[a] = std::max(wb.hi[a], w);
-                            }
-                        }
-                    }
-                    pad = 1e-5f * std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
-                    if (!(pad >= 0.f)) { // an instance without vertices that any triangle uses
-                        pad = 0.f;
-                    }
-                }
-                for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                    const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                    for (uint64_t t = 0; t < gd.n_triangles; ++t) {
-                        const float *v[3] = {gd.vertices + 3 * (size_t)gd.indices[3 * t], gd.vertices + 3 * (size_t)gd.indices[3 * t + 1],
-                                             gd.vertices + 3 * (size_t)gd.indices[3 * t + 2]};
-                        TriRec r;
-                        Aabb b;
-                        for (int a = 0; a < 3; ++a) {
-                            r.v0[a] = v[0][a];
-                            r.e1[a] = v[0][a] - v[1][a];
-                            r.e2[a] = v[2][a] - v[0][a];
-                            const float w0 = to_world(v[0], a), w1 = to_world(v[1], a), w2 = to_world(v[2], a);
-                            b.lo[a] = std::min(w0, std::min(w1, w2)) - pad;
-                            b.hi[a] = std::max(w0, std::max(w1, w2)) + pad;
-                        }
-                        r.geom = k;
-                        r.prim = (uint32_t)t;
-                        r.pad = (i << 1) | (ident ? 1u : 0u);
-                        recs.push_back(r);
-                        boxes.push_back(b);
-                    }
-                }
-            }
-            if (recs.empty()) {
-                throw std::runtime_error("scene without triangles");
-            }
-            const int wt_leaf = std::min(max_leaf, 2); // the kernels' world-tree leaf step handles one or two triangles
-            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), wt_leaf, MAX_TOP_NODES_HOST)
-                                      : build_bvh(boxes.data(), boxes.size(), wt_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
-            boxes = std::vector<Aabb>();
-            blas_depth = tree.max_depth;
-            tris.resize(recs.size());
-            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
-            for (size_t i = 0; i < recs.size(); ++i) {
-                const TriRec &r = recs[tree.order[i]];
-                const crt_instance_desc &id = s->instances[r.pad >> 1];
-                place_tri(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
-            }
-            root_frame = make_frame(tree.bounds);
-            nodes.reserve(tree.nodes.size());
-            for (const BvhNode &nd : tree.nodes) {
-                nodes.push_back(quantise(nd, root_frame));
-            }
-            n_top = tree.n_top;
-            root = 0;
-            for (InstanceRec &r : insts) {
-                r.frame = root_frame; // not read by the traversal of a world tree; blas_root stays a mesh id until the loop below
-            }
-        }
-        if (two_level) {
-            // items of the top-level tree: the cut through the grafted mesh's BLAS (if any), then one box per other instance
-            std::vector<Aabb> items;
-            std::vector<int32_t> item_ref; // what the leaf of an item becomes: a reference local to the grafted BLAS, or an instance leaf
-            std::vector<uint8_t> item_is_cut;
-            if (world_inst >= 0 && std::getenv("CRT_HIP_GRAFT_QNODES") && built_q[world_mesh].empty()) {
-                // (test hook: hand the host-built mesh over in the quantised form a device build delivers, so the CPU
-                // tests reach the read-back / re-quantise path below without a GPU)
-                for (const BvhNode &nd : built[world_mesh].nodes) {
-                    built_q[world_mesh].push_back(quantise(nd, blas_frame[world_mesh]));
-                }
-                built[world_mesh].nodes.clear();
-            }
-            const QFrame world_frame_in = world_inst >= 0 ? blas_frame[world_mesh] : QFrame{}; // the frame its quantised nodes are in
-            auto dequantised = [&](const QChild &c) {
-                Aabb b;
-                for (int a = 0; a < 3; ++a) {
-                    b.lo[a] = world_frame_in.base[a] + (float)c.q[a][0] * world_frame_in.step[a];
-                    b.hi[a] = world_frame_in.base[a] + (float)c.q[a][1] * world_frame_in.step[a];
-                }
-                return b;
-            };
-            if (world_inst >= 0) {
-                const std::vector<BvhNode> &wn = built[world_mesh].nodes;
-                const std::vector<QNode> &wq = built_q[world_mesh];
-                double inst_area = 0.0; // mean half surface area of the other instances' boxes
-                for (uint32_t i = 0; i < s->n_instances; ++i) {
-                    if ((int32_t)i != world_inst) {
-                        const Aabb &b = inst_boxes[i];
-                        const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
-                        inst_area += (dx * dy + dy * dz + dz * dx) / (double)(s->n_instances - 1);
-                    }
-                }
-                struct CutEntry {
-                    double area;
-                    Aabb box;
-                    int32_t ref;
-                    bool operator<(const CutEntry &o) const { return area < o.area; }
-                };
-                std::priority_queue<CutEntry> open; // inner nodes that may still be opened, largest first
-                std::vector<CutEntry> cut;
-                auto add_children = [&](int32_t node) {
-                    for (int k = 0; k < BVH_WIDTH; ++k) {
-                        CutEntry e;
-                        if (!wq.empty()) {
-                            const QChild &c = wq[(size_t)node].child[k];
-                            if (c.q[0][0] > c.q[0][1]) { // unused slot
-                                continue;
-                            }
-                            e.box = dequantised(c);
-                            e.ref = c.ref;
-                        } else {
-                            const BvhNode &nd = wn[(size_t)node];
-                            if (nd.c[k] == EMPTY_CHILD) {
-                                continue;
-                            }
-                            for (int a = 0; a < 3; ++a) {
-                                e.box.lo[a] = nd.lo[k][a];
-                                e.box.hi[a] = nd.hi[k][a];
-                            }
-                            e.ref = nd.c[k];
-                        }
-                        const double dx = (double)e.box.hi[0] - e.box.lo[0], dy = (double)e.box.hi[1] - e.box.lo[1],
-                                     dz = (double)e.box.hi[2] - e.box.lo[2];
-                        e.area = dx * dy + dy * dz + dz * dx;
-                        if (e.ref >= 0) {
-                            open.push(e);
-                        } else {
-                            cut.push_back(e); // a triangle leaf directly under an opened node
-                        }
-                    }
-                };
-                add_children(0);
-                // (how far to open: a cut of 1x, 4x, 16x, 64x the instance count was priced with the oracle's walker on a
-                // reduced C4 -- 4x is the flat optimum for camera, bounce and occlusion rays alike)
-                const size_t cap = 4 * (size_t)s->n_instances + 64;
-                while (!open.empty() && open.top().area > inst_area && cut.size() + open.size() + BVH_WIDTH <= cap) {
-                    const CutEntry e = open.top();
-                    open.pop();
-                    add_children(e.ref);
-                }
-                for (; !open.empty(); open.pop()) {
-                    cut.push_back(open.top());
-                }
-                for (const CutEntry &e : cut) {
-                    items.push_back(e.box);
-                    item_ref.push_back(e.ref);
-                    item_is_cut.push_back(1);
-                }
-            }
-            for (uint32_t i = 0; i < s->n_instances; ++i) {
-                if ((int32_t)i != world_inst) {
-                    items.push_back(inst_boxes[i]);
-                    item_ref.push_back(instance_leaf_ref(i));
-                    item_is_cut.push_back(0);
-                }
-            }
-            if (s->n_instances >= (1u << 28) - 1u) {
-                throw std::runtime_error("too many instances for the 28-bit leaf reference");
-            }
-            BuiltBvh tlas = build_bvh(items.data(), items.size(), 1, 0, 0, true, CRT_MAX_TOP_NODES_TWO_LEVEL, 1);
-            tlas_depth = tlas.max_depth;
-            root_frame = make_frame(tlas.bounds);
-            // where the grafted BLAS will lie: the per-mesh loop below appends the meshes in order behind the top-level nodes
-            int32_t world_node_base = (int32_t)tlas.nodes.size();
-            for (uint32_t m = 0; world_inst >= 0 && m < world_mesh; ++m) {
-                world_node_base += (int32_t)(built[m].nodes.size() + built_q[m].size());
-            }
-            const uint32_t world_tri_base = world_inst >= 0 ? (uint32_t)blas_root[world_mesh] : 0u;
-            for (BvhNode nd : tlas.nodes) {
-                for (int k = 0; k < BVH_WIDTH; ++k) {
-                    const int32_t c = nd.c[k];
-                    if (c >= 0 || c == EMPTY_CHILD) {
-                        continue;
-                    }
-                    const uint32_t id = (~(uint32_t)c) >> 3;
-                    int32_t ref = item_ref[id];
-                    if (item_is_cut[id]) { // local to the grafted BLAS -> global
-                        if (ref >= 0) {
-                            ref += world_node_base;
-                        } else {
-                            const uint32_t x = ~(uint32_t)ref;
-                            ref = (int32_t)~((((x >> 3) + world_tri_base) << 3) | (x & 7u));
-                        }
-                    }
-                    nd.c[k] = ref;
-                }
-                if (!std::getenv("CRT_HIP_NO_SLOT_ORDER")) {
-                    // Slot order is the order occlusion rays try the children in, and the order in which the children a
-                    // closest-hit ray does not take first are stacked: subtrees and triangles of the static mesh before
-                    // instances, so that a ray has found what the cheap part of the node holds (an occluder; a nearer hit
-                    // that culls the instance's box) before it pays for entering an instance.
-                    BvhNode ord = nd;
-                    int at = 0;
-                    for (int pass = 0; pass < 3; ++pass) {
-                        for (int k = 0; k < BVH_WIDTH; ++k) {
-                            const int kind = nd.c[k] == EMPTY_CHILD ? 2 : (is_instance_leaf(nd.c[k]) ? 1 : 0);
-                            if (kind == pass) {
-                                for (int a = 0; a < 3; ++a) {
-                                    ord.lo[at][a] = nd.lo[k][a];
-                                    ord.hi[at][a] = nd.hi[k][a];
-                                }
-                                ord.c[at++] = nd.c[k];
-                            }
-                        }
-                    }
-                    nd = ord;
-                }
-                nodes.push_back(quantise(nd, root_frame));
-            }
-            if (world_inst >= 0) {
-                blas_frame[world_mesh] = root_frame; // its nodes are reached from the top-level tree without a frame change
-                for (QNode &q : built_q[world_mesh]) { // device-built: from its own frame into that one, outward again
-                    for (int k = 0; k < BVH_WIDTH; ++k) {
-                        QChild &c = q.child[k];
-                        if (c.q[0][0] <= c.q[0][1]) {
-                            lbvh_quantise_child(c, dequantised(c), c.ref, root_frame);
-                        }
-                    }
-                }
-            }
-            n_top = tlas.n_top;
-        }
-        for (uint32_t m = 0; m < s->n_meshes; ++m) {
-            const int32_t node_base = (int32_t)nodes.size();
-            const uint32_t tri_base = (uint32_t)blas_root[m];
-            auto rebase = [&](int32_t c) -> int32_t {
-                if (c >= 0) {
-                    return c + node_base;
-                }
-                const uint32_t x = ~(uint32_t)c;
-                return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
-            };
-            for (QNode q : built_q[m]) { // device-built: quantised already, references local to the mesh
-                for (int k = 0; k < BVH_WIDTH; ++k) {
-                    q.child[k].ref = rebase(q.child[k].ref);
-                }
-                nodes.push_back(q);
-            }
-            for (BvhNode nd : built[m].nodes) {
-                for (int k = 0; k < BVH_WIDTH; ++k) {
-                    if (nd.c[k] != EMPTY_CHILD) {
-                        nd.c[k] = rebase(nd.c[k]);
-                    }
-                }
-                nodes.push_back(quantise(nd, blas_frame[m]));
-            }
-            blas_root[m] = node_base;
-            blas_top[m] = built[m].n_top;
-            built[m] = BuiltBvh();
-            built_q[m] = std::vector<QNode>();
-        }
-        // a ray's stack holds at most BVH_WIDTH-1 pending siblings per level of the path it is on,
-        // plus the instance-exit sentinel. The LDS part of the stack is fixed; the HBM slab behind it is
-        // sized from this number at upload, so no tree is "too deep" (the reference renders any scene)
-        ps->stack_need = (BVH_WIDTH - 1) * (blas_depth + tlas_depth) + 2;
-        if (tris.size() >= (1u << 28)) {
-            throw std::runtime_error("too many triangles for the 28-bit leaf reference");
-        }
-        for (InstanceRec &r : insts) {
-            r.blas_root = world_tree ? 0 : blas_root[r.blas_root];
-        }
-        if (world_inst >= 0) {
-            insts[(size_t)world_inst].blas_root = 0; // never entered: its subtrees hang in the top-level tree (node 0 = its root)
-        }
-        ps->world_inst = world_inst;
-        if (!two_level && !world_tree) {
-            const uint32_t mesh0 = s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id;
-            root = insts[0].blas_root;
-            n_top = blas_top[mesh0];
-            root_frame = blas_frame[mesh0];
-        }
-
-        phase("TLAS + quantisation");
-        // textures: sRGB -> linear in 8 bits, on the host, like the reference (render_embree.cpp:90-104)
-        std::vector<TexRec> &tex = ps->tex;
-        tex.assign(s->n_textures, TexRec{});
-        std::vector<uint8_t> &texels = ps->texels;
-        {
-            size_t total = 0;
-            for (uint32_t t = 0; t < s->n_textures; ++t) {
-                const crt_image_desc &im = s->textures[t];
-                if (im.width <= 0 || im.height <= 0 || im.channels < 1 || im.channels > 4 || !im.data) {
-                    throw std::runtime_error("bad texture");
-                }
-                total = (total + 15) / 16 * 16 + (size_t)tex_tiled_texels(im.width, im.height) * im.channels;
-            }
-            texels.reserve(total + 16);
-        }
-        uint8_t lut[256];
-        for (int v = 0; v < 256; ++v) {
-            const float x = srgb_to_linear(v / 255.f);
-            lut[v] = (uint8_t)std::min(std::max(x * 255.f, 0.f), 255.f);
-        }
-        // lay the textures out first, then copy + linearise them in parallel (1 GB of texels on a San-Miguel-class
-        // scene: 0.35 s on one core, and the only second-scale host phase left once the BVH comes from the device)
-        {
-            size_t total = 0;
-            for (uint32_t t = 0; t < s->n_textures; ++t) {
-                const crt_image_desc &im = s->textures[t];
-                total = (total + 15) / 16 * 16;
-                TexRec r;
-                std::memset(&r, 0, sizeof(r));
-                r.width = im.width;
-                r.height = im.height;
-                r.channels = im.channels;
-                if (total / 16 > 0xffffffffull) {
-                    throw std::runtime_error("more than 64 GB of texels");
-                }
-                r.offset16 = (uint32_t)(total / 16);
-                tex[t] = r;
-                if (tex_tiled_texels(im.width, im.height) > 0xffffffffull) {
-                    throw std::runtime_error("texture too large");
-                }
-                total += (size_t)tex_tiled_texels(im.width, im.height) * im.channels;
-            }
-            texels.assign(total, 0);
-            std::atomic<uint32_t> next_tex{0};
-            auto work = [&]() {
-                for (uint32_t t = next_tex.fetch_add(1); t < s->n_textures; t = next_tex.fetch_add(1)) {
-                    const crt_image_desc &im = s->textures[t];
-                    // rows of texels -> 8 x 4 tiles (crt_types.h tex_slot), linearising the colour channels on the way
-                    uint8_t *p = texels.data() + (size_t)tex[t].offset16 * 16;
-                    const uint8_t *src = static_cast<const uint8_t *>(im.data);
-                    const int convert_channels = im.color_space == CRT_COLORSPACE_SRGB ? std::min(3, im.channels) : 0;
-                    const uint32_t tiles_x = tex_tiles_x(im.width);
-                    for (int32_t y = 0; y < im.height; ++y) {
-                        const uint32_t row = tex_row_part(tiles_x, y);
-                        const uint8_t *s_row = src + (size_t)y * im.width * im.channels;
-                        for (int32_t x = 0; x < im.width; ++x) {
-                            uint8_t *d = p + (size_t)(row + tex_col_part(x)) * im.channels;
-                            for (int c = 0; c < im.channels; ++c) {
-                                const uint8_t v = s_row[(size_t)x * im.channels + c];
-                                d[c] = c < convert_channels ? lut[v] : v;
-                            }
-                        }
-                    }
-                }
-            };
-            std::vector<std::thread> pool;
-            const int n_workers = std::max(1, std::min<int>(n_threads, (int)s->n_textures));
-            for (int w = 1; w < n_workers; ++w) {
-                pool.emplace_back(work);
-            }
-            work();
-            for (std::thread &th : pool) {
-                th.join();
-            }
-        }
-        std::vector<float> &materials = ps->materials;
-        materials.assign((size_t)s->n_materials * 16, 0.f);
-        std::memcpy(materials.data(), s->materials, materials.size() * sizeof(float));
-        std::vector<float> &lights = ps->lights;
-        lights.assign((size_t)s->n_lights * 20, 0.f);
-        std::memcpy(lights.data(), s->lights, lights.size() * sizeof(float));
-
-        phase("textures");
-        ps->root_frame = root_frame;
-        ps->root = root;
-        ps->two_level = world_tree ? LEVELS_WORLD_TREE : two_level ? 1u : 0u;
-        ps->n_top = n_top;
-        ps->n_lights = s->n_lights;
-        ps->n_instances = s->n_instances;
-        ps->build_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
-}
-
-// device half of set_scene: the prepared arrays -> HBM, SceneView, traversal-stack slab
+// device half of set_scene (the host half: scene_prepare.cpp): the prepared arrays -> HBM, SceneView, traversal-stack slab
 void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 {
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1352,56 +490,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 
 } // namespace
 
-// Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
-// path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
-namespace {
-constexpr uint64_t PREP_MAGIC = 0x3430505250545243ull; // "CRTPRP04" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids)
-struct PrepHeader {
-    uint64_t magic, abi;
-    uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;
-    QFrame root_frame;
-    int32_t root;
-    uint32_t two_level, n_top, n_lights, n_instances, spp, stack_need;
-    int32_t world_inst;
-};
-template <typename T> bool prep_put(FILE *f, const std::vector<T> &v) { return v.empty() || std::fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
-template <typename T> bool prep_get(FILE *f, std::vector<T> &v, uint64_t n)
-{
-    v.resize(n);
-    return n == 0 || std::fread(v.data(), sizeof(T), n, f) == n;
-}
-} // namespace
-
 extern "C" {
-
-crt_hip_prepared_scene *crt_hip_prepare_scene_on(const crt_scene_desc *scene, int n_threads, int build_device)
-{
-    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
-    try {
-        if (build_device >= crt_hip_device_count()) {
-            throw std::runtime_error("prepare_scene: no such HIP device to build on");
-        }
-        prepare_scene(scene, ps.get(), n_threads > 0 ? n_threads : host_threads(), build_device);
-    } catch (const std::exception &e) {
-        g_create_error = e.what();
-        return nullptr;
-    }
-    return ps.release();
-}
-
-crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads)
-{
-    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
-    try {
-        prepare_scene(scene, ps.get(), n_threads > 0 ? n_threads : host_threads());
-    } catch (const std::exception &e) {
-        g_create_error = e.what();
-        return nullptr;
-    }
-    return ps.release();
-}
-
-void crt_hip_free_prepared_scene(crt_hip_prepared_scene *ps) { delete ps; }
 
 int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *ps)
 {
@@ -1431,140 +520,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
     });
 }
 
-int32_t crt_hip_prepared_scene_world_instance(const crt_hip_prepared_scene *ps) { return ps ? ps->world_inst : -1; }
 int32_t crt_hip_world_instance(crt_hip_ctx *ctx) { return ctx && ctx->has_scene ? ctx->sv.world_inst : -1; }
-
-int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *ps, uint64_t *n_nodes, uint64_t *n_tris,
-                                uint64_t *n_instances, int32_t *two_level, float *root_frame, int32_t *root,
-                                uint32_t *n_top_nodes, uint32_t *stack_need, double *build_ms)
-{
-    if (!ps) {
-        return fail(nullptr, CRT_HIP_EINVAL, "prepared scene is null");
-    }
-    if (n_nodes) {
-        *n_nodes = ps->nodes.size();
-    }
-    if (n_tris) {
-        *n_tris = ps->tris.size();
-    }
-    if (n_instances) {
-        *n_instances = ps->insts.size();
-    }
-    if (two_level) {
-        *two_level = (int32_t)ps->two_level;
-    }
-    if (root_frame) {
-        std::memcpy(root_frame, &ps->root_frame, sizeof(QFrame));
-    }
-    if (root) {
-        *root = ps->root;
-    }
-    if (n_top_nodes) {
-        *n_top_nodes = ps->n_top;
-    }
-    if (stack_need) {
-        *stack_need = ps->stack_need;
-    }
-    if (build_ms) {
-        *build_ms = ps->build_ms;
-    }
-    return CRT_HIP_OK;
-}
-
-int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *ps, void *nodes, void *tris, void *instances)
-{
-    if (!ps) {
-        return fail(nullptr, CRT_HIP_EINVAL, "prepared scene is null");
-    }
-    if (nodes) {
-        std::memcpy(nodes, ps->nodes.data(), ps->nodes.size() * sizeof(QNode));
-    }
-    if (tris) {
-        std::memcpy(tris, ps->tris.data(), ps->tris.size() * sizeof(TriRec));
-    }
-    if (instances) {
-        std::memcpy(instances, ps->insts.data(), ps->insts.size() * sizeof(InstanceRec));
-    }
-    return CRT_HIP_OK;
-}
-
-int crt_hip_prepared_scene_set_spp(crt_hip_prepared_scene *ps, uint32_t samples_per_pixel)
-{
-    if (!ps || samples_per_pixel == 0) {
-        return fail(nullptr, CRT_HIP_EINVAL, "prepared_scene_set_spp: bad arguments");
-    }
-    ps->spp = samples_per_pixel;
-    return CRT_HIP_OK;
-}
-
 int crt_hip_child_order(void) { return traversal_child_order(); }
 uint32_t crt_hip_lds_stack_entries(int two_level) { return traversal_lds_stack((uint32_t)two_level); }
-
-int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *path)
-{
-    if (!ps || !path) {
-        return fail(nullptr, CRT_HIP_EINVAL, "save_prepared_scene: bad arguments");
-    }
-    FILE *f = std::fopen(path, "wb");
-    if (!f) {
-        return fail(nullptr, CRT_HIP_EINVAL, std::string("cannot write ") + path);
-    }
-    PrepHeader h{};
-    h.magic = PREP_MAGIC;
-    h.abi = CRT_HIP_ABI_VERSION;
-    h.n_nodes = ps->nodes.size();
-    h.n_tris = ps->tris.size();
-    h.n_insts = ps->insts.size();
-    h.n_matids = ps->material_ids.size();
-    h.n_materials = ps->materials.size();
-    h.n_lights_f = ps->lights.size();
-    h.n_tex = ps->tex.size();
-    h.n_texels = ps->texels.size();
-    h.root_frame = ps->root_frame;
-    h.root = ps->root;
-    h.two_level = ps->two_level;
-    h.n_top = ps->n_top;
-    h.n_lights = ps->n_lights;
-    h.n_instances = ps->n_instances;
-    h.spp = ps->spp;
-    h.stack_need = ps->stack_need;
-    h.world_inst = ps->world_inst;
-    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && prep_put(f, ps->nodes) && prep_put(f, ps->tris) && prep_put(f, ps->tri_uvs) &&
-                    prep_put(f, ps->insts) && prep_put(f, ps->material_ids) && prep_put(f, ps->materials) && prep_put(f, ps->lights) &&
-                    prep_put(f, ps->tex) && prep_put(f, ps->texels);
-    const bool closed = std::fclose(f) == 0;
-    return ok && closed ? CRT_HIP_OK : fail(nullptr, CRT_HIP_EINVAL, std::string("short write to ") + path);
-}
-
-crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
-{
-    FILE *f = path ? std::fopen(path, "rb") : nullptr;
-    if (!f) {
-        g_create_error = std::string("cannot read ") + (path ? path : "(null)");
-        return nullptr;
-    }
-    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
-    PrepHeader h{};
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == PREP_MAGIC && h.abi == CRT_HIP_ABI_VERSION;
-    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->tris, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * h.n_tris) &&
-         prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
-         prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
-    std::fclose(f);
-    if (!ok) {
-        g_create_error = std::string("not a prepared scene of this build: ") + path;
-        return nullptr;
-    }
-    ps->root_frame = h.root_frame;
-    ps->root = h.root;
-    ps->two_level = h.two_level;
-    ps->n_top = h.n_top;
-    ps->n_lights = h.n_lights;
-    ps->n_instances = h.n_instances;
-    ps->spp = h.spp;
-    ps->stack_need = h.stack_need;
-    ps->world_inst = h.world_inst;
-    return ps.release();
-}
 
 // RenderEmbree::render (render_embree.cpp:135-216)
 int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], const float up_[3], float fovy,

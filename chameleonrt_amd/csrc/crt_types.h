@@ -12,7 +12,7 @@ namespace crt {
 //                              top-level tree of a scene with more than one instance: count == 8 (a value no
 //                              triangle leaf has: the builder makes leaves of <= 7) marks an INSTANCE leaf, instance
 //                              `first`; any other count is a triangle leaf of the instance that was grafted into the
-//                              top-level tree (SceneView::world_inst, crt_core.cpp), tested with the world-space ray
+//                              top-level tree (SceneView::world_inst, scene_prepare.cpp), tested with the world-space ray
 //                    c == EMPTY_CHILD -> unused slot of a node with fewer than BVH_WIDTH children (builder output only)
 // The BVH is 4-wide: one fetch decides four children, which about halves the chain of dependent
 // node fetches of a ray and the per-node bookkeeping (DESIGN.md "Traversal"; what bounds the kernel
@@ -150,7 +150,7 @@ struct SceneView {
 // transformed vertices. A ray walks that tree in world space from start to end (no instance entry, no second root,
 // no frame change, no exit) and is transformed into an instance's object space only to test a triangle of it, with
 // the two-level entry's expressions, so hits are bit-identical to the two-level walk and to the reference's
-// per-instance intersection. crt_core.cpp decides per scene (memory budget); traverse.h INST_TRIS.
+// per-instance intersection. scene_prepare.cpp decides per scene (memory budget); traverse.h INST_TRIS.
 constexpr uint32_t LEVELS_WORLD_TREE = 2u;
 
 constexpr uint32_t MATERIAL_TEXTURED = 0x80000000u; // flag on the entries of SceneView::material_ids (and HitBuf::mat)

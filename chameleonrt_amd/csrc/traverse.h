@@ -206,7 +206,7 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 //        lanes are refilled independently.
 //
 // INST_TRIS (with TWO_LEVEL = false): the scene has several instances but ONE tree over all of them in world space
-// (crt_core.cpp "world tree": every instance's triangles have records of their own, boxes around the transformed
+// (scene_prepare.cpp "world tree": every instance's triangles have records of their own, boxes around the transformed
 // vertices). Boxes are walked with the world-space ray and never change frame; a triangle record's last word says
 // whose it is, (instance << 1) | identity, and the triangle is tested -- like the reference's Embree instance -- with
 // the ray transformed into that instance's object space (same expressions as the two-level entry, so the same bits),
@@ -554,7 +554,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             const uint32_t x = ~(uint32_t)cur;
             const uint32_t first = x >> 3;
             // top level: a leaf is an instance (count field 7) or, in a scene whose static mesh was grafted into the
-            // top-level tree (crt_core.cpp), triangles of that mesh, tested right here with the world-space ray
+            // top-level tree (scene_prepare.cpp), triangles of that mesh, tested right here with the world-space ray
             if (TWO_LEVEL && !in_blas && cur != CUR_DONE && is_instance_leaf(cur)) {
                 const InstanceRec &in = sc.instances[first];
                 cur_inst = (int32_t)first;

@@ -54,7 +54,7 @@ int main(int argc, char **argv)
             boxes[i].hi[k] = c[k] + h[k];
         }
     }
-    const int max_leaf = getenv("BVH_CHECK_MAX_LEAF") ? atoi(getenv("BVH_CHECK_MAX_LEAF")) : 2; // the product default (crt_core.cpp)
+    const int max_leaf = getenv("BVH_CHECK_MAX_LEAF") ? atoi(getenv("BVH_CHECK_MAX_LEAF")) : 2; // the product default (scene_prepare.cpp)
     const BuiltBvh b = build_bvh(boxes.data(), n, max_leaf, 0, 0, false, 85, threads);
     const QFrame f = make_frame(b.bounds);
     std::vector<char> seen(n, 0);

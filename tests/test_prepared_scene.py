@@ -177,7 +177,7 @@ def test_world_tree_edge_cases(oracle, monkeypatch, tmp_path):
 def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkeypatch):
     """An identity instance whose mesh nothing else uses (the ground of the grove, the courtyard of the
     San-Miguel-like scene) is not entered like an instance: its BLAS is cut open and the subtrees hang in the
-    top-level tree next to the other instances (crt_core.cpp prepare_scene, crt_types.h). Top-level leaves are
+    top-level tree next to the other instances (scene_prepare.cpp, crt_types.h). Top-level leaves are
     instances iff their count field is 7, none of them names the grafted instance; the hits are those of the
     ungrafted build (CRT_HIP_NO_GRAFT), which the other tests of this file compare with brute force, bit for bit;
     rays need fewer instance entries, seen here as fewer node visits for rays that start on surfaces."""
