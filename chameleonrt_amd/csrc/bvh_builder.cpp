@@ -1,6 +1,7 @@
 // bvh_builder.cpp — parallel top-down binned-SAH build, collapse to 4-wide nodes, cache-aware node layout.
 #include "bvh_builder.h"
 #include "bvh_device.h"
+#include "host_parallel.h"
 #include "lbvh.h"
 
 #include <algorithm>
@@ -57,15 +58,15 @@ inline float half_area(const Aabb &b)
     return dx * dy + dy * dz + dz * dx;
 }
 
-struct TNode {
+struct TNode { // no default member initialisers: the node pool is raw storage until Builder::alloc() hands a node out
     Aabb box;
-    int32_t left = -1, right = -1; // temp-node indices; -1 = leaf
-    uint32_t first = 0, count = 0;
-    uint32_t depth = 0;
+    int32_t left, right; // temp-node indices; -1 = leaf
+    uint32_t first, count;
+    uint32_t depth;
     // Collapse to 4-wide nodes (see build_bvh): cheapest summed surface area of the wide nodes below
     // this node if it may use 1 (= it is the root of a wide node), 2 or 3 child slots of its
     // parent's wide node. Filled when both children are complete, i.e. inside the parallel build.
-    double slot_cost[3] = {0.0, 0.0, 0.0};
+    double slot_cost[3];
 };
 
 // One item as the builder moves it around: 32 B, partitioned IN PLACE so every pass streams
@@ -102,15 +103,25 @@ struct Bins { // n_bins bins on each of the 3 axes, filled in one pass over the 
 };
 
 struct Builder {
-    std::vector<Prim> prims;
-    std::vector<TNode> tn;
+    std::unique_ptr<Prim[]> prims; // raw storage, filled by several threads (build_bvh)
+    // 2n nodes of raw storage: pages are first touched by whichever build thread allocates a node there (a
+    // value-initialised vector made one thread write 1.4 GB before the 10 M-triangle build could start)
+    std::unique_ptr<TNode[]> tn;
     std::atomic<int32_t> next{0};
     std::atomic<int> spare_threads{0};
     int max_leaf;
     int n_threads = 1;
     int n_bins = MAX_BINS;
 
-    int32_t alloc() { return next.fetch_add(1); }
+    int32_t alloc()
+    {
+        const int32_t i = next.fetch_add(1);
+        TNode &t = tn[i];
+        t.left = t.right = -1;
+        t.first = t.count = t.depth = 0;
+        t.slot_cost[0] = t.slot_cost[1] = t.slot_cost[2] = 0.0;
+        return i;
+    }
 
     static inline float centroid(const Prim &p, int a) { return 0.5f * (p.lo[a] + p.hi[a]); }
 
@@ -325,12 +336,12 @@ struct Builder {
         } else if (best_axis >= 0) {
             const int axis = best_axis;
             const float lo = cb.lo[axis], sc = scale[axis];
-            auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+            auto it = std::partition(prims.get() + first, prims.get() + first + count, [&](const Prim &p) {
                 int b = (int)((centroid(p, axis) - lo) * sc);
                 b = std::min(std::max(b, 0), N_BINS - 1);
                 return b <= best_bin;
             });
-            mid = (uint32_t)(it - prims.begin());
+            mid = (uint32_t)(it - prims.get());
         }
         if (mid == first || mid == first + count) {
             // fall back to an object-median split along the widest box axis
@@ -343,7 +354,7 @@ struct Builder {
                 }
             }
             mid = first + count / 2;
-            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+            std::nth_element(prims.get() + first, prims.get() + mid, prims.get() + first + count,
                              [&](const Prim &a, const Prim &b) {
                                  const float ca = centroid(a, axis), cb2 = centroid(b, axis);
                                  return ca != cb2 ? ca < cb2 : a.id < b.id;
@@ -430,17 +441,19 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     // renders 8 % slower -- greedy SAH over a few thousand overlapping boxes is that fickle; the finer bins pay for
     // triangles, see CRT_BVH_BINS)
     b.n_bins = leaf_holds_item_id ? std::min(16, MAX_BINS) : MAX_BINS;
-    b.prims.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        Prim &p = b.prims[i];
-        for (int k = 0; k < 3; ++k) {
-            p.lo[k] = boxes[i].lo[k];
-            p.hi[k] = boxes[i].hi[k];
+    b.prims.reset(new Prim[n]);
+    parallel_for(n, b.n_threads, 1u << 16, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            Prim &p = b.prims[i];
+            for (int k = 0; k < 3; ++k) {
+                p.lo[k] = boxes[i].lo[k];
+                p.hi[k] = boxes[i].hi[k];
+            }
+            p.id = (uint32_t)i;
+            p.pad = 0;
         }
-        p.id = (uint32_t)i;
-        p.pad = 0;
-    }
-    b.tn.resize(2 * n);
+    });
+    b.tn.reset(new TNode[2 * n]);
     b.spare_threads = std::max(0, n_threads - 1);
     phase("setup");
     const int32_t root = b.build(0, (uint32_t)n, 0);
@@ -449,9 +462,11 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     BuiltBvh out;
     out.bounds = b.tn[root].box;
     out.order.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        out.order[i] = b.prims[i].id;
-    }
+    parallel_for(n, b.n_threads, 1u << 16, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            out.order[i] = b.prims[i].id;
+        }
+    });
     const int32_t n_tn = b.next.load();
     auto is_inner = [&](int32_t t) { return b.tn[t].left >= 0; };
     auto half_area = [&](int32_t t) {
@@ -557,7 +572,9 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     // it in memory)
     std::vector<int32_t> final_idx(n_tn, -1);
     std::vector<int32_t> order;  // root temp node of every wide node, in final order
+    std::vector<Wide> wides;     // and its children (worked out once, here; the emit pass below reuses them)
     order.reserve(n_tn / 3 + 1);
+    wides.reserve(n_tn / 3 + 1);
     uint32_t max_depth = 1;
     if (is_inner(root)) {
         std::queue<std::pair<int32_t, uint32_t>> q;
@@ -569,6 +586,7 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
             order.push_back(t);
             max_depth = std::max(max_depth, dep);
             const Wide w = wide_children(t);
+            wides.push_back(w);
             for (int k = 0; k < w.n; ++k) {
                 if (is_inner(w.kid[k])) {
                     q.push({w.kid[k], dep + 1});
@@ -587,6 +605,7 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
                 order.push_back(t);
                 max_depth = std::max(max_depth, dep);
                 const Wide w = wide_children(t);
+                wides.push_back(w);
                 for (int k = w.n - 1; k >= 0; --k) {
                     if (is_inner(w.kid[k])) {
                         stack.push_back({w.kid[k], dep + 1});
@@ -631,14 +650,16 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         return out;
     }
     out.nodes.resize(order.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        const Wide w = wide_children(order[i]);
-        BvhNode nd = empty_node();
-        for (int k = 0; k < w.n; ++k) {
-            set_child(nd, k, w.kid[k]);
+    parallel_for(order.size(), b.n_threads, 1u << 14, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const Wide &w = wides[i];
+            BvhNode nd = empty_node();
+            for (int k = 0; k < w.n; ++k) {
+                set_child(nd, k, w.kid[k]);
+            }
+            out.nodes[i] = nd;
         }
-        out.nodes[i] = nd;
-    }
+    });
     phase("emit nodes");
     return out;
 }

@@ -27,6 +27,7 @@
 
 #include "bvh_builder.h"
 #include "bvh_device.h"
+#include "host_parallel.h"
 #include "kernels.h"
 #include "lbvh.h"
 
@@ -373,37 +374,37 @@ struct ScenePreparer {
                     continue;
                 }
             }
-            std::vector<TriRec> recs;
-            std::vector<Aabb> boxes;
-            {
-                uint64_t n_mesh_tris = 0; // reserve ONCE: growing per geometry re-copies everything each time
-                for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                    n_mesh_tris += s->geometries[md.first_geometry + k].n_triangles;
-                }
-                recs.reserve(n_mesh_tris);
-                boxes.reserve(n_mesh_tris);
+            uint64_t n_mesh_tris = 0;
+            for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                n_mesh_tris += s->geometries[md.first_geometry + k].n_triangles;
             }
+            std::vector<TriRec> recs(n_mesh_tris);
+            std::vector<Aabb> boxes(n_mesh_tris);
+            uint64_t at0 = 0;
             for (uint32_t k = 0; k < md.n_geometries; ++k) {
                 const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                for (uint64_t t = 0; t < gd.n_triangles; ++t) {
-                    const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
-                    const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
-                    const float *v2 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 2];
-                    TriRec r;
-                    Aabb b;
-                    for (int a = 0; a < 3; ++a) {
-                        r.v0[a] = v0[a];
-                        r.e1[a] = v0[a] - v1[a];
-                        r.e2[a] = v2[a] - v0[a];
-                        b.lo[a] = std::min(v0[a], std::min(v1[a], v2[a]));
-                        b.hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
+                parallel_for((size_t)gd.n_triangles, n_threads, 1u << 15, [&](size_t lo, size_t hi) {
+                    for (uint64_t t = lo; t < hi; ++t) {
+                        const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
+                        const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
+                        const float *v2 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 2];
+                        TriRec r;
+                        Aabb b;
+                        for (int a = 0; a < 3; ++a) {
+                            r.v0[a] = v0[a];
+                            r.e1[a] = v0[a] - v1[a];
+                            r.e2[a] = v2[a] - v0[a];
+                            b.lo[a] = std::min(v0[a], std::min(v1[a], v2[a]));
+                            b.hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
+                        }
+                        r.geom = k;
+                        r.prim = (uint32_t)t;
+                        r.pad = 0;
+                        recs[at0 + t] = r;
+                        boxes[at0 + t] = b;
                     }
-                    r.geom = k;
-                    r.prim = (uint32_t)t;
-                    r.pad = 0;
-                    recs.push_back(r);
-                    boxes.push_back(b);
-                }
+                });
+                at0 += gd.n_triangles;
             }
             if (recs.empty()) {
                 throw std::runtime_error("mesh without triangles");
@@ -416,9 +417,11 @@ struct ScenePreparer {
             const size_t tri_base = tris.size();
             tris.resize(tri_base + recs.size());
             tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
-            for (size_t i = 0; i < recs.size(); ++i) {
-                place_tri(md, recs[built[m].order[i]], tri_base + i);
-            }
+            parallel_for(recs.size(), n_threads, 1u << 15, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    place_tri(md, recs[built[m].order[i]], tri_base + i);
+                }
+            });
             blas_bounds[m] = built[m].bounds;
             blas_frame[m] = make_frame(built[m].bounds);
             // re-base the node / leaf references later, once the TLAS size is known
@@ -529,11 +532,21 @@ struct ScenePreparer {
             // bit for bit as in the two-level walk); the box bounds the transformed vertices, padded like an instance box
             // (the test ray is a rounded transform of the world ray) -- and quantisation rounds outward by >= 1 quantum
             // of the scene's extent on top of that.
-            std::vector<TriRec> recs;
-            std::vector<Aabb> boxes;
-            recs.reserve(instanced_tris);
-            boxes.reserve(instanced_tris);
+            std::vector<TriRec> recs(instanced_tris);
+            std::vector<Aabb> boxes(instanced_tris);
+            // where each instance's records start, so that the instances can be filled side by side
+            std::vector<uint64_t> first_rec(s->n_instances + 1, 0);
             for (uint32_t i = 0; i < s->n_instances; ++i) {
+                const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
+                uint64_t n_inst_tris = 0;
+                for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                    n_inst_tris += s->geometries[md.first_geometry + k].n_triangles;
+                }
+                first_rec[i + 1] = first_rec[i] + n_inst_tris;
+            }
+            // (a scene is one big static instance plus many small ones, or many alike: instances are dealt out one at a
+            // time, and a big one is cut by geometry ranges inside fill_instance)
+            auto fill_instance = [&](uint32_t i, int threads) {
                 const crt_instance_desc &id = s->instances[i];
                 const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
                 const float *m = id.transform;
@@ -559,32 +572,53 @@ struct ScenePreparer {
                         }
                     }
                     pad = 1e-5f * std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
-                    if (!(pad >= 0.f)) { // an instance without vertices that any triangle uses
+                    if (!(pad >= 0.f)) { // an instance without vertices
                         pad = 0.f;
                     }
                 }
+                uint64_t at0 = first_rec[i];
                 for (uint32_t k = 0; k < md.n_geometries; ++k) {
                     const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                    for (uint64_t t = 0; t < gd.n_triangles; ++t) {
-                        const float *v[3] = {gd.vertices + 3 * (size_t)gd.indices[3 * t], gd.vertices + 3 * (size_t)gd.indices[3 * t + 1],
-                                             gd.vertices + 3 * (size_t)gd.indices[3 * t + 2]};
-                        TriRec r;
-                        Aabb b;
-                        for (int a = 0; a < 3; ++a) {
-                            r.v0[a] = v[0][a];
-                            r.e1[a] = v[0][a] - v[1][a];
-                            r.e2[a] = v[2][a] - v[0][a];
-                            const float w0 = to_world(v[0], a), w1 = to_world(v[1], a), w2 = to_world(v[2], a);
-                            b.lo[a] = std::min(w0, std::min(w1, w2)) - pad;
-                            b.hi[a] = std::max(w0, std::max(w1, w2)) + pad;
+                    parallel_for((size_t)gd.n_triangles, threads, 1u << 15, [&](size_t lo, size_t hi) {
+                        for (uint64_t t = lo; t < hi; ++t) {
+                            const float *v[3] = {gd.vertices + 3 * (size_t)gd.indices[3 * t], gd.vertices + 3 * (size_t)gd.indices[3 * t + 1],
+                                                 gd.vertices + 3 * (size_t)gd.indices[3 * t + 2]};
+                            TriRec r;
+                            Aabb b;
+                            for (int a = 0; a < 3; ++a) {
+                                r.v0[a] = v[0][a];
+                                r.e1[a] = v[0][a] - v[1][a];
+                                r.e2[a] = v[2][a] - v[0][a];
+                                const float w0 = to_world(v[0], a), w1 = to_world(v[1], a), w2 = to_world(v[2], a);
+                                b.lo[a] = std::min(w0, std::min(w1, w2)) - pad;
+                                b.hi[a] = std::max(w0, std::max(w1, w2)) + pad;
+                            }
+                            r.geom = k;
+                            r.prim = (uint32_t)t;
+                            r.pad = (i << 1) | (ident ? 1u : 0u);
+                            recs[at0 + t] = r;
+                            boxes[at0 + t] = b;
                         }
-                        r.geom = k;
-                        r.prim = (uint32_t)t;
-                        r.pad = (i << 1) | (ident ? 1u : 0u);
-                        recs.push_back(r);
-                        boxes.push_back(b);
+                    });
+                    at0 += gd.n_triangles;
+                }
+            };
+            {
+                // big instances one after the other with all threads inside, the small ones dealt out to the threads
+                const uint64_t big = std::max<uint64_t>(1u << 16, instanced_tris / (uint64_t)std::max(1, n_threads));
+                std::vector<uint32_t> small;
+                for (uint32_t i = 0; i < s->n_instances; ++i) {
+                    if (first_rec[i + 1] - first_rec[i] >= big) {
+                        fill_instance(i, n_threads);
+                    } else {
+                        small.push_back(i);
                     }
                 }
+                parallel_for(small.size(), n_threads, 4, [&](size_t lo, size_t hi) {
+                    for (size_t j = lo; j < hi; ++j) {
+                        fill_instance(small[j], 1);
+                    }
+                });
             }
             if (recs.empty()) {
                 throw std::runtime_error("scene without triangles");
@@ -596,16 +630,20 @@ struct ScenePreparer {
             blas_depth = tree.max_depth;
             tris.resize(recs.size());
             tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
-            for (size_t i = 0; i < recs.size(); ++i) {
-                const TriRec &r = recs[tree.order[i]];
-                const crt_instance_desc &id = s->instances[r.pad >> 1];
-                place_tri(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
-            }
+            parallel_for(recs.size(), n_threads, 1u << 15, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    const TriRec &r = recs[tree.order[i]];
+                    const crt_instance_desc &id = s->instances[r.pad >> 1];
+                    place_tri(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
+                }
+            });
             root_frame = make_frame(tree.bounds);
-            nodes.reserve(tree.nodes.size());
-            for (const BvhNode &nd : tree.nodes) {
-                nodes.push_back(quantise(nd, root_frame));
-            }
+            nodes.resize(tree.nodes.size());
+            parallel_for(tree.nodes.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    nodes[i] = quantise(tree.nodes[i], root_frame);
+                }
+            });
             n_top = tree.n_top;
             root = 0;
             for (InstanceRec &r : insts) {
@@ -803,14 +841,19 @@ struct ScenePreparer {
                 }
                 nodes.push_back(q);
             }
-            for (BvhNode nd : built[m].nodes) {
-                for (int k = 0; k < BVH_WIDTH; ++k) {
-                    if (nd.c[k] != EMPTY_CHILD) {
-                        nd.c[k] = rebase(nd.c[k]);
+            const size_t host_base = nodes.size();
+            nodes.resize(host_base + built[m].nodes.size());
+            parallel_for(built[m].nodes.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    BvhNode nd = built[m].nodes[i];
+                    for (int k = 0; k < BVH_WIDTH; ++k) {
+                        if (nd.c[k] != EMPTY_CHILD) {
+                            nd.c[k] = rebase(nd.c[k]);
+                        }
                     }
+                    nodes[host_base + i] = quantise(nd, blas_frame[m]);
                 }
-                nodes.push_back(quantise(nd, blas_frame[m]));
-            }
+            });
             blas_root[m] = node_base;
             blas_top[m] = built[m].n_top;
             built[m] = BuiltBvh();
