@@ -102,6 +102,24 @@ bool is_identity(const float m[16])
     return std::memcmp(m, id, sizeof(id)) == 0;
 }
 
+// How far the world box of an instance's transformed vertices (two-level) or of one of its triangles (world tree) is
+// pushed out. What lies under the box is intersected with a TRANSFORMED ray, o' = W o, d' = W d in float: a hit found
+// in object space at parameter t sits, in world space, at M (o' + t d') = o + t d + M e with |M e| of the order
+// eps * cond(M) * (size of the coordinates involved) -- and the walk only gets there if the world-space ray enters the
+// box. 1e-5 of the instance's extent covers rotations and moderate scales; the second term keeps a badly conditioned
+// transform (an instance stretched 1000 : 1) from losing hits. m: object_to_world, column-major 4x4; w2o: its inverse's
+// affine part as InstanceRec stores it; scene_mag: largest |coordinate| of the scene's world bounds.
+float instance_pad(const float m[16], const float w2o[12], float ext, float scene_mag)
+{
+    float nm = 0.f, nw = 0.f; // infinity norms of the linear parts
+    for (int r = 0; r < 3; ++r) {
+        nm = std::max(nm, std::fabs(m[r]) + std::fabs(m[4 + r]) + std::fabs(m[8 + r]));
+        nw = std::max(nw, std::fabs(w2o[r]) + std::fabs(w2o[3 + r]) + std::fabs(w2o[6 + r]));
+    }
+    const float pad = std::max(1e-5f * ext, 8.f * 1.1920929e-7f * nm * nw * scene_mag);
+    return pad >= 0.f && std::isfinite(pad) ? pad : 0.f;
+}
+
 void check_scene(const crt_scene_desc *s)
 {
     if (!s) {
@@ -186,9 +204,11 @@ bool world_tree_wanted(uint64_t instanced_tris)
     if (levels != nullptr && std::strcmp(levels, "world") == 0) {
         return true;
     }
-    // ~95 bytes per triangle (record, uv record, its share of the nodes): 2^27 triangles are 12.7 GB of a 288 GB part
+    // ~95 bytes per triangle in HBM (record, uv record, its share of the nodes): 2^26 triangles are 6.4 GB of a 288 GB
+    // part. The budget is set by the HOST: the SAH build over them needs ~300 bytes per triangle while it runs (records,
+    // boxes, the builder's items and temporary nodes) -- 20 GB for 2^26.
     const char *cap = std::getenv("CRT_HIP_WORLD_TREE_MAX_TRIS");
-    const uint64_t budget = cap != nullptr ? std::strtoull(cap, nullptr, 10) : (1ull << 27);
+    const uint64_t budget = cap != nullptr ? std::strtoull(cap, nullptr, 10) : (1ull << 26);
     return CRT_WORLD_TREE_DEFAULT && instanced_tris <= budget;
 }
 
@@ -510,13 +530,23 @@ struct ScenePreparer {
                     }
                 }
             }
-            // pad: the BLAS is walked with a transformed (rounded) ray
-            const float ext = std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
-            for (int a = 0; a < 3; ++a) {
-                wb.lo[a] -= 1e-5f * ext;
-                wb.hi[a] += 1e-5f * ext;
-            }
             inst_boxes[i] = wb;
+        }
+        // pad: the BLAS is walked with a transformed (rounded) ray (instance_pad)
+        float scene_mag = 0.f;
+        for (const Aabb &b : inst_boxes) {
+            for (int a = 0; a < 3; ++a) {
+                scene_mag = std::max(scene_mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+            }
+        }
+        for (uint32_t i = 0; i < s->n_instances && !world_tree; ++i) {
+            Aabb &wb = inst_boxes[i];
+            const float ext = std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
+            const float pad = insts[i].identity ? 1e-5f * ext : instance_pad(s->instances[i].transform, insts[i].w2o, ext, scene_mag);
+            for (int a = 0; a < 3; ++a) {
+                wb.lo[a] -= pad;
+                wb.hi[a] += pad;
+            }
         }
     }
 
@@ -544,6 +574,41 @@ struct ScenePreparer {
                 }
                 first_rec[i + 1] = first_rec[i] + n_inst_tris;
             }
+            // world box of every instance's vertices: its extent and the scene's magnitude set the padding (instance_pad)
+            std::vector<Aabb> inst_world(s->n_instances);
+            parallel_for(s->n_instances, n_threads, 1, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    const crt_instance_desc &id = s->instances[i];
+                    const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
+                    const float *m = id.transform;
+                    const bool ident = insts[i].identity != 0u;
+                    Aabb wb;
+                    for (int a = 0; a < 3; ++a) {
+                        wb.lo[a] = INFINITY;
+                        wb.hi[a] = -INFINITY;
+                    }
+                    for (uint32_t k = 0; k < md.n_geometries; ++k) {
+                        const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
+                        for (uint64_t v = 0; v < gd.n_vertices; ++v) {
+                            const float *p = gd.vertices + 3 * v;
+                            for (int a = 0; a < 3; ++a) {
+                                const float w = ident ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
+                                wb.lo[a] = std::min(wb.lo[a], w);
+                                wb.hi[a] = std::max(wb.hi[a], w);
+                            }
+                        }
+                    }
+                    inst_world[i] = wb;
+                }
+            });
+            float scene_mag = 0.f;
+            for (const Aabb &b : inst_world) {
+                for (int a = 0; a < 3; ++a) {
+                    if (b.lo[a] <= b.hi[a]) {
+                        scene_mag = std::max(scene_mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+                    }
+                }
+            }
             // (a scene is one big static instance plus many small ones, or many alike: instances are dealt out one at a
             // time, and a big one is cut by geometry ranges inside fill_instance)
             auto fill_instance = [&](uint32_t i, int threads) {
@@ -554,27 +619,10 @@ struct ScenePreparer {
                 auto to_world = [&](const float *p, int a) {
                     return ident ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
                 };
-                float pad = 0.f;
+                float pad = 0.f; // an identity instance's triangles are tested with the world ray itself
                 if (!ident) {
-                    Aabb wb;
-                    for (int a = 0; a < 3; ++a) {
-                        wb.lo[a] = INFINITY;
-                        wb.hi[a] = -INFINITY;
-                    }
-                    for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                        const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                        for (uint64_t v = 0; v < gd.n_vertices; ++v) {
-                            for (int a = 0; a < 3; ++a) {
-                                const float w = to_world(gd.vertices + 3 * v, a);
-                                wb.lo[a] = std::min(wb.lo[a], w);
-                                wb.hi[a] = std::max(wb.hi[a], w);
-                            }
-                        }
-                    }
-                    pad = 1e-5f * std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2]));
-                    if (!(pad >= 0.f)) { // an instance without vertices
-                        pad = 0.f;
-                    }
+                    const Aabb &wb = inst_world[i];
+                    pad = instance_pad(m, insts[i].w2o, std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2])), scene_mag);
                 }
                 uint64_t at0 = first_rec[i];
                 for (uint32_t k = 0; k < md.n_geometries; ++k) {

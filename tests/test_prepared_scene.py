@@ -173,6 +173,57 @@ def test_world_tree_edge_cases(oracle, monkeypatch, tmp_path):
     ps.close()
 
 
+@pytest.mark.parametrize("levels", ["world", "two"])
+def test_badly_conditioned_instances_lose_no_hits(levels, oracle, monkeypatch):
+    """Instances stretched 2000 : 1 (and squeezed 1 : 2000) far from the origin: what lies under a world-space box is
+    intersected with a transformed, i.e. rounded, ray, so the boxes must be padded by the transform's conditioning
+    (scene_prepare.cpp instance_pad) on top of the outward quantisation. Rays aimed AT the surfaces: every brute-force
+    hit must be found through the tree, whichever structure."""
+    from chameleonrt_amd.scene import Camera, Geometry, Instance, Mesh, ParameterizedMesh, Scene, disney_material, obj_default_light
+    n, stretch, shift = 40, 2000.0, 800.0
+    u, v = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n), indexing="ij")
+    verts = np.stack([u.ravel(), 0.05 * np.sin(3 * u.ravel()) * np.cos(2 * v.ravel()), v.ravel()], 1).astype(np.float32)
+    idx = [[i * n + j + d for d in tri] for i in range(n - 1) for j in range(n - 1) for tri in ((0, 1, n), (1, n + 1, n))]
+    patch = Mesh([Geometry(verts, np.array(idx, np.uint32), None)])
+
+    def trs(t, s, ry):
+        m = np.eye(4, dtype=np.float32)
+        c, si = np.cos(ry), np.sin(ry)
+        m[:3, :3] = np.array([[c, 0, si], [0, 1, 0], [-si, 0, c]], np.float32) @ np.diag(np.asarray(s, np.float32))
+        m[:3, 3] = t
+        return m.T.reshape(16).astype(np.float32)
+
+    insts = [Instance(trs([shift, 0, shift], [stretch, 1.0, 1.0], 0.6), 0),
+             Instance(trs([shift, 3, shift + 5], [1.0, 1.0, 1.0 / stretch], 1.2), 0),
+             Instance(trs([shift - 3, -2, shift], [30.0, 30.0, 30.0], 0.1), 0)]
+    sc = Scene(meshes=[patch], parameterized_meshes=[ParameterizedMesh(0, [0])], instances=insts, materials=[disney_material()],
+               lights=[obj_default_light()],
+               cameras=[Camera(np.array([shift, 40, shift + 60], np.float32), np.array([shift, 0, shift], np.float32),
+                               np.array([0, 1, 0], np.float32), 50.0)])
+    rng = np.random.default_rng(1)
+    per = 12000
+    tgt = []
+    for it in sc.instances:
+        m = np.asarray(it.transform, np.float32).reshape(4, 4).T
+        p = np.stack([rng.uniform(-1, 1, per), np.zeros(per), rng.uniform(-1, 1, per)], 1).astype(np.float32)
+        tgt.append((p @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+    tgt = np.concatenate(tgt)
+    org = (np.asarray(sc.cameras[0].position, np.float32) + rng.normal(size=tgt.shape).astype(np.float32) * 5).astype(np.float32)
+    dirs = tgt - org
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    c = oracle.OracleScene(sc).trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    monkeypatch.setenv("CRT_HIP_LEVELS", levels)
+    ps = PreparedScene(sc)
+    bvh = ps.bvh()
+    ps.close()
+    w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
+    hit = c["inst"] >= 0
+    assert hit.mean() > 0.9
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w[k], c[k]), k
+    assert np.array_equal(w["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["grove_two_level", "sanmiguel_small_instanced"])
 def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkeypatch):
     """An identity instance whose mesh nothing else uses (the ground of the grove, the courtyard of the
