@@ -252,7 +252,7 @@ struct ScenePreparer {
     ScenePreparer(const crt_scene_desc *scene, crt_hip_prepared_scene *prepared, int threads, int device)
         : s(scene), ps(prepared), n_threads(threads), build_device(device)
     {
-        }
+    }
 
     void phase(const char *what)
     {
@@ -261,7 +261,7 @@ struct ScenePreparer {
             std::fprintf(stderr, "[crt_hip] set_scene %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
         }
         t_phase = now;
-        }
+    }
 
     void run()
     {
@@ -288,7 +288,7 @@ struct ScenePreparer {
         ps->n_lights = s->n_lights;
         ps->n_instances = s->n_instances;
         ps->build_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
-        }
+    }
 
     // Several instances: either a top-level tree over instances (two-level traversal, what Embree does:
     // embree_utils.cpp:90-129), or -- when the instanced triangles fit a memory budget, which on a 288 GB part is
