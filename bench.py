@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C4", help="BASELINE.json config: C1..C5 (C4F: C4 flattened, no glass)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="0 = skip the CPU baseline and the in-run parity check; otherwise both run on the FIXED tile sample of "
+                         "the workload (sample_tiles): the same tiles whatever the box, so the figure is comparable between runs")
     ap.add_argument("--schedule", default=None, choices=["serial", "overlap"],
                     help="serial: the 17 launches of a frame one after the other (default at N = 1: every kernel's event span is its "
                          "own execution time, which the roofline needs); overlap: the occlusion launch of bounce b next to the "
@@ -55,6 +57,7 @@ def parse():
                          "over per-instance triangle records (world); default: the library's choice (world while the instanced "
                          "triangles fit its memory budget)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-schedule", action="store_true", help="N = 1: do not also time the other launch schedule")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
     return ap.parse_args()
@@ -71,6 +74,26 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def sample_tiles(width, height, spp):
+    """The fixed sample of 64x64 tiles the CPU baseline is timed on and the in-run parity check compares: every k-th tile
+    of the image (row-major tile ids, offset k // 2), k chosen from the workload alone so that the sample holds about
+    4.8 M pixel-samples (C4: every 7th of 510 tiles = 73 tiles, ~17 M rays, 15-20 s of the scalar restatement on 16 cores)."""
+    ntx, nty = (width + 63) // 64, (height + 63) // 64
+    ntiles = ntx * nty
+    stride = max(1, int(round(ntiles * 4096 * spp / 4.8e6)))
+    return list(range(stride // 2, ntiles, stride)), ntiles
+
+
+def tile_pixel_mask(width, height, tiles):
+    import numpy as np
+    ntx = (width + 63) // 64
+    m = np.zeros((height, width), bool)
+    for t in tiles:
+        tx, ty = (t % ntx) * 64, (t // ntx) * 64
+        m[ty:ty + 64, tx:tx + 64] = True
+    return m
 
 
 def wrap_device_buffer(ptr, nbytes):
@@ -124,7 +147,9 @@ class FrameLoop:
 def timed_frames(loop, args, dist, first_frame):
     """W warm-up + exactly K timed steps, barrier + synchronize on both sides; sums over the K steps."""
     import torch
-    acc = dict(rays=0, closest_rays=0, shadow_rays=0, closest_ms=0.0, shadow_ms=0.0, shade_ms=0.0)
+    acc = dict(rays=0, closest_rays=0, shadow_rays=0, closest_ms=0.0, shadow_ms=0.0, shade_ms=0.0, raygen_ms=0.0, accumulate_ms=0.0)
+    for k in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
+        acc[k] = [0.0] * MAX_PATH_DEPTH
     for f in range(args.warmup):
         loop.step(first_frame + f)
     loop.drain()
@@ -140,6 +165,12 @@ def timed_frames(loop, args, dist, first_frame):
         acc["closest_ms"] += st.closest_ms
         acc["shadow_ms"] += st.shadow_ms
         acc["shade_ms"] += st.shade_ms
+        acc["raygen_ms"] += st.raygen_ms
+        acc["accumulate_ms"] += st.accumulate_ms
+        for name in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
+            arr = getattr(st, name)
+            for b in range(MAX_PATH_DEPTH):
+                acc[name][b] += arr[b]
     loop.drain()  # the last frame's gather + assemble belong to the timed region
     torch.cuda.synchronize()
     if dist:
@@ -273,6 +304,22 @@ def main():
                        "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},
         }
 
+    # ---- N = 1: the same frames with the other launch schedule (the library's default is the overlapped one; the
+    # headline times the serial one because only then is a kernel's event span its own execution time) ----
+    if world == 1 and rank == 0 and not args.no_other_schedule:
+        other_sched = "overlap" if args.schedule == "serial" else "serial"
+        os.environ["CRT_HIP_OVERLAP"] = "1" if other_sched == "overlap" else "0"
+        r2 = RenderHIP(device=local_rank, flags=core.FLAG_TIMING, stream=stream.cuda_stream)
+        r2.initialize(width, height)
+        r2.set_prepared_scene(ps)
+        e2, rays2, _ = timed_frames(FrameLoop(r2, (eye, cdir, up, fovy), None, 0, 1), args, None, 0)
+        r2.close()
+        os.environ["CRT_HIP_OVERLAP"] = "1" if args.schedule == "overlap" else "0"
+        out["schedules"] = {args.schedule: {"ms_per_step": out["ms_per_step"], "value": out["value"]},
+                            other_sched: {"ms_per_step": round(e2 / args.steps * 1e3, 4), "value": round(rays2 / e2 / 1e6, 2)},
+                            "note": "serial: the 17 launches of a frame one after the other (headline: per-kernel spans are execution "
+                                    "times); overlap: occlusion(b) next to closest-hit(b+1) on a second stream, the library's default"}
+
     # ---- N > 1: the weak-scaling figure next to the strong-scaling headline (or the other way round) ----
     if world > 1:
         other = "weak" if args.scaling == "strong" else "strong"
@@ -404,22 +451,43 @@ def main():
                                      "trace_closest": round(acc["closest_ms"] / args.steps, 4),
                                      "trace_shadow": round(acc["shadow_ms"] / args.steps, 4),
                                      "raygen+shade+accumulate": round(acc["shade_ms"] / args.steps, 4)}
-    # ---- CPU baseline: the oracle restatement on this box's host cores (reported, not a target) ----
+        per = lambda name: [round(x / args.steps, 4) for x in acc[name]]
+        out["kernel_ms_per_bounce"] = {"trace_closest": per("closest_ms_bounce"), "trace_shadow": per("shadow_ms_bounce"),
+                                       "shade": per("shade_ms_bounce"), "raygen": round(acc["raygen_ms"] / args.steps, 4),
+                                       "accumulate": round(acc["accumulate_ms"] / args.steps, 4),
+                                       "closest_rays": [int(x / args.steps) for x in acc["closest_rays_bounce"]],
+                                       "shadow_rays": [int(x / args.steps) for x in acc["shadow_rays_bounce"]]}
+    # ---- CPU baseline + parity, on the FIXED tile sample of this workload: the oracle restatement renders frame 0 of
+    # those tiles on this box's host cores (timed: the reported baseline, not a target), and the very same pixels of the
+    # frame the HIP path renders of the SAME workload as configured -- full resolution, spp, textures -- are compared
+    # with it under the image tolerance of tests/parity.py (render_embree.ispc:198-355 on BASELINE.json's config) ----
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from tests.oracle_lib import OracleRenderer
+        from tests.parity import compare_images
         cores = usable_cores()
+        tiles, ntiles = sample_tiles(width, height, spp)
         o = OracleRenderer(scene, width, height, cores)
-        ntiles = o.num_tiles()
-        probe = max(1, ntiles // 64)
-        stp = o.render(eye, cdir, up, fovy, True, 0, probe)  # calibrate on a few tiles
-        per_tile = stp.render_time_ms / probe
-        n_sample = int(max(probe, min(ntiles, args.cpu_seconds * 1e3 / max(per_tile, 1e-3))))
-        stc = o.render(eye, cdir, up, fovy, True, 0, n_sample)
+        stc = o.render_tiles(eye, cdir, up, fovy, True, tiles)
         out["cpu_baseline"] = {"value": round(stc.rays_per_second / 1e6, 3), "unit": "MRay/s", "cores": cores,
                                "kind": "port",
                                "sample": f"CPU restatement (scalar C++, own BVH2 -- NOT Embree/ISPC/TBB, which cannot be built here): "
-                                         f"frame 0 of the same workload, first {n_sample} of {ntiles} 64x64 tiles, "
-                                         f"{stc.rays} rays in {stc.render_time_ms / 1e3:.1f} s"}
+                                         f"frame 0 of the same workload, the fixed sample of {len(tiles)} of {ntiles} 64x64 tiles "
+                                         f"(every {tiles[1] - tiles[0] if len(tiles) > 1 else 1}th), {stc.rays} rays in {stc.render_time_ms / 1e3:.1f} s"}
+        st0 = r.render(eye, cdir, up, fovy, True, True)  # frame 0 again (camera_changed resets the accumulation)
+        mask = tile_pixel_mask(width, height, tiles)
+        g, c = r.accum()[mask][:, None, :], o.accum()[mask][:, None, :]
+        diverged, mean_rel = compare_images(g, c)
+        gc, cc = r.ray_counts()[mask].astype(np.int64), o.ray_counts()[mask].astype(np.int64)
+        g8 = r.img.view(np.uint8).reshape(height, width, 4)[mask].astype(np.int32)
+        c8 = o.framebuffer().view(np.uint8).reshape(height, width, 4)[mask].astype(np.int32)
+        out["parity"] = {"tiles": len(tiles), "pixels": int(mask.sum()), "diverged": round(diverged, 6), "mean_rel": float(f"{mean_rel:.3e}"),
+                         "ray_count_mismatch": round(float((gc != cc).mean()), 6),
+                         "rays_gpu": int(gc.sum()), "rays_cpu": int(cc.sum()),
+                         "rgba8_over_1lsb": round(float((np.abs(g8 - c8) > 1).any(axis=1).mean()), 6),
+                         "tolerance": "|gpu - cpu| <= 1e-4 + 1e-3 |cpu| per channel; diverged = fraction of sampled pixels outside it "
+                                      "(bar: <= 1e-3), mean_rel over the others (bar: <= 1e-4); ray counts differ only on diverged pixels",
+                         "ok": bool(diverged <= 1e-3 and mean_rel <= 1e-4)}
+        del st0
     r.close()
     ps.close()
     if dist:

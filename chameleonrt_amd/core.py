@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(_HERE, "libcrt_hip_core
 
 FLAG_COUNTERS = 1
 FLAG_TIMING = 2
+TRACE_PRODUCTION = 2  # crt_hip_trace_rays: run the kernels a frame launches (include/crt_hip.h)
 
 # every symbol include/crt_hip.h declares
 EXPORTS = [
@@ -38,10 +39,14 @@ class RenderStats(C.Structure):
     _fields_ = [("render_time_ms", C.c_float), ("rays_per_second", C.c_float), ("rays", C.c_uint64),
                 ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("closest_ms", C.c_float),
                 ("shadow_ms", C.c_float), ("shade_ms", C.c_float), ("closest_nodes", C.c_uint64),
-                ("closest_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64)]
+                ("closest_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64),
+                # ABI 2: per path-loop iteration (MAX_PATH_DEPTH = 5)
+                ("closest_rays_bounce", C.c_uint64 * 5), ("shadow_rays_bounce", C.c_uint64 * 5),
+                ("closest_ms_bounce", C.c_float * 5), ("shadow_ms_bounce", C.c_float * 5), ("shade_ms_bounce", C.c_float * 5),
+                ("raygen_ms", C.c_float), ("accumulate_ms", C.c_float)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class CoreError(RuntimeError):

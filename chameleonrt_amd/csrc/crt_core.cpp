@@ -120,9 +120,10 @@ struct crt_hip_ctx {
     std::vector<uint32_t> tile_ids; // tiles this rank renders
     uint32_t n_local_tiles = 0, n_tiles_padded = 0;
     DeviceBuffer d_tile_ids, d_accum, d_tile_fb[2], d_img, d_ray_counts;
-    // The compact RGBA8 tile buffer is double-buffered by frame parity: the gather of frame f (RCCL, on
-    // another stream) may still read its buffer while frame f+1 is traced and accumulated into the other.
-    int tile_fb_last = 0; // buffer the last rendered frame wrote
+    // The compact RGBA8 tile buffer is double-buffered: the gather of frame f (RCCL, on another stream) may still
+    // read its buffer while frame f+1 is traced and accumulated into the other. The buffers alternate with every
+    // rendered frame, independently of frame_id (which a moving camera resets every frame).
+    int tile_fb_last = 1; // buffer the last rendered frame wrote (the first frame writes buffer 0)
     std::vector<uint32_t> img;
     uint32_t frame_id = 0;
 
@@ -217,7 +218,7 @@ void setup_queues(crt_hip_ctx *c)
         throw std::runtime_error("samples_per_pixel too large: 64 pixels x spp paths must fit one pass of 2^27 paths");
     }
     c->capacity = cap;
-    const size_t n_fields = 2 * 11 + 9 + 12 + 18 + 4;
+    const size_t n_fields = 2 * 11 + 8 + 12 + 18 + 4; // PathQueue x 2, HitBuf records, ShadowQueueA, ShadowQueueB, radiance
     c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
     uint32_t *base = c->d_queue_mem.as<uint32_t>();
     size_t k = 0;
@@ -237,15 +238,9 @@ void setup_queues(crt_hip_ctx *c)
             c->q[qi].tp[a] = f32();
         }
     }
-    c->hits.t = f32();
-    c->hits.u = f32();
-    c->hits.v = f32();
-    c->hits.tri = i32();
-    c->hits.inst = i32();
-    for (int a = 0; a < 3; ++a) {
-        c->hits.ng[a] = f32();
-    }
-    c->hits.mat = u32();
+    c->hits.rec = reinterpret_cast<float4 *>(base + k * cap); // 8 dwords per ray (cap is a multiple of 64: 16-byte aligned)
+    k += 8;
+    c->hits.inst_debug = nullptr;
     for (int a = 0; a < 3; ++a) {
         c->sa.o[a] = f32();
     }
@@ -490,6 +485,139 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
 
 } // namespace
 
+
+namespace {
+
+// crt_hip_trace_rays(CRT_HIP_TRACE_PRODUCTION): explicit rays through the kernels a FRAME launches -- k_trace_closest /
+// k_trace_shadow without counters, with ClosestSource / ShadowSource -- fed and read back through the frame's own queue
+// records, so that the bit-exact traversal tests cover the production instantiations (register allocation, retire path)
+// and not only the instrumented diagnostic kernel.
+int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const float *dir, const float *tmin, const float *tmax,
+                          bool closest, float *out_t, float *out_u, float *out_v, int32_t *out_inst, int32_t *out_geom,
+                          int32_t *out_prim, crt_render_stats *stats)
+{
+    if (!org || !dir || !tmin || !tmax || !out_t || n == 0 || n > (1ull << PATH_ID_BITS) ||
+        (closest && (!out_u || !out_v || !out_inst || !out_geom || !out_prim))) {
+        return fail(ctx, CRT_HIP_EINVAL, "trace_rays: bad arguments");
+    }
+    if (!(tmin[0] == 0.f || tmin[0] == RAY_EPS)) {
+        return fail(ctx, CRT_HIP_EINVAL, "trace_rays (production kernels): tmin must be 0 or EPSILON, as inside a frame");
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        if (tmin[i] != tmin[0] || (closest && tmax[i] != RAY_TFAR)) {
+            return fail(ctx, CRT_HIP_EINVAL, "trace_rays (production kernels): one tmin per batch, and tmax = 1e20 for closest hits");
+        }
+    }
+    if (!closest && tmin[0] != RAY_EPS) {
+        return fail(ctx, CRT_HIP_EINVAL, "trace_rays (production kernels): occlusion rays start at EPSILON");
+    }
+    const int bounce = tmin[0] == 0.f ? 0 : 1; // k_trace_closest: tnear = bounce == 0 ? 0 : EPSILON
+    hipStream_t s = ctx->stream;
+    LaunchCfg cfg = ctx->cfg();
+    cfg.counters = false;
+    // SoA ray fields, filled on the host
+    std::vector<float> soa(7 * n);
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            soa[(size_t)a * n + i] = org[3 * i + a];
+            soa[(size_t)(3 + a) * n + i] = dir[3 * i + a];
+        }
+        soa[6 * n + i] = tmax[i];
+    }
+    DeviceBuffer d_rays, d_pc, d_out, d_aux;
+    d_rays.alloc(7 * n * sizeof(float));
+    d_pc.alloc(sizeof(PassCounters));
+    HIP_CHECK(hipMemcpyAsync(d_rays.ptr, soa.data(), 7 * n * sizeof(float), hipMemcpyHostToDevice, s));
+    PassCounters pc;
+    std::memset(&pc, 0, sizeof(pc));
+    hipEvent_t e0 = get_event(ctx, 0), e1 = get_event(ctx, 1);
+    float *base = d_rays.as<float>();
+    if (closest) {
+        pc.n_queue[bounce] = (uint32_t)n;
+        HIP_CHECK(hipMemcpyAsync(d_pc.ptr, &pc, sizeof(pc), hipMemcpyHostToDevice, s));
+        PathQueue q{};
+        for (int a = 0; a < 3; ++a) {
+            q.o[a] = base + (size_t)a * n;
+            q.d[a] = base + (size_t)(3 + a) * n;
+        }
+        d_out.alloc(2 * n * sizeof(float4));
+        d_aux.alloc(n * sizeof(int32_t));
+        HIP_CHECK(hipMemsetAsync(d_out.ptr, 0xff, d_out.bytes, s));
+        HitBuf hb{d_out.as<float4>(), d_aux.as<int32_t>()};
+        HIP_CHECK(hipEventRecord(e0, s));
+        launch_trace_closest(cfg, ctx->sv, q, hb, d_pc.as<PassCounters>(), bounce);
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipGetLastError());
+        std::vector<float4> rec(2 * n);
+        std::vector<TriRec> tris(ctx->n_tris);
+        HIP_CHECK(hipMemcpyAsync(rec.data(), d_out.ptr, 2 * n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(out_inst, d_aux.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(tris.data(), ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (uint64_t i = 0; i < n; ++i) {
+            int32_t tri;
+            std::memcpy(&tri, &rec[2 * i].w, 4);
+            out_t[i] = rec[2 * i].x;
+            out_u[i] = rec[2 * i].y;
+            out_v[i] = rec[2 * i].z;
+            out_geom[i] = tri < 0 ? -1 : (int32_t)tris[(size_t)tri].geom;
+            out_prim[i] = tri < 0 ? -1 : (int32_t)tris[(size_t)tri].prim;
+        }
+    } else {
+        pc.n_shadow_a[bounce] = (uint32_t)n;
+        HIP_CHECK(hipMemcpyAsync(d_pc.ptr, &pc, sizeof(pc), hipMemcpyHostToDevice, s));
+        // one ShadowQueueA item per ray, contribution (1, 0, 0), no second ray: a visible ray leaves radiance.x = 1
+        std::vector<float> extra(5 * n);
+        for (uint64_t i = 0; i < n; ++i) {
+            extra[i] = 1.f;
+            extra[n + i] = 0.f;
+            extra[2 * n + i] = 0.f;
+            uint32_t path = (uint32_t)i;
+            int32_t bslot = -1;
+            std::memcpy(&extra[3 * n + i], &path, 4);
+            std::memcpy(&extra[4 * n + i], &bslot, 4);
+        }
+        d_aux.alloc(5 * n * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(d_aux.ptr, extra.data(), 5 * n * sizeof(float), hipMemcpyHostToDevice, s));
+        float *x = d_aux.as<float>();
+        ShadowQueueA sa{};
+        for (int a = 0; a < 3; ++a) {
+            sa.o[a] = base + (size_t)a * n;
+            sa.d[a] = base + (size_t)(3 + a) * n;
+            sa.c[a] = x + (size_t)a * n;
+        }
+        sa.tmax = base + 6 * n;
+        sa.path = reinterpret_cast<uint32_t *>(x + 3 * n);
+        sa.bslot = reinterpret_cast<int32_t *>(x + 4 * n);
+        ShadowQueueB sb{};
+        d_out.alloc(n * sizeof(float4));
+        HIP_CHECK(hipMemsetAsync(d_out.ptr, 0, d_out.bytes, s));
+        HIP_CHECK(hipEventRecord(e0, s));
+        launch_trace_shadow(cfg, ctx->sv, sa, sb, d_out.as<float4>(), d_pc.as<PassCounters>(), bounce);
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipGetLastError());
+        std::vector<float4> rad(n);
+        HIP_CHECK(hipMemcpyAsync(rad.data(), d_out.ptr, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (uint64_t i = 0; i < n; ++i) {
+            out_t[i] = rad[i].x; // 1 = the segment is unoccluded
+        }
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        stats->rays = n;
+        stats->render_time_ms = ms;
+        stats->rays_per_second = (float)(n / (ms * 1e-3));
+        (closest ? stats->closest_rays : stats->shadow_rays) = n;
+        (closest ? stats->closest_ms : stats->shadow_ms) = ms;
+    }
+    return CRT_HIP_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *ps)
@@ -573,18 +701,19 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         size_t ev = 0;
         struct Span {
             size_t a, b;
-            int kind;
+            int kind;   // 0 closest-hit traversal, 1 any-hit traversal, 2 raygen / shade / accumulate
+            int bounce; // path-loop iteration of the launch; -1 raygen, -2 accumulate
         };
         std::vector<Span> spans;
         // event pairs around each launch, recorded on the stream the launch goes to: with the overlapped
         // schedule the occlusion launches' spans live on the auxiliary stream and run concurrently with the
         // closest-hit spans of the next bounce (so the per-kind sums may add up to more than the frame time)
-        auto mark = [&](int kind, hipStream_t on) {
+        auto mark = [&](int kind, hipStream_t on, int bounce) {
             if (timing) {
                 hipEvent_t e0 = get_event(ctx, ev), e1 = get_event(ctx, ev + 1);
                 (void)e1;
                 HIP_CHECK(hipEventRecord(e0, on));
-                spans.push_back(Span{ev, ev + 1, kind});
+                spans.push_back(Span{ev, ev + 1, kind, bounce});
                 ev += 2;
             }
         };
@@ -601,6 +730,9 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         if (overlap) {
             aux_sv.stack_spill += (size_t)aux_sv.spill_stride * aux_sv.spill_depth;
         }
+        // The compact tile buffer alternates with every RENDERED frame, whatever frame_id does (a moving camera resets
+        // frame_id to 0 every frame): the asynchronous gather of the previous frame may still be reading the other one.
+        const int tile_buf = ctx->tile_fb_last ^ 1;
         const auto t0 = std::chrono::high_resolution_clock::now();
         uint32_t pass = 0;
         for (uint64_t slot0 = 0; slot0 < total_slots; slot0 += slots_per_pass, ++pass) {
@@ -611,16 +743,16 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             if (cfg.counters) { // atomicMin targets start at all-ones
                 HIP_CHECK(hipMemsetAsync(d_pc->t_start, 0xff, 2 * MAX_PATH_DEPTH * sizeof(unsigned long long), ctx->stream));
             }
-            mark(2, ctx->stream);
+            mark(2, ctx->stream, -1);
             launch_raygen(cfg, vp, d_tiles, (uint32_t)slot0, n_paths, ctx->q[0], ctx->radiance, d_pc);
             mark_end(ctx->stream);
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 if (!overlap || b == 0) {
-                    mark(0, ctx->stream);
+                    mark(0, ctx->stream, b);
                     launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
                     mark_end(ctx->stream);
                 }
-                mark(2, ctx->stream);
+                mark(2, ctx->stream, b);
                 launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
                              ctx->radiance, d_pc, b);
                 mark_end(ctx->stream);
@@ -628,25 +760,25 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                     // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the main stream } -> shade(b+1)
                     HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
                     HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-                    mark(1, ctx->aux_stream);
+                    mark(1, ctx->aux_stream, b);
                     launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
                     mark_end(ctx->aux_stream);
                     HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
                     if (b + 1 < MAX_PATH_DEPTH) {
-                        mark(0, ctx->stream);
+                        mark(0, ctx->stream, b + 1);
                         launch_trace_closest(cfg, ctx->sv, ctx->q[(b + 1) & 1], ctx->hits, d_pc, b + 1);
                         mark_end(ctx->stream);
                     }
                     HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 } else {
-                    mark(1, ctx->stream);
+                    mark(1, ctx->stream, b);
                     launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
                     mark_end(ctx->stream);
                 }
             }
-            mark(2, ctx->stream);
+            mark(2, ctx->stream, -2);
             launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
-                              ctx->d_tile_fb[ctx->frame_id & 1u].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
+                              ctx->d_tile_fb[tile_buf].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
                               ctx->d_ray_counts.as<uint32_t>());
             mark_end(ctx->stream);
             HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost,
@@ -667,6 +799,8 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 st.closest_rays += pc.n_queue[b];
                 st.shadow_rays += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
+                st.closest_rays_bounce[b] += pc.n_queue[b];
+                st.shadow_rays_bounce[b] += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
             }
             st.closest_nodes += pc.nodes_closest;
             st.closest_tris += pc.tris_closest;
@@ -711,6 +845,11 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                 float ms = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&ms, ctx->events[sp.a], ctx->events[sp.b]));
                 (sp.kind == 0 ? st.closest_ms : (sp.kind == 1 ? st.shadow_ms : st.shade_ms)) += ms;
+                if (sp.bounce >= 0) {
+                    (sp.kind == 0 ? st.closest_ms_bounce : (sp.kind == 1 ? st.shadow_ms_bounce : st.shade_ms_bounce))[sp.bounce] += ms;
+                } else {
+                    (sp.bounce == -1 ? st.raygen_ms : st.accumulate_ms) += ms;
+                }
                 if (dbg) {
                     std::fprintf(stderr, "[crt_hip] frame %u span kind %d: %.3f ms\n", ctx->frame_id, sp.kind, ms);
                 }
@@ -719,7 +858,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         if (stats) {
             *stats = st;
         }
-        ctx->tile_fb_last = (int)(ctx->frame_id & 1u);
+        ctx->tile_fb_last = tile_buf;
         ++ctx->frame_id;
         return CRT_HIP_OK;
     });
@@ -840,12 +979,18 @@ int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered, int world, in
 }
 
 int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const float *dir, const float *tmin,
-                       const float *tmax, int closest, float *out_t, float *out_u, float *out_v, int32_t *out_inst,
+                       const float *tmax, int closest_and_flags, float *out_t, float *out_u, float *out_v, int32_t *out_inst,
                        int32_t *out_geom, int32_t *out_prim, crt_render_stats *stats)
 {
+    const int closest = closest_and_flags & 1;
+    const bool production = (closest_and_flags & CRT_HIP_TRACE_PRODUCTION) != 0;
     return guarded(ctx, [&]() -> int {
         if (!ctx->has_scene) {
             return fail(ctx, CRT_HIP_ESTATE, "trace_rays before set_scene");
+        }
+        if (production) {
+            return trace_rays_production(ctx, n, org, dir, tmin, tmax, closest != 0, out_t, out_u, out_v, out_inst, out_geom,
+                                         out_prim, stats);
         }
         if (!org || !dir || !tmin || !tmax || !out_t || n == 0 || n > 0x7fffffffull ||
             (closest && (!out_u || !out_v || !out_inst || !out_geom || !out_prim))) {

@@ -15,8 +15,8 @@
 // LDS and flushed with one atomic per 128-256 entries. Traversal kernels are persistent: a fixed
 // grid of waves pulls 128-ray chunks from the queue with an atomic cursor and refills lanes as
 // their rays finish, so long rays do not stall a whole block.
-// No MFMA anywhere: the path is divergent pointer chasing, bound by vector-ALU issue at half the
-// lanes, not a contraction.
+// No MFMA anywhere: the path is divergent pointer chasing, bound by the per-CU vector-memory front end (one
+// 128-byte L2 -> L1 line fill per lane and node visit), not a contraction.
 
 #include <hip/hip_runtime.h>
 
@@ -226,25 +226,40 @@ struct ClosestSource {
         d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
         tfar = RAY_TFAR;
     }
+    // One 32-byte record per ray (wavefront.h HitBuf), two 16-byte stores by the retiring lane. The surface normal of
+    // the reference -- normalize(hit.Ng), then normalize(transpose(world_to_object) * n), render_embree.ispc:269-270,
+    // 288-290 -- is evaluated HERE, where the triangle and the instance are at hand (and still in cache), with exactly
+    // the expressions k_shade used to run on the raw Ng: K3 then needs neither the instance id nor a matrix fetch, and
+    // the record is 8 dwords instead of 9 scattered ones.
     CRT_DEV bool retire(uint32_t i, uint32_t &, const RayHit &h, V3 &, V3 &, float &, uint32_t &) const
     {
-        hits.t[i] = h.t;
-        hits.u[i] = h.u;
-        hits.v[i] = h.v;
-        hits.tri[i] = h.tri;
-        hits.inst[i] = h.inst;
+        hits.rec[2 * (size_t)i] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
+        if (hits.inst_debug != nullptr) { // crt_hip_trace_rays(CRT_HIP_TRACE_PRODUCTION) only; NULL in a frame
+            hits.inst_debug[i] = h.tri >= 0 ? h.inst : -1;
+        }
         if (h.tri >= 0) {
-            // Embree's hit.Ng (render_embree.ispc:269) and the material the reference looks up as
-            // materials[instance->material_ids[geomID]] (ispc:292-293). Resolved here, where the
-            // triangle and instance are still in cache and 8 waves/SIMD hide the latency, because in
-            // K3 each of these dependent gathers would lengthen its load chain by a level.
+            // Embree's hit.Ng = cross(e2, e1) of the hit triangle, instance-local, unnormalised (ispc:269)
             const float4 *tr = reinterpret_cast<const float4 *>(tris + h.tri);
             const float4 ta = tr[0], tb = tr[1], tc = tr[2];
-            const V3 ng = cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)); // cross(e2, e1)
-            hits.ng[0][i] = ng.x;
-            hits.ng[1][i] = ng.y;
-            hits.ng[2][i] = ng.z;
-            hits.mat[i] = material_ids[instances[h.inst].mat_base + __float_as_uint(tc.y)];
+            V3 normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
+            const InstanceRec &in = instances[h.inst];
+            // normal = normalize(transpose(world_to_object) * normal), ispc:288-290. For the identity matrix the same
+            // expression is evaluated on literal 1s and 0s -- bit for bit what the loaded matrix gives, signed zeros
+            // and non-finite values included (no fast-math: x * 0 is not folded) -- which saves the three requests
+            // for the matrix on every hit of an OBJ scene and most hits of C4.
+            if (in.identity) {
+                normal = unit(v3(1.f * normal.x + 0.f * normal.y + 0.f * normal.z,
+                                 0.f * normal.x + 1.f * normal.y + 0.f * normal.z,
+                                 0.f * normal.x + 0.f * normal.y + 1.f * normal.z));
+            } else {
+                const float *m = in.w2o; // 3x4: column c, row r at m[c*3 + r]
+                normal = unit(v3(m[0] * normal.x + m[1] * normal.y + m[2] * normal.z,
+                                 m[3] * normal.x + m[4] * normal.y + m[5] * normal.z,
+                                 m[6] * normal.x + m[7] * normal.y + m[8] * normal.z));
+            }
+            // materials[instance->material_ids[geomID]] (ispc:292-293), MATERIAL_TEXTURED in bit 31
+            const uint32_t mat = material_ids[in.mat_base + __float_as_uint(tc.y)];
+            hits.rec[2 * (size_t)i + 1] = make_float4(normal.x, normal.y, normal.z, __uint_as_float(mat));
         }
         return false;
     }
@@ -450,7 +465,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             n_rays = (word >> PATH_ID_BITS) + 1u; // + the closest-hit ray (ispc:246-248)
             rng = qin.rng[i];
             tp_in = v3(qin.tp[0][i], qin.tp[1][i], qin.tp[2][i]);
-            const int32_t tri = hits.tri[i];
+            const float4 h0 = hits.rec[2 * (size_t)i]; // {t, u, v, tri}: the half every ray has
+            const int32_t tri = __float_as_int(h0.w);
             if (tri < 0) {
                 // ispc:258-262
                 float4 L = radiance[path];
@@ -462,14 +478,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 radiance[path] = L;
             } else {
                 is_hit = true;
-                const float t = hits.t[i], bu = hits.u[i], bv = hits.v[i];
-                const InstanceRec &in = sc.instances[hits.inst[i]];
-                const uint32_t mat_word = hits.mat[i];
+                const float t = h0.x, bu = h0.y, bv = h0.z;
+                const float4 h1 = hits.rec[2 * (size_t)i + 1]; // {normal, material}: K2 ran ispc:269-270, 288-293
+                const uint32_t mat_word = __float_as_uint(h1.w);
                 const uint32_t mat_id = mat_word & ~MATERIAL_TEXTURED;
                 w_o = -d;
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
-                // hit.Ng = cross(e2, e1), instance-local, unnormalised (written by K2)
-                normal = unit(v3(hits.ng[0][i], hits.ng[1][i], hits.ng[2][i]));
+                normal = v3(h1.x, h1.y, h1.z);
                 V2 uv = v2(0.f, 0.f);
                 if (mat_word & MATERIAL_TEXTURED) { // (a material without textures never looks at uv: no record fetched)
                     // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
@@ -478,20 +493,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                     const float4 *tu = reinterpret_cast<const float4 *>(sc.tri_uvs + TRI_UV_STRIDE * (size_t)tri);
                     const float4 ab = tu[0], cz = tu[1]; // two 16-byte requests (the record is padded to 32 bytes)
                     uv = (1.f - bu - bv) * v2(ab.x, ab.y) + bu * v2(ab.z, ab.w) + bv * v2(cz.x, cz.y);
-                }
-                // normal = normalize(transpose(world_to_object) * normal), ispc:288-290. For the identity matrix the
-                // same expression is evaluated on literal 1s and 0s -- bit for bit what the loaded matrix gives,
-                // signed zeros and non-finite values included (no fast-math: x * 0 is not folded) -- which saves the
-                // three requests for the matrix on every hit of an OBJ scene and most hits of C4.
-                if (in.identity) {
-                    normal = unit(v3(1.f * normal.x + 0.f * normal.y + 0.f * normal.z,
-                                     0.f * normal.x + 1.f * normal.y + 0.f * normal.z,
-                                     0.f * normal.x + 0.f * normal.y + 1.f * normal.z));
-                } else {
-                    const float *m = in.w2o; // 3x4: column c, row r at m[c*3 + r]
-                    normal = unit(v3(m[0] * normal.x + m[1] * normal.y + m[2] * normal.z,
-                                     m[3] * normal.x + m[4] * normal.y + m[5] * normal.z,
-                                     m[6] * normal.x + m[7] * normal.y + m[8] * normal.z));
                 }
                 unpack_material(sc, mat, sc.materials + 16 * (size_t)mat_id, uv);
                 if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299

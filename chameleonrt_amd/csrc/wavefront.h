@@ -6,7 +6,7 @@
 //
 //   PathQueue (x2, ping-pong)  closest-hit rays of one bounce: origin, direction, path id,
 //                              RNG state, throughput                       11 dwords / ray
-//   HitBuf                     t, u, v, triangle index, instance, Ng, material 9 dwords / ray
+//   HitBuf                     t, u, v, triangle index | shading normal, material: ONE 32-byte record / ray
 //   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray
 //   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare) 18 dwords / ray
 //   radiance                   float4 per path: rgb = radiance so far, w = rays traced
@@ -26,12 +26,17 @@ struct PathQueue {
     float *tp[3];   // path_throughput (render_embree.ispc:241)
 };
 
+// What K2 hands K3 about a ray: one 32-byte record, two 16-byte halves written by the lane that retires the ray
+// and read back coalesced (the nine per-field dword stores of the first version left K2 with 3.3x the HBM write traffic
+// of its payload: a wave retires rays in batches of scattered indices, so every field array had a half-written line
+// open per wave, evicted and re-written several times before it filled up):
+//   rec[2i]     = {t, u, v, bits(tri)}         tri = index into SceneView::tris, -1 on a miss (the only half a miss writes)
+//   rec[2i + 1] = {n.x, n.y, n.z, bits(mat)}   n = normalize(transpose(world_to_object) * normalize(hit.Ng)), i.e.
+//                 render_embree.ispc:269-270, 288-290 evaluated where the triangle and the instance are at hand;
+//                 mat = instance->material_ids[hit.geomID] (ispc:292-293) with MATERIAL_TEXTURED in bit 31
 struct HitBuf {
-    float *t, *u, *v;
-    int32_t *tri; // index into SceneView::tris, -1 on a miss
-    int32_t *inst;
-    float *ng[3];  // Embree's hit.Ng: cross(e2, e1) of the hit triangle (valid on a hit)
-    uint32_t *mat; // material id = instance->material_ids[hit.geomID] (valid on a hit)
+    float4 *rec;
+    int32_t *inst_debug; // NULL in a frame; crt_hip_trace_rays(CRT_HIP_TRACE_PRODUCTION) asks for the instance id here
 };
 
 // First NEE shadow ray of a hit (render_embree.ispc:131-153). c = throughput * contribution,

@@ -95,7 +95,9 @@ class RenderHIP:
             self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32))), "read_ray_counts")
         return out
 
-    def trace(self, org, dirs, tmin, tmax, closest=True):
+    def trace(self, org, dirs, tmin, tmax, closest=True, production=False):
+        """production: through the kernels a frame launches (k_trace_closest / k_trace_shadow, no counters) instead of
+        the instrumented diagnostic kernel; closest hits then need tmax = 1e20 and tmin = 0 or EPSILON."""
         org = np.ascontiguousarray(org, np.float32)
         dirs = np.ascontiguousarray(dirs, np.float32)
         n = org.shape[0]
@@ -106,8 +108,8 @@ class RenderHIP:
         st = core.RenderStats()
         ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))
         core.check(self._ctx, self._lib.crt_hip_trace_rays(
-            self._ctx, n, core.fptr(org), core.fptr(dirs), core.fptr(tmin), core.fptr(tmax), int(closest),
-            core.fptr(t), core.fptr(u), core.fptr(v), ip(inst), ip(geom), ip(prim), C.byref(st)), "trace_rays")
+            self._ctx, n, core.fptr(org), core.fptr(dirs), core.fptr(tmin), core.fptr(tmax),
+            int(closest) | (core.TRACE_PRODUCTION if production else 0), core.fptr(t), core.fptr(u), core.fptr(v), ip(inst), ip(geom), ip(prim), C.byref(st)), "trace_rays")
         return dict(t=t, u=u, v=v, inst=inst, geom=geom, prim=prim, stats=st)
 
     def kat(self, fn: int, rec_in, n_out: int) -> np.ndarray:

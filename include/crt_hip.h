@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define CRT_HIP_ABI_VERSION 1
+#define CRT_HIP_ABI_VERSION 2
+#define CRT_HIP_MAX_PATH_DEPTH 5 /* MAX_PATH_DEPTH, backends/embree/util.ih:10 */
 
 enum {
     CRT_HIP_OK = 0,
@@ -127,6 +128,13 @@ typedef struct crt_render_stats {
     float shade_ms;        /* raygen + shade + accumulate launches */
     /* only when CRT_HIP_FLAG_COUNTERS: nodes fetched / triangles tested by traversal */
     uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris;
+    /* (ABI 2) the same per path-loop iteration b = 0..4 (render_embree.ispc:243-336): rays entering the
+     * closest-hit / any-hit launch of that bounce, and -- with CRT_HIP_FLAG_TIMING -- the duration of its
+     * closest-hit, any-hit and shade launches, summed over the passes of the frame. */
+    uint64_t closest_rays_bounce[CRT_HIP_MAX_PATH_DEPTH], shadow_rays_bounce[CRT_HIP_MAX_PATH_DEPTH];
+    float closest_ms_bounce[CRT_HIP_MAX_PATH_DEPTH], shadow_ms_bounce[CRT_HIP_MAX_PATH_DEPTH],
+        shade_ms_bounce[CRT_HIP_MAX_PATH_DEPTH];
+    float raygen_ms, accumulate_ms;
 } crt_render_stats;
 
 typedef struct crt_hip_ctx crt_hip_ctx;
@@ -237,11 +245,18 @@ int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered_device_ptr, in
 
 /* ---- Diagnostic entry points used by the parity tests and the roofline bench ---- */
 
-/* Trace n arbitrary world-space rays through the scene with the production traversal
- * kernels. Host arrays; tmin must hold one value for the whole batch (inside a frame it is 0
- * for primary rays and EPSILON for all others, util.ih:8). closest: out_t/out_u/out_v/out_inst/out_geom/out_prim (inst = -1
- * on a miss). any-hit (closest == 0): out_t[i] = 1 if the segment (tmin, tmax] is
- * unoccluded else 0, other outputs may be NULL. */
+/* Trace n arbitrary world-space rays through the scene with the traversal kernels. Host arrays; tmin
+ * must hold one value for the whole batch (inside a frame it is 0 for primary rays and EPSILON for all
+ * others, util.ih:8). closest: out_t/out_u/out_v/out_inst/out_geom/out_prim (inst = -1 on a miss).
+ * any-hit (closest == 0): out_t[i] = 1 if the segment (tmin, tmax] is unoccluded else 0, other outputs
+ * may be NULL.
+ * `closest` bit 1 (CRT_HIP_TRACE_PRODUCTION) selects WHICH instantiation runs: clear = the instrumented
+ * diagnostic kernel (counts nodes / triangles into stats); set = the very kernels a frame launches
+ * (k_trace_closest / k_trace_shadow without counters, fed through a PathQueue / ShadowQueueA and read back
+ * from the HitBuf / radiance buffer like k_shade reads them), which requires tmin = 0 or EPSILON and, for
+ * closest hits, tmax = 1e20 (set_ray_hit, util.ih:118) for every ray; out_inst is then -1 for a hit (the
+ * frame's hit record does not carry it: K2 resolves normal and material itself) and stats carry no counters. */
+#define CRT_HIP_TRACE_PRODUCTION 2
 int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
                        const float *dir /* n*3 */, const float *tmin, const float *tmax,
                        int closest, float *out_t, float *out_u, float *out_v,

@@ -1547,9 +1547,9 @@ extern "C" void orc_renderer_destroy(orc_renderer *r) { delete r; }
 extern "C" int orc_num_tiles(const orc_renderer *r) { return r ? r->ntx * r->nty : 0; }
 extern "C" const uint32_t *orc_framebuffer(const orc_renderer *r) { return r->img.data(); }
 
-extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir_[3], const float up_[3],
-                          float fovy, int camera_changed, int tile_begin, int tile_end,
-                          orc_stats *stats)
+// tile_list == nullptr: the tiles [tile_begin, tile_end); else the n_list tiles it names
+static int render_impl(orc_renderer *r, const float pos[3], const float dir_[3], const float up_[3], float fovy,
+                       int camera_changed, int tile_begin, int tile_end, const int *tile_list, int n_list, orc_stats *stats)
 {
     if (!r) {
         return -1;
@@ -1573,6 +1573,15 @@ extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir_[
         tile_end = ntiles;
     }
     tile_begin = std::max(0, tile_begin);
+    if (tile_list != nullptr) {
+        for (int k = 0; k < n_list; ++k) {
+            if (tile_list[k] < 0 || tile_list[k] >= ntiles) {
+                return -1;
+            }
+        }
+        tile_begin = 0;
+        tile_end = n_list;
+    }
     std::atomic<int> next(tile_begin);
     std::atomic<uint64_t> total_rays(0), total_closest(0), total_nodes(0), total_tris(0);
     const auto t0 = std::chrono::high_resolution_clock::now();
@@ -1580,10 +1589,11 @@ extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir_[
         TraceCounters ctr;
         uint64_t rays = 0, closest = 0;
         for (;;) {
-            const int tile_id = next.fetch_add(1);
-            if (tile_id >= tile_end) {
+            const int item = next.fetch_add(1);
+            if (item >= tile_end) {
                 break;
             }
+            const int tile_id = tile_list != nullptr ? tile_list[item] : item;
             const int tx = (tile_id % r->ntx) * 64, ty = (tile_id / r->ntx) * 64;
             const int tw = std::min(tx + 64, r->w) - tx, th = std::min(ty + 64, r->h) - ty;
             float *data = r->tiles[tile_id].data();
@@ -1633,6 +1643,21 @@ extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir_[
     }
     ++r->frame_id;
     return 0;
+}
+
+extern "C" int orc_render(orc_renderer *r, const float pos[3], const float dir[3], const float up[3], float fovy,
+                          int camera_changed, int tile_begin, int tile_end, orc_stats *stats)
+{
+    return render_impl(r, pos, dir, up, fovy, camera_changed, tile_begin, tile_end, nullptr, 0, stats);
+}
+
+extern "C" int orc_render_tiles(orc_renderer *r, const float pos[3], const float dir[3], const float up[3], float fovy,
+                                int camera_changed, const int *tile_ids, int n_tiles, orc_stats *stats)
+{
+    if (tile_ids == nullptr || n_tiles <= 0) {
+        return -1;
+    }
+    return render_impl(r, pos, dir, up, fovy, camera_changed, 0, 0, tile_ids, n_tiles, stats);
 }
 
 extern "C" int orc_debug_pixel(orc_renderer *r, const float pos[3], const float dir_[3], const float up_[3],

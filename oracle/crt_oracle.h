@@ -57,6 +57,10 @@ void orc_renderer_destroy(orc_renderer *r);
 int orc_render(orc_renderer *r, const float pos[3], const float dir[3], const float up[3],
                float fovy_deg, int camera_changed, int tile_begin, int tile_end,
                orc_stats *stats);
+/* The same for an explicit LIST of tiles (a fixed sample spread over the image: bench.py's cpu_baseline and in-run
+ * parity check, the full-configuration tile parity tests). Tiles not named keep what they held. */
+int orc_render_tiles(orc_renderer *r, const float pos[3], const float dir[3], const float up[3],
+                     float fovy_deg, int camera_changed, const int *tile_ids, int n_tiles, orc_stats *stats);
 const uint32_t *orc_framebuffer(const orc_renderer *r);
 int orc_read_accum(const orc_renderer *r, float *rgb /* W*H*3 row-major */);
 /* Debug aid: re-trace one pixel of frame `frame_id` printing the per-bounce state to stderr. */

@@ -38,6 +38,7 @@ def lib():
         L.orc_renderer_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.orc_renderer_destroy.argtypes = [vp]
         L.orc_render.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(OrcStats)]
+        L.orc_render_tiles.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, i32p, C.c_int, C.POINTER(OrcStats)]
         L.orc_framebuffer.restype = u32p
         L.orc_framebuffer.argtypes = [vp]
         L.orc_read_accum.argtypes = [vp, fp]
@@ -145,6 +146,16 @@ class OracleRenderer:
         a = [np.ascontiguousarray(x, np.float32) for x in (pos, dir, up)]
         rc = lib().orc_render(self.r, _fp(a[0]), _fp(a[1]), _fp(a[2]), float(fovy), int(camera_changed),
                               tile_begin, tile_end, C.byref(st))
+        assert rc == 0
+        return st
+
+    def render_tiles(self, pos, dir, up, fovy, camera_changed, tile_ids):
+        """The frame restricted to the reference's 64x64 tiles named in tile_ids (row-major tile ids)."""
+        st = OrcStats()
+        a = [np.ascontiguousarray(x, np.float32) for x in (pos, dir, up)]
+        ids = np.ascontiguousarray(tile_ids, np.int32)
+        rc = lib().orc_render_tiles(self.r, _fp(a[0]), _fp(a[1]), _fp(a[2]), float(fovy), int(camera_changed),
+                                    ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.byref(st))
         assert rc == 0
         return st
 

@@ -30,7 +30,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.crt_hip_abi_version() == 1
+    assert lib.crt_hip_abi_version() == 2
 
 
 def test_header_is_plain_c():
@@ -39,6 +39,19 @@ def test_header_is_plain_c():
     p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         "-x", "c", "-"], input=src.encode(), capture_output=True)
     assert p.returncode == 0, p.stderr.decode()
+
+
+def test_render_stats_layout_matches_the_binding(tmp_path):
+    """crt_render_stats as a C compiler lays it out == the ctypes mirror (size and the offset of its last field)."""
+    import ctypes as C
+    from chameleonrt_amd import core
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "crt_hip.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(crt_render_stats), '
+           'offsetof(crt_render_stats, closest_ms_bounce), offsetof(crt_render_stats, accumulate_ms));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", str(exe)], input=src.encode(), check=True)
+    size, off_ms, off_last = (int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert size == C.sizeof(core.RenderStats)
+    assert off_ms == core.RenderStats.closest_ms_bounce.offset and off_last == core.RenderStats.accumulate_ms.offset
 
 
 def test_product_never_links_the_oracle(lib):

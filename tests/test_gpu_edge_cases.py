@@ -125,3 +125,30 @@ def test_device_framebuffer_is_the_image_without_a_host_round_trip(hip_lib):
     r.render(e, d, u, fovy, True, True)  # the same frame again, read back the reference's way
     assert np.array_equal(dev, r.img) and (dev.view(np.uint8).reshape(136, 200, 4)[..., 3] == 255).all()
     r.close()
+
+
+def test_tile_buffer_alternates_with_a_moving_camera(hip_lib):
+    """The compact tile buffer a multi-GPU gather reads alternates with every RENDERED frame -- also when every frame
+    has camera_changed set (frame_id is then 0 each time): the asynchronous gather of frame f may still be reading its
+    buffer while frame f+1 is accumulated, so two consecutive frames must never share one (round-2 advisor finding)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # resolves to the runtime the core already uses
+    sc = scenes.cornell(spp=1)
+    e, d, u, fovy = camera_of(sc)
+    r = RenderHIP(rank=0, world=2)
+    r.initialize(128, 128)
+    r.set_scene(sc)
+    ptrs, images = [], []
+    for f in range(4):
+        e2 = e + np.float32(0.05 * f) * np.array([1, 0, 0], np.float32)
+        r.render(e2, d, u, fovy, True, False)
+        assert r.frame_id() == 1
+        p, n = r.tile_buffer()
+        ptrs.append(p)
+        buf = np.zeros(n // 4, np.uint32)
+        assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(p), C.c_size_t(n), 2) == 0  # device -> host
+        images.append(buf)
+    assert ptrs[0] != ptrs[1] and ptrs[0] == ptrs[2] and ptrs[1] == ptrs[3]
+    # and each buffer holds the frame that was rendered into it last (the four cameras give four different images)
+    assert not np.array_equal(images[0], images[1]) and not np.array_equal(images[1], images[2])
+    r.close()

@@ -135,6 +135,7 @@ def test_full_tree_rays(full, oracle):
     assert hit.mean() > 0.3
     assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (w["nodes"], w["tris"])
     deepest = w["max_stack"]
+    g0u = g["u"]
     # incoherent secondary rays leaving the surfaces (tnear = EPSILON): the expensive kind
     p = org[hit] + c["t"][hit, None] * dirs[hit]
     d2 = np.random.default_rng(32).normal(size=p.shape).astype(np.float32)
@@ -144,6 +145,7 @@ def test_full_tree_rays(full, oracle):
     c = o.trace(p, d2, 1e-4, 1e20, closest=True, brute_force=False)
     _same_hits(g, w)
     _same_hits(g, c)
+    c2 = c
     assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (w["nodes"], w["tris"])
     deepest = max(deepest, w["max_stack"])
     # occlusion rays over finite segments
@@ -154,6 +156,12 @@ def test_full_tree_rays(full, oracle):
     assert np.array_equal(g["t"], w["t"]) and np.array_equal(g["t"], c["t"])
     assert (g["stats"].shadow_nodes, g["stats"].shadow_tris) == (w["nodes"], w["tris"])
     deepest = max(deepest, w["max_stack"])
+    # the same three ray sets through the PRODUCTION instantiations (the kernels a frame launches, no counters)
+    gp = r.trace(org, dirs, 0.0, 1e20, closest=True, production=True)
+    hit0 = _same_hits(gp, o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=False))
+    assert np.array_equal(gp["u"][hit0].view(np.uint32), g0u[hit0].view(np.uint32))
+    _same_hits(r.trace(p, d2, 1e-4, 1e20, closest=True, production=True), c2)
+    assert np.array_equal(r.trace(p, d2, 1e-4, tmax, closest=False, production=True)["t"], c["t"])
     assert deepest <= bvh["stack_need"]
     print(f"\n{sc.name}: deepest traversal stack {deepest}, {bvh['lds_stack']} entries in LDS, {bvh['stack_need']} provided for")
     if bvh["two_level"]:

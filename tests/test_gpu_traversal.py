@@ -64,6 +64,35 @@ def test_closest_hit_matches_brute_force(pair):
         assert np.array_equal(g[k][hit].view(np.uint32), c[k][hit].view(np.uint32)), k
 
 
+def _same_as(g, c, with_uv=True):
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(g[k], c[k]), k
+    hit = c["inst"] >= 0
+    for k in ("t", "u", "v") if with_uv else ("t",):
+        assert np.array_equal(g[k][hit].view(np.uint32), c[k][hit].view(np.uint32)), k
+    return hit
+
+
+def test_production_kernels_match_brute_force(pair):
+    """The kernels a FRAME launches -- k_trace_closest / k_trace_shadow without counters, with ClosestSource /
+    ShadowSource, fed through the frame's queue records and read back from its hit records / radiance buffer
+    (crt_hip_trace_rays with CRT_HIP_TRACE_PRODUCTION) -- give the brute-force answer bit for bit, like the
+    instrumented diagnostic instantiation the other tests of this file run: primary rays (tnear = 0), secondary
+    rays leaving surfaces (tnear = EPSILON), occlusion over finite segments."""
+    r, o, sc = pair
+    org, dirs = probe_rays(sc, 30000, seed=1)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    hit = _same_as(r.trace(org, dirs, 0.0, 1e20, closest=True, production=True), c)
+    assert hit.sum() > 100
+    p = org[hit] + c["t"][hit, None] * dirs[hit]
+    d2 = np.random.default_rng(17).normal(size=p.shape).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    _same_as(r.trace(p, d2, 1e-4, 1e20, closest=True, production=True), o.trace(p, d2, 1e-4, 1e20, closest=True, brute_force=True))
+    tmax = np.random.default_rng(18).random(len(p)).astype(np.float32) * 10
+    g = r.trace(p, d2, 1e-4, tmax, closest=False, production=True)
+    assert np.array_equal(g["t"], o.trace(p, d2, 1e-4, tmax, closest=False, brute_force=True)["t"])
+
+
 def test_tnear_epsilon_and_finite_tfar(pair):
     r, o, sc = pair
     org, dirs = probe_rays(sc, 20000, seed=2)
