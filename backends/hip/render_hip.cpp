@@ -83,6 +83,11 @@ RenderHIP::RenderHIP()
     if (n > 1) {
         multi = std::make_unique<MultiGpu>(n);
     }
+    // a plugin compiled against another version of the boundary (crt_render_stats grew with ABI 2) must not run
+    if (crt_hip_abi_version() != CRT_HIP_ABI_VERSION) {
+        throw std::runtime_error("RenderHIP: libcrt_hip_core.so speaks ABI " + std::to_string(crt_hip_abi_version()) +
+                                 ", this plugin was built for ABI " + std::to_string(CRT_HIP_ABI_VERSION));
+    }
     for (int d = 0; d < n; ++d) {
         crt_hip_ctx *c = crt_hip_create(d, CRT_HIP_FLAG_NONE);
         if (!c) {
