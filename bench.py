@@ -31,8 +31,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_GHZ, N_CUS, SIMDS = 2.4, 256, 4  # MI355X_MICROARCH.md chip-level parameters
-NODE_BYTES, TRI_BYTES = 64, 48  # quantised BVH4 node / triangle record
-QUEUE_BYTES_CLOSEST = 24 + 36   # o,d read + t,u,v,tri,inst,Ng,material written per ray
+NODE_BYTES, SLOT_BYTES = 64, 64  # quantised BVH4 node / leaf slot of one or two triangles
+QUEUE_BYTES_CLOSEST = 24 + 32   # o,d read + the 32-byte hit record {t,u,v,tri | normal,material} written per ray
 QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
 MAX_PATH_DEPTH = 5
 
@@ -338,15 +338,19 @@ def main():
         ri = RenderHIP(device=local_rank, flags=core.FLAG_COUNTERS, rank=rank, world=world, stream=stream.cuda_stream)
         ri.initialize(width, height)
         ri.set_prepared_scene(ps)
-        cn = ct = sn = stt = cr = sr = 0
+        cn = ct = sn = stt = cr = sr = csl = ssl = 0
         n_probe = min(3, args.warmup + args.steps)
         for f in range(n_probe):  # same frames -> same rays as the timed run (deterministic)
             s2 = ri.render(eye, cdir, up, fovy, f == 0, False)
             cn, ct, sn, stt = cn + s2.closest_nodes, ct + s2.closest_tris, sn + s2.shadow_nodes, stt + s2.shadow_tris
             cr, sr = cr + s2.closest_rays, sr + s2.shadow_rays
+            csl, ssl = csl + s2.closest_slots, ssl + s2.shadow_slots
         ri.close()
-        bytes_closest = QUEUE_BYTES_CLOSEST + NODE_BYTES * cn / cr + TRI_BYTES * ct / cr
-        bytes_shadow = QUEUE_BYTES_SHADOW + NODE_BYTES * sn / max(1, sr) + TRI_BYTES * stt / max(1, sr)
+        bytes_closest = QUEUE_BYTES_CLOSEST + NODE_BYTES * cn / cr + SLOT_BYTES * csl / cr
+        bytes_shadow = QUEUE_BYTES_SHADOW + NODE_BYTES * sn / max(1, sr) + SLOT_BYTES * ssl / max(1, sr)
+        visits = {"closest": {"nodes_per_ray": round(cn / cr, 2), "leaf_slots_per_ray": round(csl / cr, 2), "triangles_per_ray": round(ct / cr, 2)},
+                  "shadow": {"nodes_per_ray": round(sn / max(1, sr), 2), "leaf_slots_per_ray": round(ssl / max(1, sr), 2),
+                             "triangles_per_ray": round(stt / max(1, sr), 2)}}
         launches = MAX_PATH_DEPTH * args.steps
         # (2) hardware counters of the same frames, measured now (separate rocprofv3 passes of a child process)
         pmc = {}
@@ -447,6 +451,7 @@ def main():
         # (overlapped schedule: the occlusion launch of bounce b runs next to the closest-hit launch of bounce b+1 on a
         # second stream; its event span then includes the time its blocks wait for CUs, so trace_shadow is an upper
         # bound and the sum over the kinds exceeds ms_per_step)
+        out["visits_per_ray"] = visits  # counted by the instrumented kernels (== the oracle's walk of the same arrays, tests/)
         out["kernel_ms_per_step"] = {"schedule": args.schedule,
                                      "trace_closest": round(acc["closest_ms"] / args.steps, 4),
                                      "trace_shadow": round(acc["shadow_ms"] / args.steps, 4),

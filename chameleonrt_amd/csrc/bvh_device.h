@@ -10,11 +10,11 @@
 namespace crt {
 
 // One mesh's BLAS as the device built it, copied back to the host: quantised 4-wide nodes in BFS
-// order (inner references are indices into `nodes`, leaf references index `tris`), the triangle
-// records and their vertex UVs (6 floats each) in leaf order.
+// order (inner references are indices into `nodes`, leaf references index `slots`), the leaf slots and
+// their triangles' vertex UVs (TRI_UV_STRIDE floats per triangle index 2 * slot + which) in leaf order.
 struct DeviceBuiltMesh {
     std::vector<QNode> nodes;
-    std::vector<TriRec> tris;
+    std::vector<LeafSlot> slots;
     std::vector<float> tri_uvs;
     Aabb bounds;
     QFrame frame;
@@ -22,11 +22,13 @@ struct DeviceBuiltMesh {
     uint32_t n_top = 0;
 };
 
-// Builds the BLAS of the mesh made of geoms[0 .. n_geoms) on HIP device `device`. Returns false (and
-// leaves `out` alone) for meshes too small to be worth it -- the caller then uses the host builder.
-// Throws std::runtime_error on HIP errors.
-bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, uint32_t max_leaf, uint32_t max_top_nodes,
-                       DeviceBuiltMesh &out);
+// Builds the BLAS of the mesh made of geoms[0 .. n_geoms) on HIP device `device`, over the leaf slots geom_slots[g] of
+// each geometry (leaf_slots.h: which triangles share a slot, decided on the host). Returns false (and leaves `out`
+// alone) for meshes too small to be worth it -- the caller then uses the host builder. Throws std::runtime_error on
+// HIP errors. The caller's current device is left as it was.
+struct SlotTris;
+bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
+                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out);
 
 // The same algorithm run serially on the host (shares lbvh.h with the kernels): what the CPU tests
 // check, and the reference the device result is compared against (CRT_BVH_BUILDER=lbvh).

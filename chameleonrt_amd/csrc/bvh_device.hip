@@ -2,17 +2,18 @@
 // rtcCommitScene in the reference, embree_utils.cpp:63-76).
 //
 // The host SAH builder (bvh_builder.cpp) takes seconds for a 10 M-triangle mesh; this path builds the same
-// kind of tree -- 4-wide, 64-byte quantised nodes, leaves of <= 2 triangles, triangles in leaf order -- on
+// kind of tree -- 4-wide, 64-byte quantised nodes, leaves of one 64-byte slot (one or two triangles), slots in leaf order -- on
 // the device in a fraction of that, at a lower tree quality (Morton-order splits instead of SAH; DESIGN.md
 // section 7 has the measured node-visit ratio). Opt-in: CRT_HIP_BUILD=device.
 //
-//   1. k_setup      triangle records (v0, e1, e2, geomID, primID), boxes, mesh bounds        (per triangle)
-//   2. k_keys       63-bit Morton code of the box centre in the mesh bounds                   (per triangle)
-//   3. rocPRIM      radix sort of (key, triangle)                                             (library sort)
+//   0. (host)       which triangles share a leaf slot (leaf_slots.h: edge neighbours, paired once per geometry)
+//   1. k_setup      leaf slots (four vertices, geomID, primIDs), boxes, mesh bounds            (per slot)
+//   2. k_keys       63-bit Morton code of the box centre in the mesh bounds                   (per slot)
+//   3. rocPRIM      radix sort of (key, slot)                                                 (library sort)
 //   4. k_karras     binary radix tree over the sorted keys (Karras 2012; lbvh.h)             (per internal node)
 //   5. k_refit      boxes bottom-up, second arriver at a node continues                      (per leaf)
 //   6. k_collapse   level by level: binary subtree -> wide node, children allocated in the next level (BFS order)
-//   7. k_emit       triangles and their vertex UVs in leaf (= sorted) order
+//   7. k_emit       slots and their triangles' vertex UVs in leaf (= sorted) order
 //
 // The result is copied back into the host-side prepared scene, so everything after the build (TLAS,
 // instance records, sharing between the GPUs of a node) is the one code path of scene_prepare.cpp.
@@ -29,6 +30,7 @@
 
 #include "bvh_device.h"
 #include "lbvh.h"
+#include "leaf_slots.h"
 
 namespace crt {
 namespace {
@@ -74,8 +76,13 @@ inline float ord2f(uint32_t o)
     return f;
 }
 
-__global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms, uint32_t n_geoms, const float *verts,
-                                               const uint32_t *indices, TriRec *recs, Aabb *boxes, uint32_t *bounds)
+// One entry per leaf slot of the mesh, from the host's pairing: the geometry and the one or two primitives it holds.
+struct SlotDev {
+    uint32_t geom, a, b, pad; // b == SLOT_NO_SECOND: single
+};
+
+__global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms, const SlotDev *table, const float *verts,
+                                               const uint32_t *indices, LeafSlot *recs, Aabb *boxes, uint32_t *bounds)
 {
     __shared__ uint32_t s_b[6];
     if (threadIdx.x < 6) {
@@ -84,33 +91,49 @@ __global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms,
     __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
-        uint32_t g_lo = 0, g_hi = n_geoms - 1; // last geometry whose tri_begin <= t
-        while (g_lo < g_hi) {
-            const uint32_t mid = (g_lo + g_hi + 1) / 2;
-            if (geoms[mid].tri_begin <= t) {
-                g_lo = mid;
-            } else {
-                g_hi = mid - 1;
-            }
-        }
-        const GeomDev g = geoms[g_lo];
-        const uint32_t prim = t - g.tri_begin;
-        const uint32_t *ix = indices + 3 * (size_t)t;
-        const float *v0 = verts + 3 * (size_t)(g.vert_begin + ix[0]);
-        const float *v1 = verts + 3 * (size_t)(g.vert_begin + ix[1]);
-        const float *v2 = verts + 3 * (size_t)(g.vert_begin + ix[2]);
-        TriRec r;
+        const SlotDev sd = table[t];
+        const GeomDev g = geoms[sd.geom];
+        // the expressions of make_leaf_slot / slot_box (leaf_slots.h, scene_prepare.cpp): same record, same box
+        const uint32_t *ia = indices + 3 * (size_t)(g.tri_begin + sd.a);
+        const float *va[3] = {verts + 3 * (size_t)(g.vert_begin + ia[0]), verts + 3 * (size_t)(g.vert_begin + ia[1]),
+                              verts + 3 * (size_t)(g.vert_begin + ia[2])};
+        LeafSlot r;
         Aabb b;
         for (int a = 0; a < 3; ++a) {
-            r.v0[a] = v0[a];
-            r.e1[a] = v0[a] - v1[a];
-            r.e2[a] = v2[a] - v0[a];
-            b.lo[a] = fminf(v0[a], fminf(v1[a], v2[a]));
-            b.hi[a] = fmaxf(v0[a], fmaxf(v1[a], v2[a]));
+            r.v[0][a] = va[0][a];
+            r.v[1][a] = va[1][a];
+            r.v[2][a] = va[2][a];
+            r.v[3][a] = va[0][a];
+            b.lo[a] = fminf(va[0][a], fminf(va[1][a], va[2][a]));
+            b.hi[a] = fmaxf(va[0][a], fmaxf(va[1][a], va[2][a]));
         }
-        r.geom = g_lo;
-        r.prim = prim;
-        r.pad = 0;
+        uint32_t sel = 0;
+        if (sd.b != SLOT_NO_SECOND) {
+            const uint32_t *ib = indices + 3 * (size_t)(g.tri_begin + sd.b);
+            for (int k = 0; k < 3; ++k) {
+                uint32_t where = 3;
+                for (uint32_t j = 0; j < 3; ++j) {
+                    if (where == 3 && ib[k] == ia[j]) {
+                        where = j;
+                    }
+                }
+                const float *p = verts + 3 * (size_t)(g.vert_begin + ib[k]);
+                if (where == 3) {
+                    r.v[3][0] = p[0];
+                    r.v[3][1] = p[1];
+                    r.v[3][2] = p[2];
+                }
+                for (int a = 0; a < 3; ++a) {
+                    b.lo[a] = fminf(b.lo[a], p[a]);
+                    b.hi[a] = fmaxf(b.hi[a], p[a]);
+                }
+                sel |= where << (2 * k);
+            }
+        }
+        r.geom_sel = sd.geom | (sel << SLOT_GEOM_BITS);
+        r.prim0 = sd.a;
+        r.prim1 = sd.b;
+        r.tag = 0;
         recs[t] = r;
         boxes[t] = b;
         for (int a = 0; a < 3; ++a) {
@@ -251,27 +274,29 @@ __global__ __launch_bounds__(256) void k_collapse(LbvhTree t, const int32_t *fro
     nodes[level_base + i] = node;
 }
 
-__global__ __launch_bounds__(256) void k_emit(uint32_t n, const TriRec *recs, const uint32_t *idx, const GeomDev *geoms,
-                                              const uint32_t *indices, const float *uvs, TriRec *tris, float *tri_uvs)
+__global__ __launch_bounds__(256) void k_emit(uint32_t n, const LeafSlot *recs, const uint32_t *idx, const GeomDev *geoms,
+                                              const uint32_t *indices, const float *uvs, LeafSlot *slots, float *tri_uvs)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) {
         return;
     }
-    const uint32_t t = idx[p];
-    const TriRec r = recs[t];
-    tris[p] = r;
-    const GeomDev g = geoms[r.geom];
-    float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (g.uv_begin >= 0) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t vi = indices[3 * (size_t)t + c];
-            out[2 * c] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi)];
-            out[2 * c + 1] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi) + 1];
+    const LeafSlot r = recs[idx[p]];
+    slots[p] = r;
+    const GeomDev g = geoms[r.geom_sel & SLOT_GEOM_MASK];
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t prim = which == 0 ? r.prim0 : r.prim1;
+        float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g.uv_begin >= 0 && prim != SLOT_NO_SECOND) { // uv_buf[indices.x|y|z], render_embree.ispc:278-283
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t vi = indices[3 * (size_t)(g.tri_begin + prim) + c];
+                out[2 * c] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi)];
+                out[2 * c + 1] = uvs[2 * (size_t)((uint32_t)g.uv_begin + vi) + 1];
+            }
         }
-    }
-    for (int c = 0; c < TRI_UV_STRIDE; ++c) {
-        tri_uvs[(size_t)TRI_UV_STRIDE * p + c] = c < 6 ? out[c] : 0.f;
+        for (int c = 0; c < TRI_UV_STRIDE; ++c) {
+            tri_uvs[(size_t)TRI_UV_STRIDE * (2 * (size_t)p + (size_t)which) + c] = c < 6 ? out[c] : 0.f;
+        }
     }
 }
 
@@ -279,21 +304,40 @@ inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 } // namespace
 
-bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, uint32_t max_leaf, uint32_t max_top_nodes,
-                       DeviceBuiltMesh &out)
+bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
+                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
 {
-    uint64_t n_tris = 0, n_verts = 0, n_uvs = 0;
+    uint64_t n_tris = 0, n_verts = 0, n_uvs = 0, n_slots = 0;
     for (uint32_t g = 0; g < n_geoms; ++g) {
         n_tris += geoms[g].n_triangles;
         n_verts += geoms[g].n_vertices;
         n_uvs += geoms[g].uvs ? geoms[g].n_vertices : 0;
+        n_slots += geom_slots[g].size();
     }
-    if (n_tris < 4096 || n_tris >= (1ull << 28)) {
+    if (n_tris < 4096 || n_tris >= (1ull << 28) || n_verts >= (1ull << 32)) {
         return false; // small meshes: the host builder takes milliseconds and builds the better tree
     }
+    // the caller's current device is restored on every way out (a thread that drives another GPU, e.g. the GL
+    // interop path, must not find its device changed), and the build runs on a stream of its own: the legacy default
+    // stream would synchronise with every blocking stream of the device
+    struct DeviceGuard {
+        int prev = -1;
+        hipStream_t stream = nullptr;
+        ~DeviceGuard()
+        {
+            if (stream) {
+                (void)hipStreamDestroy(stream);
+            }
+            if (prev >= 0) {
+                (void)hipSetDevice(prev);
+            }
+        }
+    } guard;
+    BD_CHECK(hipGetDevice(&guard.prev));
     BD_CHECK(hipSetDevice(device));
-    hipStream_t s = nullptr; // the legacy default stream: set_scene is not on the frame path
-    const uint32_t n = (uint32_t)n_tris;
+    BD_CHECK(hipStreamCreateWithFlags(&guard.stream, hipStreamNonBlocking));
+    hipStream_t s = guard.stream;
+    const uint32_t n = (uint32_t)n_slots; // the items of the tree: leaf slots
 
     // inputs, straight from the caller's arrays into concatenated device arrays
     Buf d_verts, d_indices, d_uvs, d_geoms;
@@ -327,19 +371,30 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     }
     d_geoms.alloc(n_geoms * sizeof(GeomDev));
     BD_CHECK(hipMemcpyAsync(d_geoms.p, gd.data(), n_geoms * sizeof(GeomDev), hipMemcpyHostToDevice, s));
+    std::vector<SlotDev> table;
+    table.reserve(n);
+    for (uint32_t g = 0; g < n_geoms; ++g) {
+        for (const SlotTris &st : geom_slots[g]) {
+            table.push_back(SlotDev{g, st.a, st.b, 0u});
+        }
+    }
+    Buf d_table;
+    d_table.alloc((size_t)n * sizeof(SlotDev));
+    BD_CHECK(hipMemcpyAsync(d_table.p, table.data(), (size_t)n * sizeof(SlotDev), hipMemcpyHostToDevice, s));
 
     Buf d_recs, d_boxes, d_bounds;
-    d_recs.alloc((size_t)n * sizeof(TriRec));
+    d_recs.alloc((size_t)n * sizeof(LeafSlot));
     d_boxes.alloc((size_t)n * sizeof(Aabb));
     d_bounds.alloc(6 * 4);
     {
         const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
         BD_CHECK(hipMemcpyAsync(d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
     }
-    k_setup<<<grid_for(n), 256, 0, s>>>(n, d_geoms.as<GeomDev>(), n_geoms, d_verts.as<float>(), d_indices.as<uint32_t>(),
-                                        d_recs.as<TriRec>(), d_boxes.as<Aabb>(), d_bounds.as<uint32_t>());
+    k_setup<<<grid_for(n), 256, 0, s>>>(n, d_geoms.as<GeomDev>(), d_table.as<SlotDev>(), d_verts.as<float>(), d_indices.as<uint32_t>(),
+                                        d_recs.as<LeafSlot>(), d_boxes.as<Aabb>(), d_bounds.as<uint32_t>());
     uint32_t hb[6];
-    BD_CHECK(hipMemcpy(hb, d_bounds.p, sizeof(hb), hipMemcpyDeviceToHost));
+    BD_CHECK(hipMemcpyAsync(hb, d_bounds.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+    BD_CHECK(hipStreamSynchronize(s));
     Aabb bounds;
     for (int a = 0; a < 3; ++a) {
         bounds.lo[a] = ord2f(hb[a]);
@@ -389,7 +444,8 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
                                             tb.pbox.as<Aabb>(), tb.ibox.as<Aabb>(), d_arrived.as<uint32_t>());
         k_cost<<<cost_blocks, 256, 0, s>>>(n - 1, tb.ibox.as<Aabb>(), d_partial.as<double>());
         std::vector<double> partial(cost_blocks);
-        BD_CHECK(hipMemcpy(partial.data(), d_partial.p, (size_t)cost_blocks * 8, hipMemcpyDeviceToHost));
+        BD_CHECK(hipMemcpyAsync(partial.data(), d_partial.p, (size_t)cost_blocks * 8, hipMemcpyDeviceToHost, s));
+        BD_CHECK(hipStreamSynchronize(s));
         cost[mode] = 0.0;
         for (double v : partial) {
             cost[mode] += v;
@@ -415,7 +471,8 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
         k_collapse<<<grid_for(n_in), 256, 0, s>>>(tree, fin, n_in, fout, d_count.as<uint32_t>(), level_base, d_nodes.as<QNode>(), frame,
                                                   max_leaf);
         uint32_t n_next = 0;
-        BD_CHECK(hipMemcpy(&n_next, d_count.p, 4, hipMemcpyDeviceToHost));
+        BD_CHECK(hipMemcpyAsync(&n_next, d_count.p, 4, hipMemcpyDeviceToHost, s));
+        BD_CHECK(hipStreamSynchronize(s));
         level_base += n_in;
         n_in = n_next;
         std::swap(fin, fout);
@@ -426,19 +483,20 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     }
     const uint32_t n_nodes = level_base;
 
-    // triangles + vertex UVs in leaf order
-    Buf d_tris, d_tuv;
-    d_tris.alloc((size_t)n * sizeof(TriRec));
-    d_tuv.alloc((size_t)n * TRI_UV_STRIDE * 4);
-    k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<TriRec>(), idx, d_geoms.as<GeomDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
-                                       d_tris.as<TriRec>(), d_tuv.as<float>());
+    // slots + their triangles' vertex UVs in leaf order
+    Buf d_slots, d_tuv;
+    d_slots.alloc((size_t)n * sizeof(LeafSlot));
+    d_tuv.alloc((size_t)n * 2 * TRI_UV_STRIDE * 4);
+    k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<LeafSlot>(), idx, d_geoms.as<GeomDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
+                                       d_slots.as<LeafSlot>(), d_tuv.as<float>());
     BD_CHECK(hipGetLastError());
     out.nodes.resize(n_nodes);
-    out.tris.resize(n);
-    out.tri_uvs.resize((size_t)n * TRI_UV_STRIDE);
-    BD_CHECK(hipMemcpy(out.nodes.data(), d_nodes.p, (size_t)n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
-    BD_CHECK(hipMemcpy(out.tris.data(), d_tris.p, (size_t)n * sizeof(TriRec), hipMemcpyDeviceToHost));
-    BD_CHECK(hipMemcpy(out.tri_uvs.data(), d_tuv.p, (size_t)n * TRI_UV_STRIDE * 4, hipMemcpyDeviceToHost));
+    out.slots.resize(n);
+    out.tri_uvs.resize((size_t)n * 2 * TRI_UV_STRIDE);
+    BD_CHECK(hipMemcpyAsync(out.nodes.data(), d_nodes.p, (size_t)n_nodes * sizeof(QNode), hipMemcpyDeviceToHost, s));
+    BD_CHECK(hipMemcpyAsync(out.slots.data(), d_slots.p, (size_t)n * sizeof(LeafSlot), hipMemcpyDeviceToHost, s));
+    BD_CHECK(hipMemcpyAsync(out.tri_uvs.data(), d_tuv.p, (size_t)n * 2 * TRI_UV_STRIDE * 4, hipMemcpyDeviceToHost, s));
+    BD_CHECK(hipStreamSynchronize(s));
     out.max_depth = depth;
     out.n_top = std::min(n_nodes, max_top_nodes);
     out.frame = frame;

@@ -132,7 +132,7 @@ struct crt_hip_ctx {
     uint32_t spp = 1;
     SceneView sv{};
     DeviceBuffer d_spill, d_tri_uvs;
-    DeviceBuffer d_nodes, d_tris, d_instances, d_material_ids, d_materials, d_textures, d_texels, d_lights;
+    DeviceBuffer d_nodes, d_slots, d_instances, d_material_ids, d_materials, d_textures, d_texels, d_lights;
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t stack_need = 0; // traversal-stack entries the deepest path of this scene's BVH can need
 
@@ -443,7 +443,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->spp = ps.spp;
     ctx->capacity = 0;
     upload(ctx->d_nodes, ps.nodes, ctx->stream);
-    upload(ctx->d_tris, ps.tris, ctx->stream);
+    upload(ctx->d_slots, ps.slots, ctx->stream);
     upload(ctx->d_tri_uvs, ps.tri_uvs, ctx->stream);
     upload(ctx->d_instances, ps.insts, ctx->stream);
     upload(ctx->d_material_ids, ps.material_ids, ctx->stream);
@@ -452,13 +452,13 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     upload(ctx->d_texels, ps.texels, ctx->stream);
     upload(ctx->d_lights, ps.lights, ctx->stream);
     ctx->n_nodes = ps.nodes.size();
-    ctx->n_tris = ps.tris.size();
+    ctx->n_tris = ps.slots.size(); // leaf slots (one or two triangles each)
     ctx->stack_need = ps.stack_need;
 
     SceneView &sv = ctx->sv;
     sv.nodes = ctx->d_nodes.as<QNode>();
     sv.root_frame = ps.root_frame;
-    sv.tris = ctx->d_tris.as<TriRec>();
+    sv.slots = ctx->d_slots.as<LeafSlot>();
     sv.tri_uvs = ctx->d_tri_uvs.as<float>();
     sv.instances = ctx->d_instances.as<InstanceRec>();
     sv.material_ids = ctx->d_material_ids.as<uint32_t>();
@@ -549,10 +549,10 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
         HIP_CHECK(hipEventRecord(e1, s));
         HIP_CHECK(hipGetLastError());
         std::vector<float4> rec(2 * n);
-        std::vector<TriRec> tris(ctx->n_tris);
+        std::vector<LeafSlot> slots(ctx->n_tris);
         HIP_CHECK(hipMemcpyAsync(rec.data(), d_out.ptr, 2 * n * sizeof(float4), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(out_inst, d_aux.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(tris.data(), ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(slots.data(), ctx->d_slots.ptr, ctx->n_tris * sizeof(LeafSlot), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         for (uint64_t i = 0; i < n; ++i) {
             int32_t tri;
@@ -560,8 +560,9 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
             out_t[i] = rec[2 * i].x;
             out_u[i] = rec[2 * i].y;
             out_v[i] = rec[2 * i].z;
-            out_geom[i] = tri < 0 ? -1 : (int32_t)tris[(size_t)tri].geom;
-            out_prim[i] = tri < 0 ? -1 : (int32_t)tris[(size_t)tri].prim;
+            const LeafSlot &sl = slots[tri < 0 ? 0 : (size_t)((uint32_t)tri >> 1)];
+            out_geom[i] = tri < 0 ? -1 : (int32_t)(sl.geom_sel & SLOT_GEOM_MASK);
+            out_prim[i] = tri < 0 ? -1 : (int32_t)((tri & 1) != 0 ? sl.prim1 : sl.prim0);
         }
     } else {
         pc.n_shadow_a[bounce] = (uint32_t)n;
@@ -806,6 +807,8 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             st.closest_tris += pc.tris_closest;
             st.shadow_nodes += pc.nodes_shadow;
             st.shadow_tris += pc.tris_shadow;
+            st.closest_slots += pc.slots_closest;
+            st.shadow_slots += pc.slots_shadow;
         }
         st.rays = st.closest_rays + st.shadow_rays;
         if (std::getenv("CRT_HIP_DEBUG")) { // per-bounce queue sizes of the first pass
@@ -1012,13 +1015,13 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
         d_inst.alloc(n * 4);
         d_geom.alloc(n * 4);
         d_prim.alloc(n * 4);
-        d_ctr.alloc(24);
+        d_ctr.alloc(32);
         hipStream_t s = ctx->stream;
         HIP_CHECK(hipMemcpyAsync(d_org.ptr, org, n * 12, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_dir.ptr, dir, n * 12, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_tmin.ptr, tmin, n * 4, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_tmax.ptr, tmax, n * 4, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 24, s));
+        HIP_CHECK(hipMemsetAsync(d_ctr.ptr, 0, 32, s));
         hipEvent_t e0 = get_event(ctx, 0), e1 = get_event(ctx, 1);
         HIP_CHECK(hipEventRecord(e0, s));
         launch_trace_diag(ctx->cfg(), ctx->sv, (uint32_t)n, d_org.as<float>(), d_dir.as<float>(), tmin[0],
@@ -1035,8 +1038,8 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
             HIP_CHECK(hipMemcpyAsync(out_geom, d_geom.ptr, n * 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipMemcpyAsync(out_prim, d_prim.ptr, n * 4, hipMemcpyDeviceToHost, s));
         }
-        unsigned long long ctr[2] = {0, 0};
-        HIP_CHECK(hipMemcpyAsync(ctr, d_ctr.ptr, 16, hipMemcpyDeviceToHost, s));
+        unsigned long long ctr[4] = {0, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(ctr, d_ctr.ptr, 32, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         if (stats) {
             std::memset(stats, 0, sizeof(*stats));
@@ -1050,11 +1053,13 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
                 stats->closest_ms = ms;
                 stats->closest_nodes = ctr[0];
                 stats->closest_tris = ctr[1];
+                stats->closest_slots = ctr[3];
             } else {
                 stats->shadow_rays = n;
                 stats->shadow_ms = ms;
                 stats->shadow_nodes = ctr[0];
                 stats->shadow_tris = ctr[1];
+                stats->shadow_slots = ctr[3];
             }
         }
         return CRT_HIP_OK;
@@ -1121,7 +1126,7 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
             HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
         }
         if (tris) {
-            HIP_CHECK(hipMemcpy(tris, ctx->d_tris.ptr, ctx->n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(tris, ctx->d_slots.ptr, ctx->n_tris * sizeof(LeafSlot), hipMemcpyDeviceToHost));
         }
         return CRT_HIP_OK;
     });

@@ -8,7 +8,7 @@ namespace crt {
 
 // Child reference c: c >= 0 -> inner node index (global, into Scene::nodes)
 //                    c <  0 -> leaf, x = ~c: first = x >> 3, count = (x & 7) + 1
-//                              BLAS: triangles [first, first+count) of Scene::tris
+//                              BLAS: leaf slots [first, first+count) of SceneView::slots (the builders make count == 1)
 //                              top-level tree of a scene with more than one instance: count == 8 (a value no
 //                              triangle leaf has: the builder makes leaves of <= 7) marks an INSTANCE leaf, instance
 //                              `first`; any other count is a triangle leaf of the instance that was grafted into the
@@ -26,9 +26,11 @@ constexpr int32_t EMPTY_CHILD = (int32_t)0x80000002;
 #define CRT_TYPES_HD inline
 #endif
 // (none of EMPTY_CHILD and the traversal's CUR_DONE / CUR_EXIT markers has its low three bits clear; the stack
-// sentinel 0x80000000 would be instance 2^28 - 1, which check_scene refuses)
+// sentinel 0x80000000 has -- it would be instance 2^28 - 1, which check_scene refuses for every kind of scene -- and is
+// excluded explicitly, so that no pop path depends on rewriting it first)
 CRT_TYPES_HD int32_t instance_leaf_ref(uint32_t instance) { return (int32_t)~((instance << 3) | 7u); }
-CRT_TYPES_HD bool is_instance_leaf(int32_t ref) { return ref < 0 && (ref & 7) == 0; }
+CRT_TYPES_HD bool is_instance_leaf(int32_t ref) { return ref < 0 && (ref & 7) == 0 && ref != (int32_t)0x80000000; }
+static_assert((EMPTY_CHILD & 7) != 0, "EMPTY_CHILD must not look like an instance leaf");
 struct alignas(16) BvhNode {
     float lo[BVH_WIDTH][3], hi[BVH_WIDTH][3];
     int32_t c[BVH_WIDTH];
@@ -60,15 +62,31 @@ struct alignas(16) QNode {
 };
 static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 
-// One triangle = 48 B; 3 x dwordx4. Embree-style precomputed edges:
-// e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1). geom = Embree geomID (position of the
-// Geometry in its Mesh), prim = Embree primID (triangle index in that Geometry).
-struct alignas(16) TriRec {
-    float v0[3], e1[3], e2[3];
-    uint32_t geom, prim;
-    uint32_t pad; // 0, except in a world tree (LEVELS_WORLD_TREE below): (instance << 1) | 1 if its transform is the identity
+// One LEAF of a BVH = one 64-byte slot = 4 x dwordx4 in ONE cache line: a triangle, or two triangles of one geometry
+// (and one instance) that share an edge -- a quad, Embree's own leaf form for triangle meshes -- stored as the four
+// distinct vertices in full precision plus the ids. A leaf visit is a dependent step that costs a line fill whatever
+// it fetches (tools/line_microbench.hip: 2.9 CU-cycles for 4 requests to one line, 4.1 for the 6 requests of two
+// 48-byte triangle records), and the second triangle of the earlier two-record leaf was a second dependent round trip
+// in the kernels that could not afford to preload it (profiles/r03_wave_phase_profile.txt: leaf steps of 13 000 cycles,
+// 41 % of the closest-hit kernel's wave time on C4).
+//   triangle A = (v[0], v[1], v[2])                      the vertices of primitive prim0 in index order
+//   triangle B = (v[s0], v[s1], v[s2]), s_k two bits     the vertices of primitive prim1 in ITS index order: each is one
+//                                                        of A's vertices or v[3]
+// The kernels form e1 = a - b, e2 = c - a from the selected vertices (a, b, c): the same IEEE subtractions the host made
+// for the 48-byte (v0, e1, e2) records of rounds 1-2, so t / u / v keep their bits (e1 = v0 - v1,
+// e2 = v2 - v0, Ng = cross(e2, e1); geom = Embree geomID, prim = Embree primID).
+// A hit is named by tri = 2 * slot + (0 for A, 1 for B): HitBuf, SceneView::tri_uvs (two uv records per slot).
+struct alignas(16) LeafSlot {
+    float v[4][3];
+    uint32_t geom_sel; // bits 0..25: geomID; bits 26..31: s0 | s1 << 2 | s2 << 4 (0 in a single-triangle slot)
+    uint32_t prim0;
+    uint32_t prim1;    // SLOT_NO_SECOND: the slot holds triangle A only (v[3] then repeats v[0])
+    uint32_t tag;      // 0, except in a world tree (LEVELS_WORLD_TREE below): (instance << 1) | 1 if its transform is the identity
 };
-static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+static_assert(sizeof(LeafSlot) == 64, "LeafSlot must be 64 bytes");
+constexpr uint32_t SLOT_NO_SECOND = 0xffffffffu;
+constexpr uint32_t SLOT_GEOM_BITS = 26;
+constexpr uint32_t SLOT_GEOM_MASK = (1u << SLOT_GEOM_BITS) - 1u;
 
 // One instance (util/mesh.h:40-47 + embree_utils.cpp:90-104), 128 B. What a ray needs when it enters the
 // instance sits in the first 80 bytes, laid out for five 16-byte requests: the affine part of
@@ -123,9 +141,9 @@ struct ViewParams {
 // Device pointers of the whole scene, passed to kernels by value.
 struct SceneView {
     const QNode *nodes;
-    const TriRec *tris;
+    const LeafSlot *slots;        // leaves: one or two triangles each (LeafSlot above)
     const InstanceRec *instances;
-    const float *tri_uvs;         // TRI_UV_STRIDE floats per TriRec (uv of v0, v1, v2, two of padding: 2 x dwordx4), same order as `tris`
+    const float *tri_uvs;         // TRI_UV_STRIDE floats per TRIANGLE index 2 * slot + which (uv of its three vertices, two of padding: 2 x dwordx4)
     const uint32_t *material_ids; // per instance per geomID; bit 31 (MATERIAL_TEXTURED): the material reads a texture
     const float *materials;       // 16 floats per material (14 used, MaterialParams order)
     const TexRec *textures;
@@ -145,8 +163,8 @@ struct SceneView {
 };
 
 // SceneView::two_level == LEVELS_WORLD_TREE ("world tree"): the scene has several instances, but memory is not what an
-// MI355X is short of (288 GB): every instance gets triangle records of its own -- still in ITS object space, with
-// TriRec::pad = (instance << 1) | identity -- and ONE tree is built over all of them from the boxes of their
+// MI355X is short of (288 GB): every instance gets leaf slots of its own -- still in ITS object space, with
+// LeafSlot::tag = (instance << 1) | identity -- and ONE tree is built over all of them from the boxes of their
 // transformed vertices. A ray walks that tree in world space from start to end (no instance entry, no second root,
 // no frame change, no exit) and is transformed into an instance's object space only to test a triangle of it, with
 // the two-level entry's expressions, so hits are bit-identical to the two-level walk and to the reference's
@@ -154,7 +172,7 @@ struct SceneView {
 constexpr uint32_t LEVELS_WORLD_TREE = 2u;
 
 constexpr uint32_t MATERIAL_TEXTURED = 0x80000000u; // flag on the entries of SceneView::material_ids (and HitBuf::mat)
-constexpr int TRI_UV_STRIDE = 8;      // floats per triangle in SceneView::tri_uvs
+constexpr int TRI_UV_STRIDE = 8;      // floats per triangle (2 per leaf slot) in SceneView::tri_uvs
 constexpr int TILE = 64;              // the reference's tile edge (render_embree.h:25)
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr float RAY_EPS = 0.0001f;    // EPSILON, backends/embree/util.ih:8

@@ -214,10 +214,11 @@ template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc
 }
 
 // ---- K2 trace_closest ----------------------------------------------------------------------------
-struct ClosestSource {
+template <int LEVELS> struct ClosestSource { // LEVELS: SceneView::two_level of the scene the kernel is built for
+    static constexpr bool CONST_TFAR = true, MULTI_RAY = false;
     PathQueue q;
     HitBuf hits;
-    const TriRec *tris;
+    const LeafSlot *slots;
     const InstanceRec *instances;
     const uint32_t *material_ids;
     CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
@@ -234,15 +235,22 @@ struct ClosestSource {
     CRT_DEV bool retire(uint32_t i, uint32_t &, const RayHit &h, V3 &, V3 &, float &, uint32_t &) const
     {
         hits.rec[2 * (size_t)i] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
-        if (hits.inst_debug != nullptr) { // crt_hip_trace_rays(CRT_HIP_TRACE_PRODUCTION) only; NULL in a frame
-            hits.inst_debug[i] = h.tri >= 0 ? h.inst : -1;
-        }
+
         if (h.tri >= 0) {
-            // Embree's hit.Ng = cross(e2, e1) of the hit triangle, instance-local, unnormalised (ispc:269)
-            const float4 *tr = reinterpret_cast<const float4 *>(tris + h.tri);
-            const float4 ta = tr[0], tb = tr[1], tc = tr[2];
-            V3 normal = unit(cross3(v3(tb.z, tb.w, tc.x), v3(ta.w, tb.x, tb.y)));
-            const InstanceRec &in = instances[h.inst];
+            // Embree's hit.Ng = cross(e2, e1) of the hit triangle, instance-local, unnormalised (ispc:269): triangle
+            // h.tri & 1 of leaf slot h.tri >> 1, e1 = v0 - v1 and e2 = v2 - v0 formed like the traversal forms them
+            const float4 *sl = reinterpret_cast<const float4 *>(slots + ((uint32_t)h.tri >> 1));
+            const float4 q0 = sl[0], q1 = sl[1], q2 = sl[2], q3 = sl[3];
+            const SlotVerts sv = slot_verts(q0, q1, q2);
+            const uint32_t sel = (h.tri & 1) != 0 ? __float_as_uint(q3.x) >> SLOT_GEOM_BITS : 0x24u; // A = (v[0], v[1], v[2])
+            const V3 va = slot_pick(sv, sel), vb = slot_pick(sv, sel >> 2), vc = slot_pick(sv, sel >> 4);
+            V3 normal = unit(cross3(vc - va, va - vb));
+            // the hit's instance: carried by the two-level walk, named by the slot's tag in a world tree, else the only one
+            const int32_t inst = LEVELS == 1 ? h.inst : LEVELS == 2 ? (int32_t)(__float_as_uint(q3.w) >> 1) : 0;
+            if (hits.inst_debug != nullptr) { // crt_hip_trace_rays(CRT_HIP_TRACE_PRODUCTION) only; NULL in a frame
+                hits.inst_debug[i] = inst;
+            }
+            const InstanceRec &in = instances[inst];
             // normal = normalize(transpose(world_to_object) * normal), ispc:288-290. For the identity matrix the same
             // expression is evaluated on literal 1s and 0s -- bit for bit what the loaded matrix gives, signed zeros
             // and non-finite values included (no fast-math: x * 0 is not folded) -- which saves the three requests
@@ -258,8 +266,10 @@ struct ClosestSource {
                                  m[6] * normal.x + m[7] * normal.y + m[8] * normal.z));
             }
             // materials[instance->material_ids[geomID]] (ispc:292-293), MATERIAL_TEXTURED in bit 31
-            const uint32_t mat = material_ids[in.mat_base + __float_as_uint(tc.y)];
+            const uint32_t mat = material_ids[in.mat_base + (__float_as_uint(q3.x) & SLOT_GEOM_MASK)];
             hits.rec[2 * (size_t)i + 1] = make_float4(normal.x, normal.y, normal.z, __uint_as_float(mat));
+        } else if (hits.inst_debug != nullptr) {
+            hits.inst_debug[i] = -1;
         }
         return false;
     }
@@ -279,14 +289,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
                                   (threadIdx.x & 63));
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
-    uint32_t n_nodes = 0, n_tris = 0;
-    const ClosestSource src{q, hits, sc.tris, sc.instances, sc.material_ids};
-    trace_wavefront<false, TWO_LEVEL, COUNTERS, ClosestSource, INST_TRIS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce],
-                                                                          tnear, src, n_nodes, n_tris, &pc->max_ray_nodes,
+    uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
+    const ClosestSource<levels_of(TWO_LEVEL, INST_TRIS)> src{q, hits, sc.slots, sc.instances, sc.material_ids};
+    trace_wavefront<false, TWO_LEVEL, COUNTERS, ClosestSource<levels_of(TWO_LEVEL, INST_TRIS)>, INST_TRIS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce],
+                                                                          tnear, src, n_nodes, n_tris, n_slots, &pc->max_ray_nodes,
                                                                           pc->worst_ray, &pc->t_start[bounce], &pc->prof_cycles[0][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_closest, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_closest, (unsigned long long)n_tris);
+        atomicAdd(&pc->slots_closest, (unsigned long long)n_slots);
     }
 }
 
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
 // evaluates  illum += tp * (cA*visA + cB*visB)  in the reference's order (ispc:117,151,175,301):
 // one thread per path and stream order between kernels, so no atomics on the radiance.
 struct ShadowSource {
+    static constexpr bool CONST_TFAR = false, MULTI_RAY = true;
     ShadowQueueA sa;
     ShadowQueueB sb;
     float4 *radiance;
@@ -360,14 +372,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
-    uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
     const ShadowSource src{sa, sb, radiance};
     trace_wavefront<true, TWO_LEVEL, COUNTERS, ShadowSource, INST_TRIS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce],
-                                                                        RAY_EPS, src, n_nodes, n_tris, nullptr, nullptr, nullptr,
+                                                                        RAY_EPS, src, n_nodes, n_tris, n_slots, nullptr, nullptr, nullptr,
                                                                         &pc->prof_cycles[1][0]);
     if (COUNTERS) {
         atomicAdd(&pc->nodes_shadow, (unsigned long long)n_nodes);
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
+        atomicAdd(&pc->slots_shadow, (unsigned long long)n_slots);
     }
 }
 
@@ -704,7 +717,8 @@ __global__ void k_assemble(const uint32_t *gathered, uint32_t slab_pixels, int w
 }
 
 // ---- diagnostics: explicit rays through the production traversal -------------------------------
-template <bool ANY_HIT> struct DiagSource {
+template <bool ANY_HIT, int LEVELS> struct DiagSource {
+    static constexpr bool CONST_TFAR = false, MULTI_RAY = false;
     SceneView sc;
     const float *org, *dir, *tmax;
     float *out_t, *out_u, *out_v;
@@ -723,15 +737,16 @@ template <bool ANY_HIT> struct DiagSource {
             out_t[i] = h.t;
             out_u[i] = h.u;
             out_v[i] = h.v;
-            out_inst[i] = h.tri < 0 ? -1 : h.inst;
-            out_geom[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].geom;
-            out_prim[i] = h.tri < 0 ? -1 : (int32_t)sc.tris[h.tri].prim;
+            const LeafSlot &sl = sc.slots[h.tri < 0 ? 0 : ((uint32_t)h.tri >> 1)];
+            out_geom[i] = h.tri < 0 ? -1 : (int32_t)(sl.geom_sel & SLOT_GEOM_MASK);
+            out_prim[i] = h.tri < 0 ? -1 : (int32_t)((h.tri & 1) != 0 ? sl.prim1 : sl.prim0);
+            out_inst[i] = h.tri < 0 ? -1 : LEVELS == 1 ? h.inst : LEVELS == 2 ? (int32_t)(sl.tag >> 1) : 0;
         }
         return false;
     }
 };
 
-// counters: [0] nodes, [1] triangles, [2] low word = ray cursor. tmin must be uniform over the
+// counters: [0] nodes, [1] triangles, [2] low word = ray cursor, [3] leaf slots. tmin must be uniform over the
 // batch (as it is inside a frame: 0 for primary rays, EPSILON afterwards).
 template <bool ANY_HIT, bool TWO_LEVEL, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32_t n, const float *org,
@@ -748,12 +763,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
-    uint32_t n_nodes = 0, n_tris = 0;
-    const DiagSource<ANY_HIT> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
-    trace_wavefront<ANY_HIT, TWO_LEVEL, true, DiagSource<ANY_HIT>, INST_TRIS>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]),
-                                                                              tmin, src, n_nodes, n_tris);
+    uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
+    const DiagSource<ANY_HIT, levels_of(TWO_LEVEL, INST_TRIS)> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
+    trace_wavefront<ANY_HIT, TWO_LEVEL, true, DiagSource<ANY_HIT, levels_of(TWO_LEVEL, INST_TRIS)>, INST_TRIS>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]),
+                                                                              tmin, src, n_nodes, n_tris, n_slots);
     atomicAdd(&counters[0], (unsigned long long)n_nodes);
     atomicAdd(&counters[1], (unsigned long long)n_tris);
+    atomicAdd(&counters[3], (unsigned long long)n_slots);
 }
 
 // ---- KATs of the device shading functions (record layouts: include/crt_kat.h) ------------------

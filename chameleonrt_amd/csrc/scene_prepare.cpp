@@ -30,6 +30,7 @@
 #include "host_parallel.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "leaf_slots.h"
 
 namespace crt {
 namespace {
@@ -161,6 +162,18 @@ void check_scene(const crt_scene_desc *s)
         if ((uint64_t)s->meshes[m].first_geometry + (uint64_t)s->meshes[m].n_geometries > (uint64_t)s->n_geometries) {
             throw std::runtime_error("mesh geometry range out of bounds");
         }
+        if (s->meshes[m].n_geometries > SLOT_GEOM_MASK) {
+            throw std::runtime_error("mesh with more than 2^26 geometries: the geomID shares its leaf-slot word with six selector bits");
+        }
+    }
+    // limits of the encodings, whatever acceleration structure the scene ends up with: an instance leaf holds the instance
+    // in 28 bits (and 0x80000000, the traversal stack's sentinel, would be instance 2^28 - 1); a world tree's leaf slot holds
+    // (instance << 1) | identity; bit 31 of a material id says that the material reads a texture (MATERIAL_TEXTURED)
+    if (s->n_instances >= (1u << 28) - 1u) {
+        throw std::runtime_error("too many instances for the 28-bit leaf reference");
+    }
+    if (s->n_materials >= MATERIAL_TEXTURED) {
+        throw std::runtime_error("too many materials: bit 31 of a material id is the textured flag");
     }
     for (uint32_t g = 0; g < s->n_geometries; ++g) {
         const crt_geometry_desc &gd = s->geometries[g];
@@ -213,11 +226,12 @@ bool world_tree_wanted(uint64_t instanced_tris)
 }
 
 
-// leaves of at most 2 triangles: with 4-wide nodes a leaf is one of four boxes tested per node
-// fetch, so small leaves are cheap to reach, and every triangle test saved is 3 lane requests
+// A leaf is ONE 64-byte slot (one triangle, or two that share an edge: leaf_slots.h): with 4-wide nodes a leaf is one of
+// four boxes tested per node fetch, so small leaves are cheap to reach, and a leaf visit is then exactly one cache line
+// and one dependent step. CRT_BVH_MAX_LEAF (tuning) counts slots.
 int max_leaf_setting()
 {
-    static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 2;
+    static const int max_leaf = std::getenv("CRT_BVH_MAX_LEAF") ? std::atoi(std::getenv("CRT_BVH_MAX_LEAF")) : 1;
     return max_leaf;
 }
 
@@ -243,6 +257,7 @@ struct ScenePreparer {
     int32_t world_inst = -1;                 // the instance grafted into the top-level tree, and its mesh
     uint32_t world_mesh = 0xffffffffu;
     std::vector<Aabb> inst_boxes;            // two-level: world box of every instance
+    std::vector<std::vector<SlotTris>> geom_slots; // per geometry of the scene: which triangles share a leaf slot (leaf_slots.h)
     uint32_t n_top = 0;
     int32_t root = 0;
     QFrame root_frame{};
@@ -270,6 +285,8 @@ struct ScenePreparer {
         phase("validate");
         ps->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
         choose_structure();
+        pair_all_geometries();
+        phase("triangle pairs");
         build_mesh_trees();
         phase("leaf-order triangles");
         make_instance_records();
@@ -346,26 +363,90 @@ struct ScenePreparer {
         }
     }
 
-    // triangle record + the uvs of its three vertices (uv_buf[indices.x|y|z], render_embree.ispc:278-283) at position `at`
-    void place_tri(const crt_mesh_desc &md, const TriRec &r, size_t at)
+    // Which triangles of each geometry share a leaf slot: once per geometry, whatever the number of instances of its mesh.
+    void pair_all_geometries()
     {
-        std::vector<TriRec> &tris = ps->tris;
-        std::vector<float> &tri_uvs = ps->tri_uvs;
-        tris[at] = r;
-        const crt_geometry_desc &gd = s->geometries[md.first_geometry + r.geom];
+        geom_slots.assign(s->n_geometries, {});
+        const float max_ratio = pair_max_ratio();
+        // (a scene is a handful of big geometries or thousands of small ones: one geometry per task either way)
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (uint32_t g = next.fetch_add(1); g < s->n_geometries; g = next.fetch_add(1)) {
+                const crt_geometry_desc &gd = s->geometries[g];
+                geom_slots[g] = pair_triangles(gd.vertices, gd.indices, gd.n_triangles, max_ratio);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::min<int>(n_threads, (int)s->n_geometries); ++t) {
+            pool.emplace_back(work);
+        }
+        work();
+        for (std::thread &th : pool) {
+            th.join();
+        }
+        if (dbg) {
+            uint64_t n_slots = 0, n_tris_all = 0;
+            for (uint32_t g = 0; g < s->n_geometries; ++g) {
+                n_slots += geom_slots[g].size();
+                n_tris_all += s->geometries[g].n_triangles;
+            }
+            std::fprintf(stderr, "[crt_hip] set_scene: %llu triangles in %llu leaf slots (%.1f %% of the triangles paired)\n",
+                         (unsigned long long)n_tris_all, (unsigned long long)n_slots,
+                         n_tris_all ? 200.0 * (double)(n_tris_all - n_slots) / (double)n_tris_all : 0.0);
+        }
+    }
+
+    // leaf slot + the uvs of its triangles' vertices (uv_buf[indices.x|y|z], render_embree.ispc:278-283) at position `at`
+    void place_slot(const crt_mesh_desc &md, const LeafSlot &r, size_t at)
+    {
+        ps->slots[at] = r;
+        const crt_geometry_desc &gd = s->geometries[md.first_geometry + (r.geom_sel & SLOT_GEOM_MASK)];
         if (gd.uvs) {
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t vi = gd.indices[3 * (size_t)r.prim + c];
-                tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c] = gd.uvs[2 * (size_t)vi];
-                tri_uvs[(size_t)TRI_UV_STRIDE * at + 2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
+            for (int which = 0; which < 2; ++which) {
+                const uint32_t prim = which == 0 ? r.prim0 : r.prim1;
+                if (prim == SLOT_NO_SECOND) {
+                    continue;
+                }
+                float *uv = ps->tri_uvs.data() + (size_t)TRI_UV_STRIDE * (2 * at + (size_t)which);
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t vi = gd.indices[3 * (size_t)prim + c];
+                    uv[2 * c] = gd.uvs[2 * (size_t)vi];
+                    uv[2 * c + 1] = gd.uvs[2 * (size_t)vi + 1];
+                }
             }
         }
+    }
+
+    // world-space (or, m == nullptr, object-space) box of a slot's triangles, pushed out by `pad`
+    static Aabb slot_box(const crt_geometry_desc &gd, SlotTris st, const float *m, float pad)
+    {
+        Aabb b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = INFINITY;
+            b.hi[a] = -INFINITY;
+        }
+        for (int which = 0; which < (st.b == SLOT_NO_SECOND ? 1 : 2); ++which) {
+            const uint32_t prim = which == 0 ? st.a : st.b;
+            for (int c = 0; c < 3; ++c) {
+                const float *p = gd.vertices + 3 * (size_t)gd.indices[3 * (size_t)prim + c];
+                for (int a = 0; a < 3; ++a) {
+                    const float w = m ? m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a] : p[a];
+                    b.lo[a] = std::min(b.lo[a], w);
+                    b.hi[a] = std::max(b.hi[a], w);
+                }
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] -= pad;
+            b.hi[a] += pad;
+        }
+        return b;
     }
 
     // one BLAS per Mesh (embree_utils.cpp:63-76); a world tree has none
     void build_mesh_trees()
     {
-        std::vector<TriRec> &tris = ps->tris;
+        std::vector<LeafSlot> &slots = ps->slots;
         std::vector<float> &tri_uvs = ps->tri_uvs;
         for (uint32_t m = 0; m < s->n_meshes && !world_tree; ++m) {
             const crt_mesh_desc &md = s->meshes[m];
@@ -374,14 +455,15 @@ struct ScenePreparer {
                 bool built_on_device = false;
                 try {
                     built_on_device = device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries,
-                                                        (uint32_t)max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST, db);
+                                                        geom_slots.data() + md.first_geometry, (uint32_t)max_leaf,
+                                                        two_level ? 0 : MAX_TOP_NODES_HOST, db);
                 } catch (const std::exception &e) { // e.g. out of device memory: the host builder still can
                     std::fprintf(stderr, "[crt_hip] %s -- building mesh %u on the host instead\n", e.what(), m);
                     (void)hipGetLastError();
                 }
                 if (built_on_device) {
-                    const size_t tri_base = tris.size();
-                    tris.insert(tris.end(), db.tris.begin(), db.tris.end());
+                    const size_t slot_base = slots.size();
+                    slots.insert(slots.end(), db.slots.begin(), db.slots.end());
                     tri_uvs.insert(tri_uvs.end(), db.tri_uvs.begin(), db.tri_uvs.end());
                     built_q[m] = std::move(db.nodes);
                     built[m].n_top = db.n_top;
@@ -390,41 +472,28 @@ struct ScenePreparer {
                     blas_depth = std::max(blas_depth, db.max_depth);
                     blas_bounds[m] = db.bounds;
                     blas_frame[m] = db.frame;
-                    blas_root[m] = (int32_t)tri_base;
+                    blas_root[m] = (int32_t)slot_base;
                     continue;
                 }
             }
-            uint64_t n_mesh_tris = 0;
+            uint64_t n_mesh_slots = 0;
+            std::vector<uint64_t> first_slot(md.n_geometries + 1, 0);
             for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                n_mesh_tris += s->geometries[md.first_geometry + k].n_triangles;
+                n_mesh_slots += geom_slots[md.first_geometry + k].size();
+                first_slot[k + 1] = n_mesh_slots;
             }
-            std::vector<TriRec> recs(n_mesh_tris);
-            std::vector<Aabb> boxes(n_mesh_tris);
-            uint64_t at0 = 0;
+            std::vector<LeafSlot> recs(n_mesh_slots);
+            std::vector<Aabb> boxes(n_mesh_slots);
             for (uint32_t k = 0; k < md.n_geometries; ++k) {
                 const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                parallel_for((size_t)gd.n_triangles, n_threads, 1u << 15, [&](size_t lo, size_t hi) {
-                    for (uint64_t t = lo; t < hi; ++t) {
-                        const float *v0 = gd.vertices + 3 * (size_t)gd.indices[3 * t];
-                        const float *v1 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 1];
-                        const float *v2 = gd.vertices + 3 * (size_t)gd.indices[3 * t + 2];
-                        TriRec r;
-                        Aabb b;
-                        for (int a = 0; a < 3; ++a) {
-                            r.v0[a] = v0[a];
-                            r.e1[a] = v0[a] - v1[a];
-                            r.e2[a] = v2[a] - v0[a];
-                            b.lo[a] = std::min(v0[a], std::min(v1[a], v2[a]));
-                            b.hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
-                        }
-                        r.geom = k;
-                        r.prim = (uint32_t)t;
-                        r.pad = 0;
-                        recs[at0 + t] = r;
-                        boxes[at0 + t] = b;
+                const std::vector<SlotTris> &gs = geom_slots[md.first_geometry + k];
+                const uint64_t at0 = first_slot[k];
+                parallel_for(gs.size(), n_threads, 1u << 15, [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi; ++i) {
+                        recs[at0 + i] = make_leaf_slot(gd.vertices, gd.indices, k, gs[i], 0u);
+                        boxes[at0 + i] = slot_box(gd, gs[i], nullptr, 0.f);
                     }
                 });
-                at0 += gd.n_triangles;
             }
             if (recs.empty()) {
                 throw std::runtime_error("mesh without triangles");
@@ -433,19 +502,19 @@ struct ScenePreparer {
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
                                              two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
             blas_depth = std::max(blas_depth, built[m].max_depth);
-            // triangles in leaf order
-            const size_t tri_base = tris.size();
-            tris.resize(tri_base + recs.size());
-            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
+            // slots in leaf order
+            const size_t slot_base = slots.size();
+            slots.resize(slot_base + recs.size());
+            tri_uvs.resize((size_t)TRI_UV_STRIDE * 2 * slots.size(), 0.f);
             parallel_for(recs.size(), n_threads, 1u << 15, [&](size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; ++i) {
-                    place_tri(md, recs[built[m].order[i]], tri_base + i);
+                    place_slot(md, recs[built[m].order[i]], slot_base + i);
                 }
             });
             blas_bounds[m] = built[m].bounds;
             blas_frame[m] = make_frame(built[m].bounds);
             // re-base the node / leaf references later, once the TLAS size is known
-            blas_root[m] = (int32_t)tri_base; // temporarily: triangle base
+            blas_root[m] = (int32_t)slot_base; // temporarily: slot base
         }
     }
 
@@ -553,27 +622,28 @@ struct ScenePreparer {
     void build_world_tree()
     {
         std::vector<QNode> &nodes = ps->nodes;
-        std::vector<TriRec> &tris = ps->tris;
+        std::vector<LeafSlot> &slots = ps->slots;
         std::vector<float> &tri_uvs = ps->tri_uvs;
         std::vector<InstanceRec> &insts = ps->insts;
         if (world_tree) {
-            // One record + one world-space box per (instance, triangle). The record is the mesh's own (object space: the
-            // triangle test runs there, with the ray transformed like the reference transforms it, so t / u / v come out
-            // bit for bit as in the two-level walk); the box bounds the transformed vertices, padded like an instance box
-            // (the test ray is a rounded transform of the world ray) -- and quantisation rounds outward by >= 1 quantum
-            // of the scene's extent on top of that.
-            std::vector<TriRec> recs(instanced_tris);
-            std::vector<Aabb> boxes(instanced_tris);
-            // where each instance's records start, so that the instances can be filled side by side
+            // One leaf slot + one world-space box per (instance, slot of its mesh). The record is the mesh's own (object
+            // space: the triangle test runs there, with the ray transformed like the reference transforms it, so t / u / v
+            // come out bit for bit as in the two-level walk); the box bounds the transformed vertices, padded like an
+            // instance box (the test ray is a rounded transform of the world ray) -- and quantisation rounds outward by
+            // >= 1 quantum of the scene's extent on top of that.
+            // where each instance's slots start, so that the instances can be filled side by side
             std::vector<uint64_t> first_rec(s->n_instances + 1, 0);
             for (uint32_t i = 0; i < s->n_instances; ++i) {
                 const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id];
-                uint64_t n_inst_tris = 0;
+                uint64_t n_inst_slots = 0;
                 for (uint32_t k = 0; k < md.n_geometries; ++k) {
-                    n_inst_tris += s->geometries[md.first_geometry + k].n_triangles;
+                    n_inst_slots += geom_slots[md.first_geometry + k].size();
                 }
-                first_rec[i + 1] = first_rec[i] + n_inst_tris;
+                first_rec[i + 1] = first_rec[i] + n_inst_slots;
             }
+            const uint64_t instanced_slots = first_rec[s->n_instances];
+            std::vector<LeafSlot> recs(instanced_slots);
+            std::vector<Aabb> boxes(instanced_slots);
             // world box of every instance's vertices: its extent and the scene's magnitude set the padding (instance_pad)
             std::vector<Aabb> inst_world(s->n_instances);
             parallel_for(s->n_instances, n_threads, 1, [&](size_t lo, size_t hi) {
@@ -616,9 +686,6 @@ struct ScenePreparer {
                 const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
                 const float *m = id.transform;
                 const bool ident = insts[i].identity != 0u;
-                auto to_world = [&](const float *p, int a) {
-                    return ident ? p[a] : m[a] * p[0] + m[4 + a] * p[1] + m[8 + a] * p[2] + m[12 + a];
-                };
                 float pad = 0.f; // an identity instance's triangles are tested with the world ray itself
                 if (!ident) {
                     const Aabb &wb = inst_world[i];
@@ -627,33 +694,19 @@ struct ScenePreparer {
                 uint64_t at0 = first_rec[i];
                 for (uint32_t k = 0; k < md.n_geometries; ++k) {
                     const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];
-                    parallel_for((size_t)gd.n_triangles, threads, 1u << 15, [&](size_t lo, size_t hi) {
-                        for (uint64_t t = lo; t < hi; ++t) {
-                            const float *v[3] = {gd.vertices + 3 * (size_t)gd.indices[3 * t], gd.vertices + 3 * (size_t)gd.indices[3 * t + 1],
-                                                 gd.vertices + 3 * (size_t)gd.indices[3 * t + 2]};
-                            TriRec r;
-                            Aabb b;
-                            for (int a = 0; a < 3; ++a) {
-                                r.v0[a] = v[0][a];
-                                r.e1[a] = v[0][a] - v[1][a];
-                                r.e2[a] = v[2][a] - v[0][a];
-                                const float w0 = to_world(v[0], a), w1 = to_world(v[1], a), w2 = to_world(v[2], a);
-                                b.lo[a] = std::min(w0, std::min(w1, w2)) - pad;
-                                b.hi[a] = std::max(w0, std::max(w1, w2)) + pad;
-                            }
-                            r.geom = k;
-                            r.prim = (uint32_t)t;
-                            r.pad = (i << 1) | (ident ? 1u : 0u);
-                            recs[at0 + t] = r;
-                            boxes[at0 + t] = b;
+                    const std::vector<SlotTris> &gs = geom_slots[md.first_geometry + k];
+                    parallel_for(gs.size(), threads, 1u << 15, [&](size_t lo, size_t hi) {
+                        for (size_t t = lo; t < hi; ++t) {
+                            recs[at0 + t] = make_leaf_slot(gd.vertices, gd.indices, k, gs[t], (i << 1) | (ident ? 1u : 0u));
+                            boxes[at0 + t] = slot_box(gd, gs[t], ident ? nullptr : m, pad);
                         }
                     });
-                    at0 += gd.n_triangles;
+                    at0 += gs.size();
                 }
             };
             {
                 // big instances one after the other with all threads inside, the small ones dealt out to the threads
-                const uint64_t big = std::max<uint64_t>(1u << 16, instanced_tris / (uint64_t)std::max(1, n_threads));
+                const uint64_t big = std::max<uint64_t>(1u << 16, instanced_slots / (uint64_t)std::max(1, n_threads));
                 std::vector<uint32_t> small;
                 for (uint32_t i = 0; i < s->n_instances; ++i) {
                     if (first_rec[i + 1] - first_rec[i] >= big) {
@@ -671,18 +724,17 @@ struct ScenePreparer {
             if (recs.empty()) {
                 throw std::runtime_error("scene without triangles");
             }
-            const int wt_leaf = std::min(max_leaf, 2); // the kernels' world-tree leaf step handles one or two triangles
-            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), wt_leaf, MAX_TOP_NODES_HOST)
-                                      : build_bvh(boxes.data(), boxes.size(), wt_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
+            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
+                                      : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
             boxes = std::vector<Aabb>();
             blas_depth = tree.max_depth;
-            tris.resize(recs.size());
-            tri_uvs.resize((size_t)TRI_UV_STRIDE * tris.size(), 0.f);
+            slots.resize(recs.size());
+            tri_uvs.resize((size_t)TRI_UV_STRIDE * 2 * slots.size(), 0.f);
             parallel_for(recs.size(), n_threads, 1u << 15, [&](size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; ++i) {
-                    const TriRec &r = recs[tree.order[i]];
-                    const crt_instance_desc &id = s->instances[r.pad >> 1];
-                    place_tri(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
+                    const LeafSlot &r = recs[tree.order[i]];
+                    const crt_instance_desc &id = s->instances[r.tag >> 1];
+                    place_slot(s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id], r, i);
                 }
             });
             root_frame = make_frame(tree.bounds);
@@ -801,9 +853,6 @@ struct ScenePreparer {
                     item_is_cut.push_back(0);
                 }
             }
-            if (s->n_instances >= (1u << 28) - 1u) {
-                throw std::runtime_error("too many instances for the 28-bit leaf reference");
-            }
             BuiltBvh tlas = build_bvh(items.data(), items.size(), 1, 0, 0, true, CRT_MAX_TOP_NODES_TWO_LEVEL, 1);
             tlas_depth = tlas.max_depth;
             root_frame = make_frame(tlas.bounds);
@@ -911,14 +960,13 @@ struct ScenePreparer {
 
     void finish_references()
     {
-        std::vector<TriRec> &tris = ps->tris;
         std::vector<InstanceRec> &insts = ps->insts;
         // a ray's stack holds at most BVH_WIDTH-1 pending siblings per level of the path it is on,
         // plus the instance-exit sentinel. The LDS part of the stack is fixed; the HBM slab behind it is
         // sized from this number at upload, so no tree is "too deep" (the reference renders any scene)
         ps->stack_need = (BVH_WIDTH - 1) * (blas_depth + tlas_depth) + 2;
-        if (tris.size() >= (1u << 28)) {
-            throw std::runtime_error("too many triangles for the 28-bit leaf reference");
+        if (ps->slots.size() >= (1u << 28)) {
+            throw std::runtime_error("too many leaf slots for the 28-bit leaf reference");
         }
         for (InstanceRec &r : insts) {
             r.blas_root = world_tree ? 0 : blas_root[r.blas_root];
@@ -1081,7 +1129,7 @@ int fail_global(int code, const std::string &msg)
 // Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
 // path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
 namespace {
-constexpr uint64_t PREP_MAGIC = 0x3430505250545243ull; // "CRTPRP04" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids)
+constexpr uint64_t PREP_MAGIC = 0x3530505250545243ull; // "CRTPRP05" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids; 05: 64-byte leaf slots)
 struct PrepHeader {
     uint64_t magic, abi;
     uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;
@@ -1141,7 +1189,7 @@ int crt_hip_prepared_scene_info(const crt_hip_prepared_scene *ps, uint64_t *n_no
         *n_nodes = ps->nodes.size();
     }
     if (n_tris) {
-        *n_tris = ps->tris.size();
+        *n_tris = ps->slots.size();
     }
     if (n_instances) {
         *n_instances = ps->insts.size();
@@ -1176,7 +1224,7 @@ int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *ps, void *nodes, v
         std::memcpy(nodes, ps->nodes.data(), ps->nodes.size() * sizeof(QNode));
     }
     if (tris) {
-        std::memcpy(tris, ps->tris.data(), ps->tris.size() * sizeof(TriRec));
+        std::memcpy(tris, ps->slots.data(), ps->slots.size() * sizeof(LeafSlot));
     }
     if (instances) {
         std::memcpy(instances, ps->insts.data(), ps->insts.size() * sizeof(InstanceRec));
@@ -1207,7 +1255,7 @@ int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *pa
     h.magic = PREP_MAGIC;
     h.abi = CRT_HIP_ABI_VERSION;
     h.n_nodes = ps->nodes.size();
-    h.n_tris = ps->tris.size();
+    h.n_tris = ps->slots.size();
     h.n_insts = ps->insts.size();
     h.n_matids = ps->material_ids.size();
     h.n_materials = ps->materials.size();
@@ -1223,7 +1271,7 @@ int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *pa
     h.spp = ps->spp;
     h.stack_need = ps->stack_need;
     h.world_inst = ps->world_inst;
-    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && prep_put(f, ps->nodes) && prep_put(f, ps->tris) && prep_put(f, ps->tri_uvs) &&
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && prep_put(f, ps->nodes) && prep_put(f, ps->slots) && prep_put(f, ps->tri_uvs) &&
                     prep_put(f, ps->insts) && prep_put(f, ps->material_ids) && prep_put(f, ps->materials) && prep_put(f, ps->lights) &&
                     prep_put(f, ps->tex) && prep_put(f, ps->texels);
     const bool closed = std::fclose(f) == 0;
@@ -1240,7 +1288,7 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
     std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
     PrepHeader h{};
     bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == PREP_MAGIC && h.abi == CRT_HIP_ABI_VERSION;
-    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->tris, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * h.n_tris) &&
+    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->slots, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * 2 * h.n_tris) &&
          prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
          prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
     std::fclose(f);

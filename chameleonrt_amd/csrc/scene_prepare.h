@@ -10,8 +10,8 @@
 // What crt_hip_prepare_scene hands out (include/crt_hip.h): the arrays the kernels read, ready for upload.
 struct crt_hip_prepared_scene {
     std::vector<crt::QNode> nodes;
-    std::vector<crt::TriRec> tris;
-    std::vector<float> tri_uvs; // TRI_UV_STRIDE per TriRec
+    std::vector<crt::LeafSlot> slots; // the leaves: one or two triangles each (crt_types.h)
+    std::vector<float> tri_uvs;      // TRI_UV_STRIDE per triangle index 2 * slot + which
     std::vector<crt::InstanceRec> insts;
     std::vector<uint32_t> material_ids;
     std::vector<float> materials, lights;

@@ -24,7 +24,8 @@ namespace crt {
 
 struct SlabRay {
     float qa[3], qb[3];  // t(q) = fma(q, qa, qb) per axis
-    uint32_t rot[3];     // 0 if qa >= 0 (entry plane = lo), 16 if qa < 0 (entry plane = hi)
+    // (the rotate count of an axis -- 0 if qa >= 0: entry plane = lo; 16 if qa < 0: entry plane = hi -- is derived from
+    // qa's sign where it is used: three registers less to keep alive across the leaf steps of the traversal kernels)
 };
 
 CRT_SLAB_FN uint32_t slab_rotr(uint32_t w, uint32_t sh) { return (w >> sh) | (w << ((32u - sh) & 31u)); }
@@ -39,7 +40,7 @@ CRT_SLAB_FN uint32_t slab_rot_of(float qa) { return (slab_bits(qa) >> 31) << 4; 
 // enters it within [tmin, tmax] (exit widened by 2 ulp, like every box test of this path tracer).
 CRT_SLAB_FN bool slab_enter(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay &r, float tmin, float tmax, float &tn)
 {
-    const uint32_t rx = slab_rotr(wx, r.rot[0]), ry = slab_rotr(wy, r.rot[1]), rz = slab_rotr(wz, r.rot[2]);
+    const uint32_t rx = slab_rotr(wx, slab_rot_of(r.qa[0])), ry = slab_rotr(wy, slab_rot_of(r.qa[1])), rz = slab_rotr(wz, slab_rot_of(r.qa[2]));
     const float nx = __builtin_fmaf((float)(rx & 0xffffu), r.qa[0], r.qb[0]), fx = __builtin_fmaf((float)(rx >> 16), r.qa[0], r.qb[0]);
     const float ny = __builtin_fmaf((float)(ry & 0xffffu), r.qa[1], r.qb[1]), fy = __builtin_fmaf((float)(ry >> 16), r.qa[1], r.qb[1]);
     const float nz = __builtin_fmaf((float)(rz & 0xffffu), r.qa[2], r.qb[2]), fz = __builtin_fmaf((float)(rz >> 16), r.qa[2], r.qb[2]);

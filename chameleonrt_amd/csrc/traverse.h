@@ -20,13 +20,13 @@ namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
 // vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 15 for the two-level ones,
-// which also keep 10 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
+// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 16 for the two-level ones,
+// which also keep 9 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
 #define CRT_LDS_STACK 16
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
-#define CRT_LDS_STACK_TWO_LEVEL 15
+#define CRT_LDS_STACK_TWO_LEVEL 16
 #endif
 // the kernels of a world tree (INST_TRIS below) keep the world-space ray in LDS next to the stack, like the two-level
 // ones: six dwords per lane, paid for with two stack entries (26 KB per block)
@@ -35,7 +35,7 @@ namespace crt {
 #endif
 // levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
 constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
-constexpr int lds_cold_of(int levels) { return levels == 1 ? 10 : levels == 2 ? 6 : 1; } // dwords of cold per-ray state per lane in LDS
+constexpr int lds_cold_of(int levels) { return levels == 1 ? 9 : levels == 2 ? 6 : 1; } // dwords of cold per-ray state per lane in LDS
 constexpr int levels_of(bool two_level, bool inst_tris) { return two_level ? 1 : inst_tris ? 2 : 0; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
 // and compact per wave, so deep traversals stay within a few pages. Its depth is a property of the
@@ -104,10 +104,12 @@ CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, const SlabRay &sr, floa
     return slab_child_key(k.x, k.y, k.z, slot, sr, tmin, tmax);
 }
 
-CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D, float tnear, float tfar,
-                      float &t, float &u, float &v)
+// (a, b, c): the triangle's vertices in its index order. e1 = v0 - v1, e2 = v2 - v0 are formed here from
+// the leaf slot's vertices -- the IEEE subtractions the host made for the 48-byte records of rounds 1-2, so every bit of
+// t / u / v is what it was.
+CRT_DEV bool tri_test(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnear, float tfar, float &t, float &u, float &v)
 {
-    const V3 v0 = v3(a.x, a.y, a.z), e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
+    const V3 v0 = a, e1 = a - b, e2 = c - a;
     const V3 Ng = cross3(e2, e1);
     const V3 C = v0 - O;
     const V3 R = cross3(C, D);
@@ -130,6 +132,26 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
     u = U / abs_den;
     v = V / abs_den;
     return true;
+}
+
+// The four quarters of a leaf slot (crt_types.h LeafSlot) -> its vertices, and triangle B's vertex k (two selector bits).
+struct SlotVerts {
+    V3 p0, p1, p2, p3;
+};
+CRT_DEV SlotVerts slot_verts(const float4 q0, const float4 q1, const float4 q2)
+{
+    SlotVerts s;
+    s.p0 = v3(q0.x, q0.y, q0.z);
+    s.p1 = v3(q0.w, q1.x, q1.y);
+    s.p2 = v3(q1.z, q1.w, q2.x);
+    s.p3 = v3(q2.y, q2.z, q2.w);
+    return s;
+}
+CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
+{
+    sel &= 3u;
+    const V3 lo = sel == 0u ? s.p0 : s.p1, hi = sel == 2u ? s.p2 : s.p3;
+    return sel < 2u ? lo : hi;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -178,10 +200,6 @@ CRT_DEV bool tri_test(const float4 a, const float4 b, const float4 c, V3 O, V3 D
 #ifndef CRT_POOL_CHUNK
 #define CRT_POOL_CHUNK 128
 #endif
-// leaf step: 1 = all loads of the step (both triangles, next stack entry) in flight before the first test
-#ifndef CRT_LEAF_V2
-#define CRT_LEAF_V2 1
-#endif
 // two-level scenes: 0 = instances are entered in the leaf phase; 1 = in the inner-node phase (see there) -- measured
 // 16 % SLOWER on the instanced C4 (123.2 vs 105.9 ms): the entry's transform and frame change then sit in the hot
 // loop that most iterations run, for the few lanes that need them
@@ -198,9 +216,12 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 }
 
 // Source: struct with
+//   static constexpr bool CONST_TFAR;                          every ray of the source ends at RAY_TFAR (load's tfar is ignored)
+//   static constexpr bool MULTI_RAY;                           retire() may hand the lane a follow-up ray (uses stage / carry)
 //   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   first ray of queue item i
 //   bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const;
-//        consume a finished ray's result (h.tri < 0: miss / unoccluded). Returning true hands the
+//        consume a finished ray's result (h.tri < 0: miss / unoccluded; h.inst is maintained by the two-level kernels
+//        only: with one instance it is 0, in a world tree the hit's leaf slot names it). Returning true hands the
 //        lane a follow-up ray of the same item (o, d, tfar, stage updated): the two NEE occlusion
 //        rays of one hit are traced back to back by one lane, which costs nothing in a wave whose
 //        lanes are refilled independently.
@@ -213,7 +234,7 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 // which the lane keeps until a triangle of another instance comes along.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source, bool INST_TRIS = false>
 CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> &st, uint32_t n,
-                             uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris,
+                             uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris, uint32_t &n_slots,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
                              unsigned long long *prof = nullptr /* PassCounters::prof_cycles[kind], iters, lanes 8 and 16 on */)
@@ -263,44 +284,57 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     V3 o = v3(0.f), d = v3(0.f);                 // ray in the space being traversed
     SlabRay sr;                                  // that ray in the fixed-point frame of the current BVH
     sr.qa[0] = sr.qa[1] = sr.qa[2] = sr.qb[0] = sr.qb[1] = sr.qb[2] = 0.f;
-    sr.rot[0] = sr.rot[1] = sr.rot[2] = 0u;
-    float tfar = 0.f;
+    float tfar_var = 0.f;
     RayHit hit;
     hit.t = 0.f;
     hit.u = hit.v = 0.f;
     hit.tri = hit.inst = -1;
-    uint32_t best_geom = 0, best_prim = 0;
-    // Two level: the barycentrics and ids of the best hit so far are written when a hit is accepted and
-    // read when the ray retires (ids also on an exact tie in t): cold state, kept in LDS next to the
-    // world-space ray (slots 6..9).
-    auto store_hit_cold = [&](float u, float v, uint32_t geom, uint32_t prim) {
+    // Two level: the barycentrics of the best hit so far are written when a hit is accepted and read when the ray
+    // retires: cold state, kept in LDS next to the world-space ray (slots 6, 7). Its geomID / primID are only ever
+    // needed on an EXACT tie in t between two hits of one instance -- two coincident triangles -- and are then read back
+    // from the best hit's leaf slot rather than carried in two registers through every step of every ray.
+    auto store_hit_cold = [&](float u, float v) {
         if (TWO_LEVEL) {
             st.cold[6 * st.stride] = u;
             st.cold[7 * st.stride] = v;
-            st.cold[8 * st.stride] = __uint_as_float(geom);
-            st.cold[9 * st.stride] = __uint_as_float(prim);
         } else {
             hit.u = u;
             hit.v = v;
-            best_geom = geom;
-            best_prim = prim;
         }
     };
-    auto tie_break = [&](uint32_t geom, uint32_t prim) -> bool { // (geom, prim) < (best_geom, best_prim)
-        const uint32_t bg = TWO_LEVEL ? __float_as_uint(st.cold[8 * st.stride]) : best_geom;
-        const uint32_t bp = TWO_LEVEL ? __float_as_uint(st.cold[9 * st.stride]) : best_prim;
+    // (inst, geom, prim) < those of the best hit so far? The best hit's ids are not carried in registers: its leaf slot
+    // names geomID / primID and, in a world tree, the instance (tag); with one instance there is nothing to compare.
+    auto tie_break = [&](int32_t inst, uint32_t geom, uint32_t prim) -> bool {
+        const LeafSlot &b = sc.slots[(uint32_t)hit.tri >> 1];
+        const int32_t bi = TWO_LEVEL ? hit.inst : INST_TRIS ? (int32_t)(b.tag >> 1) : inst;
+        if (inst != bi) {
+            return inst < bi;
+        }
+        const uint32_t bg = b.geom_sel & SLOT_GEOM_MASK, bp = (hit.tri & 1) != 0 ? b.prim1 : b.prim0;
         return geom != bg ? geom < bg : prim < bp;
     };
     int32_t cur_inst = TWO_LEVEL ? sc.world_inst : 0;
     bool in_blas = !TWO_LEVEL;
     static_assert(!(INST_TRIS && TWO_LEVEL), "per-triangle instances belong to the single tree in world space");
-    static_assert(!INST_TRIS || CRT_LEAF_V2, "per-triangle instances are implemented in the all-loads-first leaf step");
     // INST_TRIS: like the two-level kernels, the lane keeps the world-space ray in its cold LDS slots 0..5 and (o, d) is
     // the ray in the space of the triangle it tested last: xf_space = 1 for world space (every identity instance), else
     // the tag (instance << 1) of a transformed instance. (Both rays in registers cost the kernels scratch spills.)
     uint32_t xf_space = 1u;
     st.sp = 0;
-    uint32_t stage = 0, carry = 0; // multi-ray items (Source::retire)
+    // multi-ray items (Source::retire): which ray of the item the lane is on (bit 0) and what it carries over (bit 1) --
+    // read and written only when a ray retires, so one dword, and for the sources that use it (Source::MULTI_RAY)
+    // a cold LDS slot of the lane where the kernel has LDS to spare (one instance, two-level), not a register
+    constexpr int ITEM_STATE_SLOT = TWO_LEVEL ? 8 : 0;
+    constexpr bool ITEM_STATE_IN_LDS = Source::MULTI_RAY && !INST_TRIS;
+    uint32_t item_state_r = 0;
+    auto item_state = [&]() -> uint32_t { return ITEM_STATE_IN_LDS ? __float_as_uint(st.cold[ITEM_STATE_SLOT * st.stride]) : item_state_r; };
+    auto set_item_state = [&](uint32_t x) {
+        if (ITEM_STATE_IN_LDS) {
+            st.cold[ITEM_STATE_SLOT * st.stride] = __uint_as_float(x);
+        } else {
+            item_state_r = x;
+        }
+    };
     // wave-uniform pool of ray indices
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
@@ -318,9 +352,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         sr.qb[0] = (f.base[0] - o.x) * inv.x;
         sr.qb[1] = (f.base[1] - o.y) * inv.y;
         sr.qb[2] = (f.base[2] - o.z) * inv.z;
-        sr.rot[0] = slab_rot_of(sr.qa[0]);
-        sr.rot[1] = slab_rot_of(sr.qa[1]);
-        sr.rot[2] = slab_rot_of(sr.qa[2]);
     };
 
     // start traversing the world-space ray (org, dir, tfar)
@@ -341,7 +372,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             xf_space = 1u;
         }
         set_frame(sc.root_frame);
-        hit.t = tfar;
+        hit.t = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
         hit.u = hit.v = 0.f;
         hit.tri = -1;
         hit.inst = -1;
@@ -394,9 +425,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     if (rank < take) {
                         ray = (int32_t)(pool_next + rank);
                         V3 wo, wd;
-                        src.load((uint32_t)ray, wo, wd, tfar);
+                        src.load((uint32_t)ray, wo, wd, tfar_var);
                         set_world(wo, wd);
-                        stage = 0;
+                        if (Source::MULTI_RAY) {
+                            set_item_state(0u);
+                        }
                         begin_ray();
                     }
                 }
@@ -566,33 +599,26 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
             } else if (!entered && cur < 0 && cur != CUR_DONE) {
-                const uint32_t count = (x & 7u) + 1u;
+                const uint32_t count = (x & 7u) + 1u; // leaf slots (the builders make leaves of one)
                 bool occluded = false;
-#if CRT_LEAF_V2
-                // All of the leaf's loads are issued before anything is tested -- both triangles of a
-                // two-triangle leaf (the builder makes leaves of <= 2) and the stack entry the lane will
-                // continue with -- so a leaf step pays ONE memory latency instead of up to three in a
-                // row (PMC + wave profile, DESIGN.md section 6: leaf steps ran 4 700 cycles each with a
-                // third of the lanes and took 31-39 % of the traversal kernels' wave time).
-                const float4 *p = reinterpret_cast<const float4 *>(sc.tris + first);
-                const float4 a0 = p[0], b0 = p[1], c0 = p[2];
-                // (two-level kernels hold more ray state: there the second triangle is fetched after the first
-                // has been tested, which keeps them at 6 waves per SIMD instead of 5)
-                constexpr bool PRELOAD_BOTH = !TWO_LEVEL && !INST_TRIS;
-                float4 a1 = a0, b1 = b0, c1 = c0;
-                if (PRELOAD_BOTH && count > 1u) {
-                    a1 = p[3];
-                    b1 = p[4];
-                    c1 = p[5];
-                }
+                // ALL of the step's loads are issued before anything is tested: the slot -- one 64-byte line holding the
+                // leaf's one or two triangles -- and the stack entry the lane will continue with, so a leaf step pays ONE
+                // memory latency (plus one for the instance's matrix when a world tree's triangle belongs to another
+                // instance than the last one tested).
+                const float4 *p = reinterpret_cast<const float4 *>(sc.slots + first);
+                float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const bool have_next = st.sp > 0;
                 const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
-                auto test_one = [&](const float4 a, const float4 b, const float4 c, uint32_t k) {
+                // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
+                const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
+                auto test_slot = [&](uint32_t slot) {
                     if (COUNTERS) {
-                        ++n_tris;
+                        ++n_slots;
                     }
+                    const uint32_t geom = __float_as_uint(q3.x) & SLOT_GEOM_MASK, sel = __float_as_uint(q3.x) >> SLOT_GEOM_BITS;
+                    const uint32_t prim0 = __float_as_uint(q3.y), prim1 = __float_as_uint(q3.z);
                     if (INST_TRIS) {
-                        const uint32_t tag = __float_as_uint(c.w); // TriRec::pad: (instance << 1) | identity
+                        const uint32_t tag = __float_as_uint(q3.w); // LeafSlot::tag: (instance << 1) | identity
                         cur_inst = (int32_t)(tag >> 1);
                         const uint32_t space = (tag & 1u) != 0u ? 1u : tag;
                         if (space != xf_space) {
@@ -608,44 +634,58 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                             xf_space = space;
                         }
                     }
-                    float t, u, v;
-                    if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
-                        if (ANY_HIT) {
-                            occluded = true;
-                            return;
-                        }
-                        const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
+                    const SlotVerts sv = slot_verts(q0, q1, q2);
+                    auto accept = [&](float t, float u, float v, uint32_t prim, uint32_t which) {
                         bool take = t < hit.t;
-                        if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
-                            take = cur_inst != hit.inst ? cur_inst < hit.inst : tie_break(geom, prim);
+                        if (t == hit.t && hit.tri >= 0) { // exact tie with the best hit so far: (inst, geom, prim) decides
+                            take = tie_break(cur_inst, geom, prim);
                         } else if (t == hit.t) {
                             take = true; // first hit exactly at tfar
                         }
                         if (take) {
                             hit.t = t;
-                            hit.tri = (int32_t)k;
-                            hit.inst = cur_inst;
-                            store_hit_cold(u, v, geom, prim);
+                            hit.tri = (int32_t)(2u * slot + which);
+                            if (TWO_LEVEL) { // (one instance: 0; world tree: the slot's tag names it -- see tie_break)
+                                hit.inst = cur_inst;
+                            }
+                            store_hit_cold(u, v);
+                        }
+                    };
+                    float t, u, v;
+                    if (COUNTERS) {
+                        ++n_tris;
+                    }
+                    if (tri_test(sv.p0, sv.p1, sv.p2, o, d, tnear, tfar, t, u, v)) {
+                        if (ANY_HIT) {
+                            occluded = true;
+                            return;
+                        }
+                        accept(t, u, v, prim0, 0u);
+                    }
+                    if (prim1 != SLOT_NO_SECOND) {
+                        if (COUNTERS) {
+                            ++n_tris;
+                        }
+                        if (tri_test(slot_pick(sv, sel), slot_pick(sv, sel >> 2), slot_pick(sv, sel >> 4), o, d, tnear, tfar, t, u, v)) {
+                            if (ANY_HIT) {
+                                occluded = true;
+                                return;
+                            }
+                            accept(t, u, v, prim1, 1u);
                         }
                     }
                 };
-                test_one(a0, b0, c0, first);
-                if (count > 1u && !(ANY_HIT && occluded)) {
-                    if (!PRELOAD_BOTH) {
-                        a1 = p[3];
-                        b1 = p[4];
-                        c1 = p[5];
-                    }
-                    test_one(a1, b1, c1, first + 1u);
-                }
-                // (a world tree is built with leaves of <= 2, whatever CRT_BVH_MAX_LEAF says: one inlined copy less of the test)
-                for (uint32_t k = first + 2u; !INST_TRIS && k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of > 2 (CRT_BVH_MAX_LEAF)
-                    const float4 *pk = reinterpret_cast<const float4 *>(sc.tris + k);
-                    test_one(pk[0], pk[1], pk[2], k);
+                test_slot(first);
+                for (uint32_t k = first + 1u; k < first + count && !(ANY_HIT && occluded); ++k) { // leaves of several slots (CRT_BVH_MAX_LEAF)
+                    const float4 *pk = reinterpret_cast<const float4 *>(sc.slots + k);
+                    q0 = pk[0];
+                    q1 = pk[1];
+                    q2 = pk[2];
+                    q3 = pk[3];
+                    test_slot(k);
                 }
                 if (ANY_HIT && occluded) {
                     hit.tri = 0;
-                    hit.inst = cur_inst;
                     hit.t = 0.f;
                     cur = CUR_DONE;
                 } else if (!have_next) {
@@ -654,43 +694,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     --st.sp; // consume the entry read above
                     cur = TWO_LEVEL && next_ref == STACK_SENTINEL ? CUR_EXIT : next_ref;
                 }
-#else
-                for (uint32_t k = first; k < first + count; ++k) {
-                    const float4 *p = reinterpret_cast<const float4 *>(sc.tris + k);
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    if (COUNTERS) {
-                        ++n_tris;
-                    }
-                    float t, u, v;
-                    if (tri_test(a, b, c, o, d, tnear, tfar, t, u, v)) {
-                        if (ANY_HIT) {
-                            occluded = true;
-                            break;
-                        }
-                        const uint32_t geom = __float_as_uint(c.y), prim = __float_as_uint(c.z);
-                        bool take = t < hit.t;
-                        if (t == hit.t && hit.tri >= 0) { // tie: (inst, geom, prim) decides
-                            take = cur_inst != hit.inst ? cur_inst < hit.inst : tie_break(geom, prim);
-                        } else if (t == hit.t) {
-                            take = true; // first hit exactly at tfar
-                        }
-                        if (take) {
-                            hit.t = t;
-                            hit.tri = (int32_t)k;
-                            hit.inst = cur_inst;
-                            store_hit_cold(u, v, geom, prim);
-                        }
-                    }
-                }
-                if (ANY_HIT && occluded) {
-                    hit.tri = 0;
-                    hit.inst = cur_inst;
-                    hit.t = 0.f;
-                    cur = CUR_DONE;
-                } else {
-                    pop_next();
-                }
-#endif
             }
         }
 
@@ -729,7 +732,17 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 hit.v = st.cold[7 * st.stride];
             }
             V3 wo = world_org(), wd = world_dir();
-            if (src.retire((uint32_t)ray, stage, hit, wo, wd, tfar, carry)) {
+            uint32_t stage = 0, carry = 0;
+            if (Source::MULTI_RAY) {
+                const uint32_t is = item_state();
+                stage = is & 1u;
+                carry = is >> 1;
+            }
+            const bool again = src.retire((uint32_t)ray, stage, hit, wo, wd, tfar_var, carry);
+            if (Source::MULTI_RAY && again) {
+                set_item_state(stage | (carry << 1));
+            }
+            if (again) {
                 set_world(wo, wd);
                 begin_ray();
             } else {

@@ -74,6 +74,7 @@ struct PassCounters {
     uint32_t cur_shadow_b[MAX_PATH_DEPTH];
     uint32_t max_ray_nodes; // CRT_HIP_FLAG_COUNTERS: most node fetches spent on one ray, and that ray
     unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow; // CRT_HIP_FLAG_COUNTERS
+    unsigned long long slots_closest, slots_shadow;                            // leaf slots fetched (1-2 triangles each)
     float worst_ray[8];
     // CRT_HIP_FLAG_COUNTERS: wall-clock ticks (100 MHz) of the closest-hit launches: first wave start,
     // first wave that found the queue empty, last wave end -- how much of a launch is tail

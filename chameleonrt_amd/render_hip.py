@@ -125,7 +125,7 @@ class RenderHIP:
         core.check(self._ctx, self._lib.crt_hip_bvh_info(self._ctx, C.byref(nn), C.byref(nt), C.byref(ni),
                                                          C.byref(tl), core.fptr(frame)), "bvh_info")
         nodes = np.zeros((nn.value, 16), np.uint32)  # 64-byte 4-wide nodes
-        tris = np.zeros((nt.value, 12), np.float32)
+        tris = np.zeros((nt.value, 16), np.uint32)  # 64-byte leaf slots: 4 vertices (float bits), geomID | selectors, primIDs, tag
         core.check(self._ctx, self._lib.crt_hip_bvh_copy(self._ctx, nodes.ctypes.data_as(C.c_void_p),
                                                          tris.ctypes.data_as(C.c_void_p)), "bvh_copy")
         root, child_order = C.c_int32(), C.c_int32()
@@ -178,7 +178,7 @@ class PreparedScene:
                                                    C.byref(ms))
         assert rc == 0
         nodes = np.zeros((nn.value, 16), np.uint32)
-        tris = np.zeros((nt.value, 12), np.float32)
+        tris = np.zeros((nt.value, 16), np.uint32)  # 64-byte leaf slots: 4 vertices (float bits), geomID | selectors, primIDs, tag
         insts = np.zeros((ni.value, 32), np.uint32)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         assert self._lib.crt_hip_prepared_scene_copy(self.handle, vp(nodes), vp(tris), vp(insts)) == 0

@@ -135,6 +135,8 @@ typedef struct crt_render_stats {
     float closest_ms_bounce[CRT_HIP_MAX_PATH_DEPTH], shadow_ms_bounce[CRT_HIP_MAX_PATH_DEPTH],
         shade_ms_bounce[CRT_HIP_MAX_PATH_DEPTH];
     float raygen_ms, accumulate_ms;
+    /* only when CRT_HIP_FLAG_COUNTERS: 64-byte leaf slots fetched (each holds one or two triangles) */
+    uint64_t closest_slots, shadow_slots;
 } crt_render_stats;
 
 typedef struct crt_hip_ctx crt_hip_ctx;

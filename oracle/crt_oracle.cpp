@@ -1817,8 +1817,8 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 // rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
 // fixed point, ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
 // ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
-// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; 48-byte triangle
-// records. child_order 0: the children whose box is entered are visited in ascending order of the key
+// an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; a leaf is `count`
+// 64-byte leaf slots of one or two triangles each (FSlot below; tris_tested counts triangles). child_order 0: the children whose box is entered are visited in ascending order of the key
 // (bits(t_entry) & 0x7ffffffc) | slot, the rest stacked farthest first. child_order 1: the child with
 // the smallest key first, the others stacked in slot order, highest slot deepest.
 // Two-level scenes (instances != NULL): a TLAS leaf names an instance (128-byte product record:
@@ -1835,9 +1835,11 @@ struct FChild {
 struct FNode {
     FChild child[4];
 };
-struct FTri {
-    f3 v0, e1, e2;
-    uint32_t geom, prim, pad;
+// the product's 64-byte leaf slot (chameleonrt_amd/csrc/crt_types.h LeafSlot): one triangle A = (v[0], v[1], v[2]) or,
+// prim1 != 0xffffffff, also triangle B = (v[s0], v[s1], v[s2]) with the three 2-bit selectors in bits 26..31 of geom_sel
+struct FSlot {
+    f3 v[4];
+    uint32_t geom_sel, prim0, prim1, tag;
 };
 struct FInst {
     float w2o[12]; // affine 3x4 part of world_to_object: column c, row r at [c*3 + r]
@@ -1858,7 +1860,7 @@ inline f3 fxfm_vector(const float *m, f3 v)
     return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
                m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
-static_assert(sizeof(FNode) == 64 && sizeof(FTri) == 48 && sizeof(FInst) == 128, "product BVH record sizes");
+static_assert(sizeof(FNode) == 64 && sizeof(FSlot) == 64 && sizeof(FInst) == 128, "product BVH record sizes");
 constexpr int32_t F_SENTINEL = (int32_t)0x80000000;
 inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
@@ -1877,21 +1879,21 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                                     uint64_t n, const float *org, const float *dir, const float *tmin,
                                     const float *tmax, int closest, uint64_t *nodes_visited, uint64_t *tris_tested,
                                     uint32_t *max_stack, float *out_t, int32_t *out_inst, int32_t *out_geom,
-                                    int32_t *out_prim, uint64_t *inst_entries, int levels)
+                                    int32_t *out_prim, uint64_t *inst_entries, int levels, uint64_t *leaf_slots)
 {
     const FNode *nodes = static_cast<const FNode *>(nodes_);
-    const FTri *tris = static_cast<const FTri *>(tris_);
+    const FSlot *slots = static_cast<const FSlot *>(tris_);
     const FInst *insts = static_cast<const FInst *>(instances_);
     // levels (the product's SceneView::two_level): 0 one instance, 1 top-level tree over instances, 2 one tree in world
     // space whose triangle records carry (instance << 1) | identity in their last word; < 0: 0 or 1 by instance count
     const bool world_tree = levels == 2 && insts != nullptr;
     const bool two_level = !world_tree && (levels < 0 ? insts != nullptr && n_instances > 1 : levels == 1);
     const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0), ne_t(nthreads, 0), nb_t(nthreads, 0);
+    std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0), ne_t(nthreads, 0), nb_t(nthreads, 0), ls_t(nthreads, 0);
     std::vector<uint32_t> ms_t(nthreads, 0);
     std::vector<int> bad_t(nthreads, 0);
     auto work = [&](int tid) {
-        uint64_t nv = 0, tt = 0, ne = 0, nb = 0;
+        uint64_t nv = 0, tt = 0, ne = 0, nb = 0, ls = 0;
         uint32_t ms = 0;
         std::vector<int32_t> stack(1024);
         for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
@@ -1993,12 +1995,13 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                         cur = in.blas_root;
                         continue;
                     }
-                    for (uint32_t k = first; k < first + count; ++k) {
-                        ++tt;
-                        TriRec tr{tris[k].v0, tris[k].e1, tris[k].e2, tris[k].geom, tris[k].prim};
+                    for (uint32_t k = first; k < first + count && !done; ++k) {
+                        const FSlot &sl = slots[k];
+                        ++ls;
+                        const uint32_t geom = sl.geom_sel & 0x03ffffffu, sel = sl.geom_sel >> 26;
                         f3 ro = o, rd = d;
-                        if (world_tree) { // the triangle's own instance; tested in its object space (traverse.h INST_TRIS)
-                            const uint32_t tag = tris[k].pad;
+                        if (world_tree) { // the slot's own instance; tested in its object space (traverse.h INST_TRIS)
+                            const uint32_t tag = sl.tag;
                             cur_inst = (int32_t)(tag >> 1);
                             if ((tag & 1u) == 0u) {
                                 if (tag != xf_tag) {
@@ -2011,26 +2014,33 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                                 rd = xd;
                             }
                         }
-                        float t, u, v;
-                        if (tri_test(tr, ro, rd, tmin[i], tmax[i], t, u, v)) {
-                            if (!closest) {
-                                done = true;
-                                b_tri = 0;
-                                break;
-                            }
-                            bool take = t < best;
-                            if (t == best && b_tri >= 0) {
-                                take = cur_inst != b_inst ? cur_inst < b_inst
-                                                          : (tr.geom != b_geom ? tr.geom < b_geom : tr.prim < b_prim);
-                            } else if (t == best) {
-                                take = true;
-                            }
-                            if (take) {
-                                best = t;
-                                b_tri = (int32_t)k;
-                                b_inst = cur_inst;
-                                b_geom = tr.geom;
-                                b_prim = tr.prim;
+                        for (uint32_t which = 0; which < (sl.prim1 != 0xffffffffu ? 2u : 1u); ++which) {
+                            ++tt;
+                            // e1 = v0 - v1, e2 = v2 - v0 from the slot's vertices, as the kernels form them
+                            const f3 va = which ? sl.v[sel & 3u] : sl.v[0], vb = which ? sl.v[(sel >> 2) & 3u] : sl.v[1],
+                                     vc = which ? sl.v[(sel >> 4) & 3u] : sl.v[2];
+                            TriRec tr{va, va - vb, vc - va, geom, which ? sl.prim1 : sl.prim0};
+                            float t, u, v;
+                            if (tri_test(tr, ro, rd, tmin[i], tmax[i], t, u, v)) {
+                                if (!closest) {
+                                    done = true;
+                                    b_tri = 0;
+                                    break;
+                                }
+                                bool take = t < best;
+                                if (t == best && b_tri >= 0) {
+                                    take = cur_inst != b_inst ? cur_inst < b_inst
+                                                              : (tr.geom != b_geom ? tr.geom < b_geom : tr.prim < b_prim);
+                                } else if (t == best) {
+                                    take = true;
+                                }
+                                if (take) {
+                                    best = t;
+                                    b_tri = (int32_t)(2u * k + which);
+                                    b_inst = cur_inst;
+                                    b_geom = tr.geom;
+                                    b_prim = tr.prim;
+                                }
                             }
                         }
                     }
@@ -2068,6 +2078,7 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         tt_t[tid] = tt;
         ne_t[tid] = ne;
         nb_t[tid] = nb;
+        ls_t[tid] = ls;
         ms_t[tid] = ms;
     };
     std::vector<std::thread> pool;
@@ -2095,6 +2106,13 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     }
     if (inst_entries) {
         *inst_entries = ne;
+    }
+    if (leaf_slots) {
+        uint64_t ls = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            ls += ls_t[t];
+        }
+        *leaf_slots = ls;
     }
     if (std::getenv("ORC_WALK_SPLIT")) { // development aid (tools/tree_cost.py): node visits inside instances
         uint64_t nb = 0;

@@ -84,7 +84,7 @@ int orc_intersect1(const orc_scene *s, const float org[3], const float dir[3], f
                    float *t, float *u, float *v, int32_t *inst, int32_t *geom, int32_t *prim);
 int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar);
 
-/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frames / 48-byte triangles /
+/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frames / 64-byte leaf slots of 1-2 triangles /
  * 128-byte instance records) with the product's documented visit rule (child_order =
  * the product's CRT_CHILD_ORDER build setting): counts nodes fetched / triangles tested, to
  * cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers (the roofline input), reports the
@@ -99,7 +99,7 @@ int orc_walk_foreign_bvh(const void *nodes, const void *tris, const void *instan
                          const float *dir, const float *tmin, const float *tmax, int closest,
                          uint64_t *nodes_visited, uint64_t *tris_tested, uint32_t *max_stack, float *out_t,
                          int32_t *out_inst, int32_t *out_geom, int32_t *out_prim, uint64_t *inst_entries,
-                         int levels);
+                         int levels, uint64_t *leaf_slots /* 64-byte leaf slots fetched (each holds 1-2 triangles), or NULL */);
 
 /* Shading-function KATs, record layouts in include/crt_kat.h. scene may be NULL for the
  * functions that need none. */

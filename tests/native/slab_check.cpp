@@ -74,7 +74,6 @@ int main(int argc, char **argv)
             const float inv = 1.f / box_dir(d[k]);
             qa[k] = r.qa[k] = step[k] * inv;
             qb[k] = r.qb[k] = (base[k] - o[k]) * inv;
-            r.rot[k] = slab_rot_of(r.qa[k]);
         }
         const float tmin = (i & 1) ? 0.f : 1e-4f;
         const float tmax = (i % 4 != 1) ? 1e20f : std::fabs(2.f * U(rng)); // d is unnormalised when aimed: t ~ 1 at the box

@@ -48,7 +48,7 @@ def lib():
                                      i32p, i32p, i32p, C.POINTER(OrcStats)]
         L.orc_walk_foreign_bvh.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32, C.c_int32, fp, C.c_int, C.c_uint64, fp, fp, fp, fp,
                                            C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
-                                           C.POINTER(C.c_uint32), fp, i32p, i32p, i32p, C.POINTER(C.c_uint64), C.c_int]
+                                           C.POINTER(C.c_uint32), fp, i32p, i32p, i32p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         L.orc_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
         _LIB = L
     return _LIB
@@ -100,7 +100,7 @@ def walk_product_bvh(bvh, org, dirs, tmin, tmax, closest=True):
     n = org.shape[0]
     tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
     tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
-    nv, tt, ms, ne = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+    nv, tt, ms, ne, ls = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
     t = np.zeros(n, np.float32)
     inst, geom, prim = (np.zeros(n, np.int32) for _ in range(3))
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
@@ -108,10 +108,10 @@ def walk_product_bvh(bvh, org, dirs, tmin, tmax, closest=True):
     rc = lib().orc_walk_foreign_bvh(vp(bvh["nodes"]), vp(bvh["tris"]), vp(bvh["instances"]), bvh["n_instances"],
                                     bvh.get("world_inst", -1), bvh["root"], _fp(bvh["frame"]), bvh["child_order"], n, _fp(org), _fp(dirs),
                                     _fp(tmin), _fp(tmax), int(closest), C.byref(nv), C.byref(tt), C.byref(ms),
-                                    _fp(t), ip(inst), ip(geom), ip(prim), C.byref(ne), int(bvh.get("levels", -1)))
+                                    _fp(t), ip(inst), ip(geom), ip(prim), C.byref(ne), int(bvh.get("levels", -1)), C.byref(ls))
     assert rc == 0
     return dict(nodes=nv.value, tris=tt.value, max_stack=ms.value, t=t, inst=inst, geom=geom, prim=prim,
-                inst_entries=ne.value)
+                inst_entries=ne.value, slots=ls.value)
 
 
 def kat(fn, rec_in, n_out, scene_handle=None):

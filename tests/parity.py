@@ -12,6 +12,12 @@ from chameleonrt_amd.camera import camera_of, look_at  # noqa: F401  (camera_of 
 ABS_TOL, REL_TOL, MAX_DIVERGED = 1e-4, 1e-3, 1e-3
 
 
+def slot_triangles(bvh):
+    """Triangles per leaf slot of a product BVH (RenderHIP.bvh() / PreparedScene.bvh()): bvh["tris"] holds the 64-byte leaf
+    slots -- four vertices, geomID | selectors, primID of triangle A, primID of triangle B or 0xffffffff, tag (crt_types.h)."""
+    return 1 + (bvh["tris"][:, 14].view(np.uint32) != 0xffffffff).astype(np.int64)
+
+
 def probe_rays(scene, n, seed=0, spread=0.3):
     """Half camera-cone rays, half uniformly random directions from points around the scene."""
     rng = np.random.default_rng(seed)

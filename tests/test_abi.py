@@ -46,12 +46,12 @@ def test_render_stats_layout_matches_the_binding(tmp_path):
     import ctypes as C
     from chameleonrt_amd import core
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "crt_hip.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(crt_render_stats), '
-           'offsetof(crt_render_stats, closest_ms_bounce), offsetof(crt_render_stats, accumulate_ms));return 0;}\n')
+           'offsetof(crt_render_stats, closest_ms_bounce), offsetof(crt_render_stats, shadow_slots));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", str(exe)], input=src.encode(), check=True)
     size, off_ms, off_last = (int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
     assert size == C.sizeof(core.RenderStats)
-    assert off_ms == core.RenderStats.closest_ms_bounce.offset and off_last == core.RenderStats.accumulate_ms.offset
+    assert off_ms == core.RenderStats.closest_ms_bounce.offset and off_last == core.RenderStats.shadow_slots.offset
 
 
 def test_product_never_links_the_oracle(lib):

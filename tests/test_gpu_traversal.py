@@ -163,7 +163,7 @@ def test_counters_match_oracle_walk_of_the_same_bvh(pair, oracle):
     org, dirs = probe_rays(sc, 5000, seed=8)
     g = r.trace(org, dirs, 0.0, 1e20, closest=True)
     w = oracle.walk_product_bvh(bvh, org, dirs, 0.0, 1e20, closest=True)
-    assert (g["stats"].closest_nodes, g["stats"].closest_tris) == (w["nodes"], w["tris"])
+    assert (g["stats"].closest_nodes, g["stats"].closest_tris, g["stats"].closest_slots) == (w["nodes"], w["tris"], w["slots"])
     for k in ("inst", "geom", "prim"):
         assert np.array_equal(g[k], w[k]), k
     hit = w["inst"] >= 0
@@ -172,5 +172,5 @@ def test_counters_match_oracle_walk_of_the_same_bvh(pair, oracle):
     tmax = np.random.default_rng(11).random(len(org)).astype(np.float32) * 10
     g = r.trace(org, dirs, 1e-4, tmax, closest=False)
     w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, tmax, closest=False)
-    assert (g["stats"].shadow_nodes, g["stats"].shadow_tris) == (w["nodes"], w["tris"])
+    assert (g["stats"].shadow_nodes, g["stats"].shadow_tris, g["stats"].shadow_slots) == (w["nodes"], w["tris"], w["slots"])
     assert np.array_equal(g["t"], w["t"])

@@ -98,7 +98,7 @@ def main():
     t0 = time.time()
     ps = PreparedScene(sc)
     bvh = ps.bvh()
-    print(f"{tag}: prepare {time.time() - t0:.2f} s, {bvh['nodes'].shape[0]} nodes, {bvh['tris'].shape[0]} tris, "
+    print(f"{tag}: prepare {time.time() - t0:.2f} s, {bvh['nodes'].shape[0]} nodes, {bvh['tris'].shape[0]} leaf slots, "
           f"{bvh['n_instances']} instances, stack_need {bvh['stack_need']}")
     total = entries = 0.0
     for key, closest, tmin in (("p", True, 0.0), ("b1", True, 1e-4), ("b2", True, 1e-4), ("s", False, 1e-4)):
@@ -106,10 +106,11 @@ def main():
         tmax = rays["s_tmax"] if key == "s" else 1e20
         r = oracle_lib.walk_product_bvh(bvh, o, dd, tmin, tmax, closest=closest)
         m = len(o)
-        print(f"  {key:3s} {m:7d} rays: nodes/ray {r['nodes'] / m:7.2f}  tris/ray {r['tris'] / m:6.2f}  "
-              f"lines/ray {(r['nodes'] + r['tris']) / m:7.2f}  instance entries/ray {r['inst_entries'] / m:5.2f}  "
+        # a dependent "line visit" = one 64-byte node or one 64-byte leaf slot (1-2 triangles) fetched
+        print(f"  {key:3s} {m:7d} rays: nodes/ray {r['nodes'] / m:7.2f}  leaf slots/ray {r['slots'] / m:6.2f}  tris/ray {r['tris'] / m:6.2f}  "
+              f"lines/ray {(r['nodes'] + r['slots']) / m:7.2f}  instance entries/ray {r['inst_entries'] / m:5.2f}  "
               f"max stack {r['max_stack']}")
-        total += (r["nodes"] + r["tris"]) / m
+        total += (r["nodes"] + r["slots"]) / m
         entries += r["inst_entries"] / m
     print(f"  sum over the four sets: lines/ray {total:.2f}, instance entries/ray {entries:.2f}")
 
