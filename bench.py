@@ -243,7 +243,8 @@ def main():
     t_gen = t_prep = 0.0
     if rank == 0:
         t0 = time.time()
-        scene = gen(spp=spp, **kw)
+        scene, _, _, _ = scenes.make_workload(args.workload)  # the real asset under $CRT_SCENE_DIR if there is one, else the stand-in
+        scene.samples_per_pixel = spp
         t_gen = time.time() - t0
         t0 = time.time()
         ps = PreparedScene(scene, n_threads=usable_cores())
@@ -290,8 +291,10 @@ def main():
             "metric": "MRay/s (REPORT_RAY_STATS)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "MRay/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {scene.name} {width}x{height} (synthetic stand-in, SURVEY 8d)",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "real" if scene.name.startswith("real:") else "synthetic",
+            "config": {"workload": f"{args.workload} {scene.name} {width}x{height}" +
+                                   ("" if scene.name.startswith("real:") else " (synthetic stand-in, SURVEY 8d)"),
                        "spp_per_frame": spp, "triangles": scene.total_tris(), "instances": len(scene.instances),
                        "textures": len(scene.textures), "materials": len(scene.materials),
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,

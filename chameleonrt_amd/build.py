@@ -41,6 +41,21 @@ def build(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+IO_LIB = os.path.join(HERE, "libcrt_scene_io.so")
+IO_SOURCES = ["obj_reader.cpp"]
+
+
+def build_scene_io(force=False):
+    """The harness's scene-file readers (include/crt_scene_io.h): plain C++17, no HIP, no GPU."""
+    deps = [os.path.join(CSRC, f) for f in IO_SOURCES] + [os.path.join(HERE, "..", "include", "crt_scene_io.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(IO_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(IO_LIB) for d in deps):
+        return IO_LIB
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] +
+                          [os.path.join(CSRC, f) for f in IO_SOURCES] + ["-o", IO_LIB])
+    return IO_LIB
+
+
 if __name__ == "__main__":
+    build_scene_io(force="--force" in sys.argv)
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)

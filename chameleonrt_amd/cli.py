@@ -79,17 +79,9 @@ def main(argv=None) -> int:
     elif scene_file.startswith("synthetic:"):
         scene = getattr(scenes, scene_file.split(":", 1)[1])()
         scene.samples_per_pixel = spp
-    elif scene_file.lower().endswith(".crts"):  # dispatch on the extension like Scene::Scene (util/scene.cpp:49-72)
-        from .crts_io import load_crts
-        scene = load_crts(scene_file, mat_mode, spp)
-        mat_mode = "default"  # already applied by the loader, the way the reference does it
-    elif scene_file.lower().endswith((".gltf", ".glb")):
-        from .gltf_io import load_gltf
-        scene = load_gltf(scene_file, mat_mode, spp)
+    else:  # dispatch on the extension like Scene::Scene (util/scene.cpp:49-72); the loaders apply the material mode
+        scene = scenes.load_scene_file(scene_file, mat_mode, spp)
         mat_mode = "default"
-    else:
-        from .obj_io import load_obj
-        scene = load_obj(scene_file, "default", spp)
     if mat_mode == "white_diffuse":
         scene = scene.white_diffuse()
     print(f"Scene '{scene_file}':\n# Unique Triangles: {_pretty(scene.unique_tris())}\n"

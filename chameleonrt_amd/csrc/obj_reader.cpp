@@ -1,0 +1,376 @@
+// obj_reader.cpp — streaming Wavefront OBJ reader for the harness, behind the small C API of
+// include/crt_scene_io.h (libcrt_scene_io.so, plain g++: no HIP in here).
+//
+// What the reference's importer makes of an OBJ file (util/scene.cpp:94-228, on tinyobjloader): every `o` / `g` group
+// that has faces becomes one Geometry; polygons are triangulated as fans; the vertices of a group are re-indexed on
+// unique (position, normal, uv) index triples in order of first use; a group's material is the material of its FIRST
+// face. This file does the text half of that -- the part that is hopeless line by line in Python on the 10 M-triangle
+// assets BASELINE.json names (Rungholt, San Miguel): one pass over the memory-mapped file with std::from_chars
+// (correctly rounded, like Python's float() followed by the float32 conversion of the reference loader), an
+// open-addressing table per group for the re-indexing. Materials (MTL -> Disney, textures) stay in obj_io.py: a few
+// dozen lines of text. chameleonrt_amd/obj_io.py::load_obj uses this reader and keeps its pure-Python twin for the
+// tests that demand identical arrays from both (tests/test_obj_io.py).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <charconv>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crt_scene_io.h"
+
+namespace {
+
+struct Corner {
+    int32_t v, n, t;
+};
+
+struct Shape {
+    std::vector<float> verts, uvs;  // after re-indexing
+    std::vector<uint32_t> indices;
+    std::string material;           // usemtl name in force at the group's first face ("" = none)
+    int material_libs = 0;          // mtllib lines read when that usemtl was met: the name resolves against those only
+    bool has_material = false, has_uv = false, mixed_uv = false;
+    // re-indexing table: open addressing on the (v, n, t) triple
+    std::vector<Corner> keys;
+    std::vector<uint32_t> vals;
+    size_t used = 0;
+    std::vector<Corner> pending;    // corners of the group's faces, three per triangle, before re-indexing
+};
+
+inline uint64_t hash_corner(const Corner &c)
+{
+    uint64_t h = (uint64_t)(uint32_t)c.v * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)(uint32_t)c.n + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= ((uint64_t)(uint32_t)c.t + 0x165667B1ull) * 0x9E3779B185EBCA87ull;
+    return h ^ (h >> 29);
+}
+
+struct Parser {
+    const char *p, *end;
+    std::vector<float> pos, tex;
+    size_t n_normals = 0;
+    std::vector<Shape> shapes;
+    std::vector<std::string> mtllibs;
+    std::string cur_mat;
+    bool have_mat = false;
+    int cur_mat_libs = 0;
+    int cur = -1; // index into shapes, -1: the next face opens a new one
+    std::string error;
+
+    static bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
+    void skip_space()
+    {
+        while (p < end && is_space(*p)) {
+            ++p;
+        }
+    }
+    const char *token_end() const
+    {
+        const char *q = p;
+        while (q < end && !is_space(*q) && *q != '\n') {
+            ++q;
+        }
+        return q;
+    }
+    void skip_line()
+    {
+        while (p < end && *p != '\n') {
+            ++p;
+        }
+        if (p < end) {
+            ++p;
+        }
+    }
+    bool at_eol()
+    {
+        skip_space();
+        return p >= end || *p == '\n';
+    }
+    bool read_float(float &out)
+    {
+        skip_space();
+        const char *q = token_end();
+        if (q == p) {
+            return false;
+        }
+        const char *b = p;
+        if (*b == '+') {
+            ++b; // from_chars does not accept a leading plus; Python's float() does
+        }
+        double d = 0.0;
+        const auto r = std::from_chars(b, q, d);
+        if (r.ec != std::errc() || r.ptr != q) {
+            return false;
+        }
+        out = (float)d; // float(x) -> float32, like np.asarray(..., np.float32)
+        p = q;
+        return true;
+    }
+    // rest of the line, whitespace-separated tokens joined by single blanks (Python: " ".join(tok[1:]))
+    std::string rest_joined()
+    {
+        std::string s;
+        while (!at_eol()) {
+            const char *q = token_end();
+            if (!s.empty()) {
+                s.push_back(' ');
+            }
+            s.append(p, q);
+            p = q;
+        }
+        return s;
+    }
+    static bool parse_int(const char *b, const char *e, long &out)
+    {
+        if (b < e && *b == '+') {
+            ++b;
+        }
+        const auto r = std::from_chars(b, e, out);
+        return r.ec == std::errc() && r.ptr == e;
+    }
+    // OBJ indices are 1-based; negative = relative to what has been read so far
+    static int32_t resolve(long i, size_t n) { return (int32_t)(i > 0 ? i - 1 : (long)n + i); }
+
+    bool parse_face()
+    {
+        Corner first{0, 0, 0}, prev{0, 0, 0};
+        int count = 0;
+        while (!at_eol()) {
+            const char *q = token_end();
+            const char *s1 = (const char *)memchr(p, '/', (size_t)(q - p));
+            const char *s2 = s1 ? (const char *)memchr(s1 + 1, '/', (size_t)(q - s1 - 1)) : nullptr;
+            long vi = 0, ti = 0, ni = 0;
+            if (!parse_int(p, s1 ? s1 : q, vi)) {
+                error = "bad face index";
+                return false;
+            }
+            Corner c;
+            c.v = resolve(vi, pos.size() / 3);
+            c.t = -1;
+            c.n = -1;
+            if (s1) {
+                const char *te = s2 ? s2 : q;
+                if (te > s1 + 1) {
+                    if (!parse_int(s1 + 1, te, ti)) {
+                        error = "bad face index";
+                        return false;
+                    }
+                    c.t = resolve(ti, tex.size() / 2);
+                }
+                if (s2 && q > s2 + 1) {
+                    if (!parse_int(s2 + 1, q, ni)) {
+                        error = "bad face index";
+                        return false;
+                    }
+                    c.n = resolve(ni, n_normals);
+                }
+            }
+            if (c.v < 0 || (size_t)c.v >= pos.size() / 3 || (c.t >= 0 && (size_t)c.t >= tex.size() / 2)) {
+                error = "face index out of range";
+                return false;
+            }
+            p = q;
+            if (count == 0) {
+                first = c;
+            } else if (count >= 2) { // fan: (first, prev, this)
+                if (cur < 0) {
+                    shapes.emplace_back();
+                    cur = (int)shapes.size() - 1;
+                }
+                Shape &s = shapes[(size_t)cur];
+                if (s.pending.empty()) {
+                    s.material = cur_mat;
+                    s.has_material = have_mat;
+                    s.material_libs = cur_mat_libs;
+                }
+                s.pending.push_back(first);
+                s.pending.push_back(prev);
+                s.pending.push_back(c);
+            }
+            prev = c;
+            ++count;
+        }
+        return true;
+    }
+
+    bool run()
+    {
+        while (p < end) {
+            skip_space();
+            if (p >= end) {
+                break;
+            }
+            if (*p == '\n' || *p == '#') {
+                skip_line();
+                continue;
+            }
+            const char *q = token_end();
+            const size_t len = (size_t)(q - p);
+            const char *kw = p;
+            p = q;
+            if (len == 1 && kw[0] == 'v') {
+                float x[3];
+                if (!read_float(x[0]) || !read_float(x[1]) || !read_float(x[2])) {
+                    error = "bad vertex";
+                    return false;
+                }
+                pos.insert(pos.end(), x, x + 3);
+            } else if (len == 2 && kw[0] == 'v' && kw[1] == 't') {
+                float u = 0.f, v = 0.f;
+                if (!read_float(u)) {
+                    error = "bad texture coordinate";
+                    return false;
+                }
+                if (!at_eol() && !read_float(v)) {
+                    error = "bad texture coordinate";
+                    return false;
+                }
+                tex.push_back(u);
+                tex.push_back(v);
+            } else if (len == 2 && kw[0] == 'v' && kw[1] == 'n') {
+                ++n_normals; // vertex normals only take part in the re-indexing key (the renderer ignores them: quirk Q7)
+            } else if (len == 1 && kw[0] == 'f') {
+                if (!parse_face()) {
+                    return false;
+                }
+            } else if (len == 1 && (kw[0] == 'o' || kw[0] == 'g')) {
+                // a new group; tinyobj does not emit empty shapes, so one without faces is simply continued
+                if (!(cur >= 0 && shapes[(size_t)cur].pending.empty())) {
+                    cur = -1;
+                }
+            } else if (len == 6 && std::memcmp(kw, "usemtl", 6) == 0) {
+                cur_mat = rest_joined();
+                have_mat = true;
+                cur_mat_libs = (int)mtllibs.size();
+            } else if (len == 6 && std::memcmp(kw, "mtllib", 6) == 0) {
+                skip_space();
+                const char *e = token_end();
+                mtllibs.emplace_back(p, e);
+                p = e;
+            }
+            skip_line();
+        }
+        // re-index every group on unique (v, n, t) triples in order of first use
+        for (Shape &s : shapes) {
+            size_t cap = 16;
+            while (cap < 2 * s.pending.size()) {
+                cap *= 2;
+            }
+            s.keys.assign(cap, Corner{-2, -2, -2});
+            s.vals.assign(cap, 0u);
+            s.indices.reserve(s.pending.size());
+            size_t n_uv = 0;
+            for (const Corner &c : s.pending) {
+                size_t h = (size_t)hash_corner(c) & (cap - 1);
+                for (;;) {
+                    const Corner &k = s.keys[h];
+                    if (k.v == -2) {
+                        s.keys[h] = c;
+                        s.vals[h] = (uint32_t)(s.verts.size() / 3);
+                        s.verts.insert(s.verts.end(), pos.begin() + 3 * (size_t)c.v, pos.begin() + 3 * (size_t)c.v + 3);
+                        if (c.t >= 0) {
+                            s.uvs.insert(s.uvs.end(), tex.begin() + 2 * (size_t)c.t, tex.begin() + 2 * (size_t)c.t + 2);
+                            ++n_uv;
+                        }
+                        break;
+                    }
+                    if (k.v == c.v && k.n == c.n && k.t == c.t) {
+                        break;
+                    }
+                    h = (h + 1) & (cap - 1);
+                }
+                s.indices.push_back(s.vals[h]);
+            }
+            s.has_uv = n_uv > 0;
+            s.mixed_uv = n_uv > 0 && n_uv != s.verts.size() / 3;
+            s.keys = std::vector<Corner>();
+            s.vals = std::vector<uint32_t>();
+            s.pending = std::vector<Corner>();
+        }
+        // groups without faces never became shapes
+        return true;
+    }
+};
+
+} // namespace
+
+struct crt_obj_file {
+    Parser parser;
+    std::string error;
+};
+
+extern "C" {
+
+crt_obj_file *crt_obj_parse(const char *path)
+{
+    crt_obj_file *f = new crt_obj_file;
+    const int fd = path ? open(path, O_RDONLY) : -1;
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) {
+        f->error = std::string("cannot read ") + (path ? path : "(null)");
+        if (fd >= 0) {
+            close(fd);
+        }
+        return f;
+    }
+    const size_t size = (size_t)st.st_size;
+    void *map = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (size && map == MAP_FAILED) {
+        f->error = std::string("cannot map ") + path;
+        return f;
+    }
+    f->parser.p = static_cast<const char *>(map);
+    f->parser.end = f->parser.p + size;
+    if (!f->parser.run()) {
+        f->error = f->parser.error.empty() ? "parse error" : f->parser.error;
+    }
+    if (map) {
+        munmap(map, size);
+    }
+    f->parser.pos = std::vector<float>();
+    f->parser.tex = std::vector<float>();
+    return f;
+}
+
+const char *crt_obj_error(const crt_obj_file *f) { return f && !f->error.empty() ? f->error.c_str() : nullptr; }
+void crt_obj_free(crt_obj_file *f) { delete f; }
+int crt_obj_num_shapes(const crt_obj_file *f) { return f ? (int)f->parser.shapes.size() : 0; }
+int crt_obj_num_mtllibs(const crt_obj_file *f) { return f ? (int)f->parser.mtllibs.size() : 0; }
+const char *crt_obj_mtllib(const crt_obj_file *f, int i) { return f->parser.mtllibs[(size_t)i].c_str(); }
+
+int crt_obj_shape_info(const crt_obj_file *f, int s, uint64_t *n_vertices, uint64_t *n_triangles, int *has_uv, int *has_material)
+{
+    if (!f || s < 0 || (size_t)s >= f->parser.shapes.size()) {
+        return -1;
+    }
+    const Shape &sh = f->parser.shapes[(size_t)s];
+    *n_vertices = sh.verts.size() / 3;
+    *n_triangles = sh.indices.size() / 3;
+    *has_uv = sh.mixed_uv ? -1 : (sh.has_uv ? 1 : 0); // -1: the group mixes vertices with and without texture coordinates
+    *has_material = sh.has_material ? 1 : 0;
+    return 0;
+}
+const char *crt_obj_shape_material(const crt_obj_file *f, int s) { return f->parser.shapes[(size_t)s].material.c_str(); }
+int crt_obj_shape_material_libs(const crt_obj_file *f, int s) { return f->parser.shapes[(size_t)s].material_libs; }
+
+int crt_obj_shape_copy(const crt_obj_file *f, int s, float *vertices, uint32_t *indices, float *uvs)
+{
+    if (!f || s < 0 || (size_t)s >= f->parser.shapes.size()) {
+        return -1;
+    }
+    const Shape &sh = f->parser.shapes[(size_t)s];
+    std::memcpy(vertices, sh.verts.data(), sh.verts.size() * sizeof(float));
+    std::memcpy(indices, sh.indices.data(), sh.indices.size() * sizeof(uint32_t));
+    if (uvs && sh.has_uv && !sh.mixed_uv) {
+        std::memcpy(uvs, sh.uvs.data(), sh.uvs.size() * sizeof(float));
+    }
+    return 0;
+}
+
+} // extern "C"

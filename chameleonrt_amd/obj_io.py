@@ -51,7 +51,73 @@ def _load_texture(path: str, name: str) -> Image:
     return Image(a.shape[1], a.shape[0], 4, a, SRGB, name)
 
 
-def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int = 1) -> Scene:
+def _read_obj_native(path: str):
+    """Geometry half of load_obj through the streaming C++ reader (csrc/obj_reader.cpp, include/crt_scene_io.h):
+    [(vertices, indices, uvs or None, material name or None)], mtllib file names."""
+    import ctypes as C
+    from . import build
+    L = C.CDLL(build.build_scene_io())
+    L.crt_obj_parse.restype = C.c_void_p
+    L.crt_obj_parse.argtypes = [C.c_char_p]
+    L.crt_obj_error.restype = C.c_char_p
+    L.crt_obj_error.argtypes = [C.c_void_p]
+    L.crt_obj_free.argtypes = [C.c_void_p]
+    L.crt_obj_mtllib.restype = C.c_char_p
+    L.crt_obj_mtllib.argtypes = [C.c_void_p, C.c_int]
+    L.crt_obj_num_mtllibs.argtypes = [C.c_void_p]
+    L.crt_obj_num_shapes.argtypes = [C.c_void_p]
+    L.crt_obj_shape_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.crt_obj_shape_material.restype = C.c_char_p
+    L.crt_obj_shape_material.argtypes = [C.c_void_p, C.c_int]
+    L.crt_obj_shape_material_libs.argtypes = [C.c_void_p, C.c_int]
+    L.crt_obj_shape_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    f = L.crt_obj_parse(os.fsencode(path))
+    try:
+        err = L.crt_obj_error(f)
+        if err:
+            raise ValueError(f"{path}: {err.decode()}")
+        libs = [L.crt_obj_mtllib(f, i).decode() for i in range(L.crt_obj_num_mtllibs(f))]
+        shapes = []
+        for s in range(L.crt_obj_num_shapes(f)):
+            nv, nt, has_uv, has_mat = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_int()
+            assert L.crt_obj_shape_info(f, s, C.byref(nv), C.byref(nt), C.byref(has_uv), C.byref(has_mat)) == 0
+            if has_uv.value < 0:
+                raise ValueError("OBJ group mixes vertices with and without texture coordinates")
+            v = np.zeros((nv.value, 3), np.float32)
+            ix = np.zeros((nt.value, 3), np.uint32)
+            uv = np.zeros((nv.value, 2), np.float32) if has_uv.value else None
+            assert L.crt_obj_shape_copy(f, s, v.ctypes.data_as(C.c_void_p), ix.ctypes.data_as(C.c_void_p),
+                                        uv.ctypes.data_as(C.c_void_p) if uv is not None else None) == 0
+            shapes.append((v, ix, uv, L.crt_obj_shape_material(f, s).decode() if has_mat.value else None, L.crt_obj_shape_material_libs(f, s)))
+        return shapes, libs
+    finally:
+        L.crt_obj_free(f)
+
+
+def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int = 1, reader: str = "native") -> Scene:
+    """reader="native": the streaming C++ reader (a 10 M-triangle OBJ in seconds); "python": the line-by-line twin this
+    module started with, kept as the statement of the semantics -- both must produce identical arrays (tests/test_obj_io.py)."""
+    if reader == "python":
+        return _load_obj_python(path, material_mode, samples_per_pixel)
+    base_dir = os.path.dirname(os.path.abspath(path))
+    raw, libs = _read_obj_native(path)
+    if not raw:
+        raise ValueError(f"no faces in {path}")
+    obj_materials: List[dict] = []
+    mat_index_after: List[Dict[str, int]] = [{}]  # name -> id with the first k mtllib files read
+    for lib in libs:
+        idx = dict(mat_index_after[-1])
+        for m in _parse_mtl(os.path.join(base_dir, lib)):
+            idx[m["name"]] = len(obj_materials)
+            obj_materials.append(m)
+        mat_index_after.append(idx)
+    geoms = [Geometry(v, ix, uv) for v, ix, uv, _, _ in raw]
+    material_ids = [(mat_index_after[k].get(name, -1) if name is not None else -1) if material_mode == "default" else -1
+                    for _, _, _, name, k in raw]
+    return _assemble_obj_scene(path, base_dir, geoms, material_ids, obj_materials, material_mode, samples_per_pixel)
+
+
+def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixel: int = 1) -> Scene:
     base_dir = os.path.dirname(os.path.abspath(path))
     positions: List[List[float]] = []
     normals: List[List[float]] = []
@@ -135,7 +201,11 @@ def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int =
             raise ValueError("OBJ group mixes vertices with and without texture coordinates")
         geoms.append(Geometry(np.asarray(verts, np.float32), np.asarray(tris, np.uint32),
                               np.asarray(uvs, np.float32) if has_uv else None))
+    return _assemble_obj_scene(path, base_dir, geoms, material_ids, obj_materials, material_mode, samples_per_pixel)
 
+
+def _assemble_obj_scene(path, base_dir, geoms, material_ids, obj_materials, material_mode, samples_per_pixel) -> Scene:
+    """One Mesh, one ParameterizedMesh, one identity Instance, MTL -> Disney, the generated light (scene.cpp:184-227)."""
     sc = Scene(name=os.path.basename(path))
     sc.meshes = [Mesh(geoms)]
     sc.instances = [Instance(np.eye(4, dtype=np.float32).reshape(16), 0)]

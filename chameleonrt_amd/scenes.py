@@ -575,8 +575,64 @@ WORKLOADS = {
 }
 
 
+# Where the REAL assets of BASELINE.json's configurations are looked for when $CRT_SCENE_DIR is set (the
+# synthetic stand-ins are used "unless real assets are found under $CRT_SCENE_DIR"): one directory per asset holding
+# the scene file (.obj + .mtl + textures, .gltf / .glb, or .crts) and, optionally, camera.json
+# {"eye": [x, y, z], "center": [...], "up": [...], "fovy": degrees} -- OBJ and glTF files carry no camera, and the
+# reference's default (eye (0, 0, 5), centre (0, 0, 0), up (0, 1, 0), fovy 65: main.cpp:122-125) sees little of a
+# building from inside a wall.
+REAL_ASSETS = {"C1": "cornell", "C2": "sponza", "C3": "rungholt", "C4": "san-miguel", "C4F": "san-miguel", "C5": "san-miguel"}
+
+
+def load_scene_file(path: str, material_mode: str = "default", samples_per_pixel: int = 1) -> Scene:
+    """Dispatch on the extension like Scene::Scene (util/scene.cpp:49-72): .crts, .gltf / .glb, else OBJ."""
+    low = path.lower()
+    if low.endswith(".crts"):
+        from .crts_io import load_crts
+        return load_crts(path, material_mode, samples_per_pixel)
+    if low.endswith((".gltf", ".glb")):
+        from .gltf_io import load_gltf
+        return load_gltf(path, material_mode, samples_per_pixel)
+    from .obj_io import load_obj
+    sc = load_obj(path, "default", samples_per_pixel)
+    return sc.white_diffuse() if material_mode == "white_diffuse" else sc
+
+
+def real_asset(name: str):
+    """Path of the real scene file of workload `name` under $CRT_SCENE_DIR, or None (then the stand-in is generated)."""
+    import os
+    root = os.environ.get("CRT_SCENE_DIR")
+    if not root or name not in REAL_ASSETS:
+        return None
+    d = os.path.join(root, REAL_ASSETS[name])
+    if not os.path.isdir(d):
+        return None
+    for ext in (".crts", ".glb", ".gltf", ".obj"):
+        found = sorted(f for f in os.listdir(d) if f.lower().endswith(ext))
+        if found:
+            return os.path.join(d, found[0])
+    return None
+
+
 def make_workload(name: str, **overrides):
+    """(scene, width, height, spp) of a BASELINE.json configuration: the real asset if $CRT_SCENE_DIR provides it
+    (scene.name then starts with "real:"), else the deterministic synthetic stand-in of SURVEY 8d."""
     gen, kw, w, h, spp = WORKLOADS[name]
+    path = real_asset(name)
+    if path is not None and not overrides:
+        import json
+        import os
+        sc = load_scene_file(path, "default", spp)
+        sc.name = "real:" + os.path.basename(path)
+        cam_file = os.path.join(os.path.dirname(path), "camera.json")
+        if os.path.exists(cam_file):
+            with open(cam_file) as f:
+                c = json.load(f)
+            sc.cameras = [Camera(np.asarray(c["eye"], np.float32), np.asarray(c["center"], np.float32),
+                                 np.asarray(c.get("up", [0, 1, 0]), np.float32), float(c.get("fovy", 65.0)))]
+        elif not sc.cameras:
+            sc.cameras = [Camera(np.array([0, 0, 5], np.float32), np.zeros(3, np.float32), np.array([0, 1, 0], np.float32), 65.0)]
+        return sc, w, h, spp
     kw = dict(kw)
     kw.update(overrides)
     return gen(spp=spp, **kw), w, h, spp

@@ -33,9 +33,21 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.crt_hip_abi_version() == 2
 
 
+def test_scene_io_library_exports_its_header():
+    """include/crt_scene_io.h (the harness's streaming OBJ reader) == what libcrt_scene_io.so exports."""
+    import ctypes as C
+    from chameleonrt_amd import build
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "crt_scene_io.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(crt_obj_[a-z_]+)\s*\(", src)))
+    assert len(names) >= 9
+    L = C.CDLL(build.build_scene_io())
+    for n in names:
+        assert hasattr(L, n), n
+
+
 def test_header_is_plain_c():
     """The boundary must be consumable from C (cgo/JNI/ctypes style bindings)."""
-    src = '#include "crt_hip.h"\n#include "crt_kat.h"\nint main(void){return crt_hip_abi_version()==CRT_HIP_ABI_VERSION?0:1;}\n'
+    src = '#include "crt_hip.h"\n#include "crt_kat.h"\n#include "crt_scene_io.h"\nint main(void){return crt_hip_abi_version()==CRT_HIP_ABI_VERSION?0:1;}\n'
     p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         "-x", "c", "-"], input=src.encode(), capture_output=True)
     assert p.returncode == 0, p.stderr.decode()

@@ -54,3 +54,28 @@ def test_packed_scene_layout():
     assert d.n_meshes == 4 and d.n_instances == 65 and d.n_geometries == 6
     assert d.meshes[1].first_geometry == 1 and d.meshes[1].n_geometries == 2
     assert d.samples_per_pixel == sc.samples_per_pixel
+
+
+def test_real_assets_are_used_when_the_scene_directory_has_them(tmp_path, monkeypatch):
+    """the synthetic stand-ins are generated "unless real assets are found under $CRT_SCENE_DIR" -- a
+    directory per asset (cornell, sponza, rungholt, san-miguel) holding the scene file and, optionally, camera.json."""
+    import json
+    import os
+    from chameleonrt_amd.obj_io import load_obj, save_obj
+    d = tmp_path / "cornell"
+    d.mkdir()
+    save_obj(scenes.cornell(), str(d / "CornellBox-Original.obj"))
+    monkeypatch.setenv("CRT_SCENE_DIR", str(tmp_path))
+    sc, w, h, spp = scenes.make_workload("C1")
+    assert sc.name == "real:CornellBox-Original.obj" and (w, h, spp) == (512, 512, 1) and sc.samples_per_pixel == 1
+    ref = load_obj(str(d / "CornellBox-Original.obj"))
+    assert sc.total_tris() == ref.total_tris() == 34
+    assert np.allclose(sc.cameras[0].position, [0, 0, 5]) and sc.cameras[0].fov_y == 65.0  # main.cpp:122-125
+    (d / "camera.json").write_text(json.dumps({"eye": [0, 1, 3.4], "center": [0, 1, 0], "fovy": 40}))
+    sc, _, _, _ = scenes.make_workload("C1")
+    assert np.allclose(sc.cameras[0].position, [0, 1, 3.4]) and sc.cameras[0].fov_y == 40.0
+    # no directory for the asset: the stand-in, as before
+    sc3, _, _, _ = scenes.make_workload("C2", detail=0.01, tex_size=8)
+    assert not sc3.name.startswith("real:")
+    monkeypatch.delenv("CRT_SCENE_DIR")
+    assert scenes.make_workload("C1")[0].name == "cornell"
