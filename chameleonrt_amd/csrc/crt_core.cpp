@@ -165,7 +165,11 @@ struct crt_hip_ctx {
             (void)hipStreamDestroy(own_stream);
         }
     }
-    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0}; }
+    // bounces traced a wave at a time (packet.h): CRT_HIP_PACKET_BOUNCES, default 1 = the camera rays and their occlusion
+    // rays; 0 when the scene's tree is deeper than a wave's stack
+    int packet_bounces = 1;
+    bool packet_ok = true;
+    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, packet_ok ? packet_bounces : 0}; }
 };
 
 namespace {
@@ -340,6 +344,9 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
+        if (const char *e = std::getenv("CRT_HIP_PACKET_BOUNCES")) {
+            c->packet_bounces = std::max(0, std::min(std::atoi(e), (int)MAX_PATH_DEPTH));
+        }
         c->stream = c->own_stream;
     } catch (const HipError &err) {
         set_global_error(err.msg);
@@ -454,6 +461,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->n_nodes = ps.nodes.size();
     ctx->n_tris = ps.slots.size(); // leaf slots (one or two triangles each)
     ctx->stack_need = ps.stack_need;
+    ctx->packet_ok = ps.stack_need <= packet_stack_entries();
 
     SceneView &sv = ctx->sv;
     sv.nodes = ctx->d_nodes.as<QNode>();

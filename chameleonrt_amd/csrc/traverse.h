@@ -61,6 +61,7 @@ template <int LDS_STACK> struct TraversalStack {
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
+    TV_LDS uint32_t *junk; // 256 bytes of the block's LDS nobody reads: where prefetch_leaf()'s LDS-DMA loads land
     int sp;
     CRT_DEV void push(int32_t x)
     {
@@ -193,6 +194,10 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 // but 14 % slower on C4, where the nearer child is much more often the occluder
 #ifndef CRT_ANYHIT_SORT
 #define CRT_ANYHIT_SORT 1
+#endif
+// 1: a lane starts fetching a leaf slot's line the moment the leaf becomes its next reference (prefetch_leaf below)
+#ifndef CRT_LEAF_PREFETCH
+#define CRT_LEAF_PREFETCH 1
 #endif
 #ifndef CRT_DEFER_RETIRE
 #define CRT_DEFER_RETIRE 1
@@ -380,6 +385,23 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         cur = sc.root;
     };
 
+    // LEAF PREFETCH. A leaf slot is touched by few rays, so its line usually comes from HBM (the nodes above it mostly from
+    // L2): a leaf step used to take 12 000 cycles against 3 700 for an inner-node step -- 34 % of the closest-hit kernel's wave
+    // time on C4 spent with 29 lanes waiting for memory (profiles/r03_wave_phase_profile.txt). The moment a lane KNOWS it
+    // will visit a leaf -- the reference has become its `cur` -- it starts fetching the slot's line; the lane then usually
+    // sits through a few more inner-node iterations of its wave before the leaf phase comes round, and finds the line in
+    // the L2 (or L1). gfx950 has no prefetch instruction; an LDS-DMA load (global_load_lds_dword: HBM -> LDS, no VGPR
+    // written, so nothing for a late return to clobber) of the slot's first dword into 256 bytes of LDS that nobody reads
+    // is one: one extra request per leaf visit, to the line the visit needs anyway.
+    auto prefetch_leaf = [&](int32_t ref) {
+#if CRT_LEAF_PREFETCH
+        if (ref < 0 && ref != CUR_DONE && ref != CUR_EXIT && ref != STACK_SENTINEL && !(TWO_LEVEL && !in_blas && is_instance_leaf(ref))) {
+            const LeafSlot *slot = sc.slots + ((~(uint32_t)ref) >> 3);
+            __builtin_amdgcn_global_load_lds((const TV_HBM void *)slot, (TV_LDS void *)st.junk, 4, 0, 0);
+        }
+#endif
+    };
+
     // Take the next reference off the stack (or finish). Popping the instance-exit sentinel only MARKS the lane
     // (CUR_EXIT): restoring the world-space ray and its frame (three reciprocals, a dozen multiplies, six LDS reads)
     // is done by the leaf phase, like entering an instance, so that the inner-node loop -- which most iterations
@@ -393,6 +415,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         if (TWO_LEVEL && cur == STACK_SENTINEL) {
             cur = CUR_EXIT;
         }
+        prefetch_leaf(cur);
     };
 
     for (;;) {
@@ -526,6 +549,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                             st.push((int32_t)k1.w);
                         }
                         cur = (int32_t)(first == 0 ? k0.w : first == 1 ? k1.w : first == 2 ? k2.w : k3.w);
+                        prefetch_leaf(cur);
                     }
                 } else if (CRT_CHILD_ORDER == 1) {
                     // nearest child first, the other entered children stacked in slot order: no sort
@@ -547,6 +571,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                             st.push((int32_t)k0.w);
                         }
                         cur = ref_of(nearest);
+                        prefetch_leaf(cur);
                     }
                 } else if (b0 == 0xffffffffu) {
                     pop_next();
@@ -561,6 +586,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                         st.push(ref_of(c1));
                     }
                     cur = ref_of(b0);
+                    prefetch_leaf(cur);
                 }
             }
             pf_mark(1, n_inner);
@@ -693,6 +719,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 } else {
                     --st.sp; // consume the entry read above
                     cur = TWO_LEVEL && next_ref == STACK_SENTINEL ? CUR_EXIT : next_ref;
+                    prefetch_leaf(cur);
                 }
             }
         }
