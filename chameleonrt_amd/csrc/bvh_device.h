@@ -30,6 +30,14 @@ struct SlotTris;
 bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
                        uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out);
 
+// The WORLD TREE of a scene with several instances (crt_types.h LEVELS_WORLD_TREE) built the same way: one item per
+// (instance, leaf slot of its mesh), the slot record in the mesh's object space with tag = (instance << 1) | identity, the
+// box around the transformed vertices pushed out by inst_pad[instance] (scene_prepare.cpp instance_pad; 0 for an identity
+// instance) -- the host loop of build_world_tree, per item on the device. The reference's role: rtcCommitScene of the
+// top-level scene (embree_utils.cpp:121-129).
+bool device_build_world(int device, const crt_scene_desc *scene, const std::vector<SlotTris> *geom_slots, const uint32_t *inst_identity,
+                        const float *inst_pad, uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out);
+
 // The same algorithm run serially on the host (shares lbvh.h with the kernels): what the CPU tests
 // check, and the reference the device result is compared against (CRT_BVH_BUILDER=lbvh).
 BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes);

@@ -76,13 +76,23 @@ inline float ord2f(uint32_t o)
     return f;
 }
 
-// One entry per leaf slot of the mesh, from the host's pairing: the geometry and the one or two primitives it holds.
+// One entry per leaf slot of the tree, from the host's pairing: the geometry (index into the uploaded GeomDev array) and
+// the one or two primitives it holds; for a world tree also the instance the slot belongs to.
 struct SlotDev {
-    uint32_t geom, a, b, pad; // b == SLOT_NO_SECOND: single
+    uint32_t geom, a, b, inst; // b == SLOT_NO_SECOND: single; inst == NO_INSTANCE: a mesh's own BLAS
+};
+constexpr uint32_t NO_INSTANCE = 0xffffffffu;
+// World tree: what a slot needs of its instance (scene_prepare.cpp build_world_tree: the same expressions on the host)
+struct InstDev {
+    float m[16];         // object_to_world, column-major
+    float pad;           // how far the slot's world box is pushed out (instance_pad): 0 for an identity instance
+    uint32_t identity;
+    uint32_t geom_first; // first geometry of the instance's mesh: LeafSlot::geom_sel holds the geomID INSIDE the mesh
+    uint32_t unused;
 };
 
-__global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms, const SlotDev *table, const float *verts,
-                                               const uint32_t *indices, LeafSlot *recs, Aabb *boxes, uint32_t *bounds)
+__global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms, const SlotDev *table, const InstDev *insts,
+                                               const float *verts, const uint32_t *indices, LeafSlot *recs, Aabb *boxes, uint32_t *bounds)
 {
     __shared__ uint32_t s_b[6];
     if (threadIdx.x < 6) {
@@ -93,7 +103,13 @@ __global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms,
     if (t < n) {
         const SlotDev sd = table[t];
         const GeomDev g = geoms[sd.geom];
+        const bool instanced = sd.inst != NO_INSTANCE;
+        const InstDev *in = instanced ? insts + sd.inst : nullptr;
+        const bool xform = instanced && in->identity == 0u;
         // the expressions of make_leaf_slot / slot_box (leaf_slots.h, scene_prepare.cpp): same record, same box
+        auto to_box = [&](const float *p, int a) -> float {
+            return xform ? in->m[a] * p[0] + in->m[4 + a] * p[1] + in->m[8 + a] * p[2] + in->m[12 + a] : p[a];
+        };
         const uint32_t *ia = indices + 3 * (size_t)(g.tri_begin + sd.a);
         const float *va[3] = {verts + 3 * (size_t)(g.vert_begin + ia[0]), verts + 3 * (size_t)(g.vert_begin + ia[1]),
                               verts + 3 * (size_t)(g.vert_begin + ia[2])};
@@ -104,8 +120,9 @@ __global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms,
             r.v[1][a] = va[1][a];
             r.v[2][a] = va[2][a];
             r.v[3][a] = va[0][a];
-            b.lo[a] = fminf(va[0][a], fminf(va[1][a], va[2][a]));
-            b.hi[a] = fmaxf(va[0][a], fmaxf(va[1][a], va[2][a]));
+            const float w0 = to_box(va[0], a), w1 = to_box(va[1], a), w2 = to_box(va[2], a);
+            b.lo[a] = fminf(w0, fminf(w1, w2));
+            b.hi[a] = fmaxf(w0, fmaxf(w1, w2));
         }
         uint32_t sel = 0;
         if (sd.b != SLOT_NO_SECOND) {
@@ -124,16 +141,22 @@ __global__ __launch_bounds__(256) void k_setup(uint32_t n, const GeomDev *geoms,
                     r.v[3][2] = p[2];
                 }
                 for (int a = 0; a < 3; ++a) {
-                    b.lo[a] = fminf(b.lo[a], p[a]);
-                    b.hi[a] = fmaxf(b.hi[a], p[a]);
+                    const float w = to_box(p, a);
+                    b.lo[a] = fminf(b.lo[a], w);
+                    b.hi[a] = fmaxf(b.hi[a], w);
                 }
                 sel |= where << (2 * k);
             }
         }
-        r.geom_sel = sd.geom | (sel << SLOT_GEOM_BITS);
+        const float pad = instanced ? in->pad : 0.f;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] -= pad;
+            b.hi[a] += pad;
+        }
+        r.geom_sel = (sd.geom - (instanced ? in->geom_first : 0u)) | (sel << SLOT_GEOM_BITS);
         r.prim0 = sd.a;
         r.prim1 = sd.b;
-        r.tag = 0;
+        r.tag = instanced ? (sd.inst << 1) | (in->identity != 0u ? 1u : 0u) : 0u;
         recs[t] = r;
         boxes[t] = b;
         for (int a = 0; a < 3; ++a) {
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(256) void k_collapse(LbvhTree t, const int32_t *fro
     nodes[level_base + i] = node;
 }
 
-__global__ __launch_bounds__(256) void k_emit(uint32_t n, const LeafSlot *recs, const uint32_t *idx, const GeomDev *geoms,
+__global__ __launch_bounds__(256) void k_emit(uint32_t n, const LeafSlot *recs, const uint32_t *idx, const GeomDev *geoms, const SlotDev *table,
                                               const uint32_t *indices, const float *uvs, LeafSlot *slots, float *tri_uvs)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, const LeafSlot *recs, 
     }
     const LeafSlot r = recs[idx[p]];
     slots[p] = r;
-    const GeomDev g = geoms[r.geom_sel & SLOT_GEOM_MASK];
+    const GeomDev g = geoms[table[idx[p]].geom];
     for (int which = 0; which < 2; ++which) {
         const uint32_t prim = which == 0 ? r.prim0 : r.prim1;
         float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -304,18 +327,22 @@ inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 } // namespace
 
-bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
-                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
+namespace {
+
+// The pipeline behind both entry points: geometry upload, k_setup over the slot table, keys / sort / radix tree / refit with
+// both key normalisations, collapse, emit.
+bool build_on_device(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotDev> &table,
+                     const std::vector<InstDev> &inst_table, uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
 {
-    uint64_t n_tris = 0, n_verts = 0, n_uvs = 0, n_slots = 0;
+    uint64_t n_tris = 0, n_verts = 0, n_uvs = 0;
     for (uint32_t g = 0; g < n_geoms; ++g) {
         n_tris += geoms[g].n_triangles;
         n_verts += geoms[g].n_vertices;
         n_uvs += geoms[g].uvs ? geoms[g].n_vertices : 0;
-        n_slots += geom_slots[g].size();
     }
-    if (n_tris < 4096 || n_tris >= (1ull << 28) || n_verts >= (1ull << 32)) {
-        return false; // small meshes: the host builder takes milliseconds and builds the better tree
+    const uint64_t n_slots = table.size();
+    if (n_slots < 2048 || n_slots >= (1ull << 28) || n_tris >= (1ull << 32) || n_verts >= (1ull << 32)) {
+        return false; // small trees: the host builder takes milliseconds and builds the better tree
     }
     // the caller's current device is restored on every way out (a thread that drives another GPU, e.g. the GL
     // interop path, must not find its device changed), and the build runs on a stream of its own: the legacy default
@@ -366,21 +393,16 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
             t0 += geoms[g].n_triangles;
             v0 += geoms[g].n_vertices;
         }
-        // (a geometry without triangles shares its tri_begin with its successor; k_setup's search returns the LAST
-        // geometry whose tri_begin <= t, which is the one that owns t; trailing empty ones begin past the end)
     }
     d_geoms.alloc(n_geoms * sizeof(GeomDev));
     BD_CHECK(hipMemcpyAsync(d_geoms.p, gd.data(), n_geoms * sizeof(GeomDev), hipMemcpyHostToDevice, s));
-    std::vector<SlotDev> table;
-    table.reserve(n);
-    for (uint32_t g = 0; g < n_geoms; ++g) {
-        for (const SlotTris &st : geom_slots[g]) {
-            table.push_back(SlotDev{g, st.a, st.b, 0u});
-        }
-    }
-    Buf d_table;
+    Buf d_table, d_insts;
     d_table.alloc((size_t)n * sizeof(SlotDev));
     BD_CHECK(hipMemcpyAsync(d_table.p, table.data(), (size_t)n * sizeof(SlotDev), hipMemcpyHostToDevice, s));
+    d_insts.alloc(inst_table.size() * sizeof(InstDev));
+    if (!inst_table.empty()) {
+        BD_CHECK(hipMemcpyAsync(d_insts.p, inst_table.data(), inst_table.size() * sizeof(InstDev), hipMemcpyHostToDevice, s));
+    }
 
     Buf d_recs, d_boxes, d_bounds;
     d_recs.alloc((size_t)n * sizeof(LeafSlot));
@@ -390,7 +412,7 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
         const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
         BD_CHECK(hipMemcpyAsync(d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
     }
-    k_setup<<<grid_for(n), 256, 0, s>>>(n, d_geoms.as<GeomDev>(), d_table.as<SlotDev>(), d_verts.as<float>(), d_indices.as<uint32_t>(),
+    k_setup<<<grid_for(n), 256, 0, s>>>(n, d_geoms.as<GeomDev>(), d_table.as<SlotDev>(), d_insts.as<InstDev>(), d_verts.as<float>(), d_indices.as<uint32_t>(),
                                         d_recs.as<LeafSlot>(), d_boxes.as<Aabb>(), d_bounds.as<uint32_t>());
     uint32_t hb[6];
     BD_CHECK(hipMemcpyAsync(hb, d_bounds.p, sizeof(hb), hipMemcpyDeviceToHost, s));
@@ -487,7 +509,7 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     Buf d_slots, d_tuv;
     d_slots.alloc((size_t)n * sizeof(LeafSlot));
     d_tuv.alloc((size_t)n * 2 * TRI_UV_STRIDE * 4);
-    k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<LeafSlot>(), idx, d_geoms.as<GeomDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
+    k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<LeafSlot>(), idx, d_geoms.as<GeomDev>(), d_table.as<SlotDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
                                        d_slots.as<LeafSlot>(), d_tuv.as<float>());
     BD_CHECK(hipGetLastError());
     out.nodes.resize(n_nodes);
@@ -501,6 +523,43 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
     out.n_top = std::min(n_nodes, max_top_nodes);
     out.frame = frame;
     return true;
+}
+
+} // namespace
+
+bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
+                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
+{
+    std::vector<SlotDev> table;
+    for (uint32_t g = 0; g < n_geoms; ++g) {
+        for (const SlotTris &st : geom_slots[g]) {
+            table.push_back(SlotDev{g, st.a, st.b, NO_INSTANCE});
+        }
+    }
+    return build_on_device(device, geoms, n_geoms, table, {}, max_leaf, max_top_nodes, out);
+}
+
+bool device_build_world(int device, const crt_scene_desc *scene, const std::vector<SlotTris> *geom_slots, const uint32_t *inst_identity,
+                        const float *inst_pad, uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
+{
+    std::vector<InstDev> insts(scene->n_instances);
+    std::vector<SlotDev> table;
+    for (uint32_t i = 0; i < scene->n_instances; ++i) {
+        const crt_instance_desc &id = scene->instances[i];
+        const crt_mesh_desc &md = scene->meshes[scene->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
+        InstDev &d = insts[i];
+        std::memcpy(d.m, id.transform, sizeof(d.m));
+        d.pad = inst_pad[i];
+        d.identity = inst_identity[i];
+        d.geom_first = md.first_geometry;
+        d.unused = 0;
+        for (uint32_t k = 0; k < md.n_geometries; ++k) { // the order of scene_prepare.cpp's host loop: instance, geometry, slot
+            for (const SlotTris &st : geom_slots[md.first_geometry + k]) {
+                table.push_back(SlotDev{md.first_geometry + k, st.a, st.b, i});
+            }
+        }
+    }
+    return build_on_device(device, scene->geometries, scene->n_geometries, table, insts, max_leaf, max_top_nodes, out);
 }
 
 } // namespace crt

@@ -642,8 +642,8 @@ struct ScenePreparer {
                 first_rec[i + 1] = first_rec[i] + n_inst_slots;
             }
             const uint64_t instanced_slots = first_rec[s->n_instances];
-            std::vector<LeafSlot> recs(instanced_slots);
-            std::vector<Aabb> boxes(instanced_slots);
+            std::vector<LeafSlot> recs; // (sized below, once it is clear that the host builds the tree)
+            std::vector<Aabb> boxes;
             // world box of every instance's vertices: its extent and the scene's magnitude set the padding (instance_pad)
             std::vector<Aabb> inst_world(s->n_instances);
             parallel_for(s->n_instances, n_threads, 1, [&](size_t lo, size_t hi) {
@@ -679,6 +679,49 @@ struct ScenePreparer {
                     }
                 }
             }
+            auto pad_of = [&](uint32_t i) -> float { // an identity instance's triangles are tested with the world ray itself
+                if (insts[i].identity != 0u) {
+                    return 0.f;
+                }
+                const Aabb &wb = inst_world[i];
+                return instance_pad(s->instances[i].transform, insts[i].w2o,
+                                    std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2])), scene_mag);
+            };
+            if (build_device >= 0 && !host_lbvh) {
+                // The same tree on the device (bvh_device.hip device_build_world): slot records and world boxes per
+                // (instance, slot), Morton sort, radix tree, refit, collapse -- set_scene of the instanced C4 without the
+                // host SAH build over 5 M slots. Falls through to the host builder if the device cannot (memory).
+                std::vector<uint32_t> ident(s->n_instances);
+                std::vector<float> pads(s->n_instances);
+                for (uint32_t i = 0; i < s->n_instances; ++i) {
+                    ident[i] = insts[i].identity;
+                    pads[i] = pad_of(i);
+                }
+                DeviceBuiltMesh db;
+                bool built_on_device = false;
+                try {
+                    built_on_device = device_build_world(build_device, s, geom_slots.data(), ident.data(), pads.data(), (uint32_t)max_leaf,
+                                                         MAX_TOP_NODES_HOST, db);
+                } catch (const std::exception &e) {
+                    std::fprintf(stderr, "[crt_hip] %s -- building the world tree on the host instead\n", e.what());
+                    (void)hipGetLastError();
+                }
+                if (built_on_device) {
+                    nodes = std::move(db.nodes);
+                    slots = std::move(db.slots);
+                    tri_uvs = std::move(db.tri_uvs);
+                    blas_depth = db.max_depth;
+                    root_frame = db.frame;
+                    n_top = db.n_top;
+                    root = 0;
+                    for (InstanceRec &r : insts) {
+                        r.frame = root_frame;
+                    }
+                    return;
+                }
+            }
+            recs.resize(instanced_slots);
+            boxes.resize(instanced_slots);
             // (a scene is one big static instance plus many small ones, or many alike: instances are dealt out one at a
             // time, and a big one is cut by geometry ranges inside fill_instance)
             auto fill_instance = [&](uint32_t i, int threads) {
@@ -686,11 +729,7 @@ struct ScenePreparer {
                 const crt_mesh_desc &md = s->meshes[s->parameterized_meshes[id.parameterized_mesh_id].mesh_id];
                 const float *m = id.transform;
                 const bool ident = insts[i].identity != 0u;
-                float pad = 0.f; // an identity instance's triangles are tested with the world ray itself
-                if (!ident) {
-                    const Aabb &wb = inst_world[i];
-                    pad = instance_pad(m, insts[i].w2o, std::max(wb.hi[0] - wb.lo[0], std::max(wb.hi[1] - wb.lo[1], wb.hi[2] - wb.lo[2])), scene_mag);
-                }
+                const float pad = pad_of(i);
                 uint64_t at0 = first_rec[i];
                 for (uint32_t k = 0; k < md.n_geometries; ++k) {
                     const crt_geometry_desc &gd = s->geometries[md.first_geometry + k];

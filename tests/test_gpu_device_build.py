@@ -95,3 +95,60 @@ def test_frames_with_a_device_built_scene_equal_frames_with_the_host_built_one(h
         r.close()
         ps.close()
     assert np.array_equal(imgs[0][0], imgs[1][0], equal_nan=True) and np.array_equal(imgs[0][1], imgs[1][1])
+
+
+def test_world_tree_built_on_the_device(oracle, hip_lib, monkeypatch):
+    """The WORLD TREE of an instanced scene (the default structure for several instances) built on the device
+    (bvh_device.hip device_build_world): per (instance, leaf slot) the slot record in the mesh's object space, tagged with
+    its instance, and the world box of its transformed vertices -- then the same linear-BVH pipeline as a mesh's BLAS.
+    The result is the serial twin's tree (CRT_BVH_BUILDER=lbvh on the host: same node count, same slots in the same
+    order, bit for bit), its walk finds what brute force over the instances finds, the production kernels on it agree
+    with that walk in hits and counters, and frames equal the frames of the host SAH world tree bit for bit."""
+    from tests.parity import camera_of, slot_triangles
+    sc = scenes.sanmiguel_like(spp=2, detail=0.05, tex_size=32, n_trees=120, leaves_per_tree=600, n_instanced=60, glass=True)
+    monkeypatch.delenv("CRT_HIP_LEVELS", raising=False)
+    t0 = time.time()
+    dev = PreparedScene(sc, build_device=0)
+    t_dev = time.time() - t0
+    b_dev = dev.bvh()
+    assert b_dev["levels"] == 2 and slot_triangles(b_dev).sum() == sc.total_tris()
+    monkeypatch.setenv("CRT_BVH_BUILDER", "lbvh")
+    b_ref = PreparedScene(sc).bvh()
+    monkeypatch.delenv("CRT_BVH_BUILDER")
+    t0 = time.time()
+    sah = PreparedScene(sc)
+    t_sah = time.time() - t0
+    b_sah = sah.bvh()
+    assert b_dev["nodes"].shape == b_ref["nodes"].shape and b_dev["stack_need"] == b_ref["stack_need"]
+    assert np.array_equal(b_dev["tris"], b_ref["tris"]), "leaf slots: device build vs its serial twin"
+    assert np.array_equal(b_dev["nodes"], b_ref["nodes"]), "quantised nodes: device build vs its serial twin"
+    o = oracle.OracleScene(sc)
+    org, dirs = probe_rays(sc, 30000, seed=43)
+    c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    w_dev = oracle.walk_product_bvh(b_dev, org, dirs, 0.0, 1e20, closest=True)
+    w_sah = oracle.walk_product_bvh(b_sah, org, dirs, 0.0, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w_dev[k], c[k]), k
+    hit = c["inst"] >= 0
+    assert (c["inst"][hit] > 0).any()
+    assert np.array_equal(w_dev["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
+    e, d, u, fovy = camera_of(sc)
+    imgs = []
+    for ps in (dev, sah):
+        r = RenderHIP(flags=core.FLAG_COUNTERS)
+        r.initialize(320, 180)
+        r.set_prepared_scene(ps)
+        if ps is dev:
+            g = r.trace(org, dirs, 0.0, 1e20, closest=True)
+            for k in ("inst", "geom", "prim"):
+                assert np.array_equal(g[k], c[k]), k
+            assert (g["stats"].closest_nodes, g["stats"].closest_slots) == (w_dev["nodes"], w_dev["slots"])
+        for f in range(2):
+            r.render(e, d, u, fovy, f == 0, True)
+        imgs.append((r.accum().copy(), r.ray_counts().copy()))
+        r.close()
+        ps.close()
+    assert np.array_equal(imgs[0][0], imgs[1][0], equal_nan=True) and np.array_equal(imgs[0][1], imgs[1][1])
+    print(f"\nworld tree of {b_dev['tris'].shape[0]} leaf slots: device build {t_dev:.2f} s, host SAH {t_sah:.2f} s; "
+          f"nodes/ray device {w_dev['nodes'] / len(org):.1f} vs SAH {w_sah['nodes'] / len(org):.1f} "
+          f"(+{100.0 * (w_dev['nodes'] / w_sah['nodes'] - 1):.0f} %)")
