@@ -56,6 +56,7 @@ def parse():
                     help="scenes with several instances: a top-level tree over the instances (two) or one tree in world space "
                          "over per-instance triangle records (world); default: the library's choice (world while the instanced "
                          "triangles fit its memory budget)")
+    ap.add_argument("--no-cache", action="store_true", help="do not keep / reuse the prepared scene under /dev/shm between runs")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-schedule", action="store_true", help="N = 1: do not also time the other launch schedule")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
@@ -227,9 +228,11 @@ def main():
         os.environ["CRT_HIP_LEVELS"] = args.levels  # read when a scene is prepared
     gen, kw, width, height, base_spp = scenes.WORKLOADS[args.workload]
     spp = base_spp * (world if args.scaling == "weak" else 1)
-    # ---- scene: generated and prepared ONCE per node (rank 0), shared through /dev/shm ----------------
-    tag = f"{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid() if dist else os.getpid()}"
-    # tmpfs if it has room for a prepared San-Miguel-class scene (~2 GB: nodes, triangles, 8-bit texels); every
+    # ---- scene: generated and prepared ONCE per node (rank 0), shared through /dev/shm; and once per BOX: the prepared
+    # arrays stay there as a cache keyed by the workload and the library build, so that the back-to-back runs of a scaling
+    # series (N = 1, 2, 4, 8) do not each spend ~20 s on scene generation and the BVH build while N - 1 ranks wait at the
+    # barrier (--no-cache: always regenerate; caches older than two hours are swept) ----------------
+    # tmpfs if it has room for a prepared San-Miguel-class scene (~2 GB: nodes, leaf slots, 8-bit texels); every
     # rank evaluates the same rule on the same node, so they agree on the path
     shm = "/tmp"
     try:
@@ -238,34 +241,70 @@ def main():
             shm = "/dev/shm"
     except OSError:
         pass
-    prepared_path, meta_path = f"{shm}/crt_prepared_{tag}.bin", f"{shm}/crt_prepared_{tag}.json"
+    build_on_device = os.environ.get("CRT_HIP_BUILD") == "device"  # the BVH by the device builder (bvh_device.hip) instead of host SAH
+    import hashlib
+    lib_stat = os.stat(core.LIB_PATH)
+    key = hashlib.sha1(repr((args.workload, sorted(kw.items()), args.levels, build_on_device, os.environ.get("CRT_SCENE_DIR"),
+                             [os.environ.get(k) for k in ("CRT_PAIR_MAX_RATIO", "CRT_BVH_MAX_LEAF", "CRT_BVH_BUILDER", "CRT_HIP_NO_GRAFT")],
+                             lib_stat.st_size, int(lib_stat.st_mtime))).encode()).hexdigest()[:12]
+    prepared_path, meta_path = f"{shm}/crt_prepared_{args.workload}_{key}.bin", f"{shm}/crt_prepared_{args.workload}_{key}.json"
     scene = None
     t_gen = t_prep = 0.0
+    cache_hit = False
+    meta = None
+
+    def the_scene():
+        """The Scene object itself (the oracle needs it; a cache hit of the prepared arrays does not)."""
+        nonlocal scene, t_gen
+        if scene is None:
+            t0 = time.time()
+            scene, _, _, _ = scenes.make_workload(args.workload)  # the real asset under $CRT_SCENE_DIR if there is one, else the stand-in
+            scene.samples_per_pixel = spp
+            t_gen = time.time() - t0
+        return scene
+
     if rank == 0:
-        t0 = time.time()
-        scene, _, _, _ = scenes.make_workload(args.workload)  # the real asset under $CRT_SCENE_DIR if there is one, else the stand-in
-        scene.samples_per_pixel = spp
-        t_gen = time.time() - t0
-        t0 = time.time()
-        ps = PreparedScene(scene, n_threads=usable_cores())
-        t_prep = time.time() - t0
-        eye, cdir, up, fovy = camera_of(scene)
+        for f in os.listdir(shm):  # sweep stale caches
+            if f.startswith("crt_prepared_"):
+                try:
+                    if time.time() - os.path.getmtime(os.path.join(shm, f)) > 7200:
+                        os.remove(os.path.join(shm, f))
+                except OSError:
+                    pass
+        if not args.no_cache and os.path.exists(prepared_path) and os.path.exists(meta_path):
+            try:
+                ps = PreparedScene(path=prepared_path)
+                with open(meta_path) as f:
+                    meta = json.load(f)
+                ps.set_samples_per_pixel(spp)
+                cache_hit = True
+            except Exception:  # a truncated or foreign file: rebuild
+                meta = None
+        if not cache_hit:
+            sc = the_scene()
+            t0 = time.time()
+            ps = PreparedScene(sc, n_threads=usable_cores(), build_device=local_rank if build_on_device else -1)
+            t_prep = time.time() - t0
+            e0, d0, u0, f0 = camera_of(sc)
+            meta = {"width": width, "height": height, "eye": [float(x) for x in e0], "dir": [float(x) for x in d0],
+                    "up": [float(x) for x in u0], "fovy": float(f0), "name": sc.name, "triangles": sc.total_tris(),
+                    "instances": len(sc.instances), "textures": len(sc.textures), "materials": len(sc.materials),
+                    "scene_gen_s": round(t_gen, 2), "set_scene_host_s": round(t_prep, 2)}
+            if world > 1 or not args.no_cache or not (args.no_pmc or args.no_roofline):
+                ps.save(prepared_path + ".tmp")
+                os.replace(prepared_path + ".tmp", prepared_path)
+                with open(meta_path, "w") as f:
+                    json.dump(meta, f)
         bvh_levels = ps.levels()
-        if world > 1 or not (args.no_pmc or args.no_roofline):
-            ps.save(prepared_path)
-            with open(meta_path, "w") as f:
-                json.dump({"width": width, "height": height, "eye": [float(x) for x in eye], "dir": [float(x) for x in cdir],
-                           "up": [float(x) for x in up], "fovy": float(fovy), "name": scene.name,
-                           "triangles": scene.total_tris(), "textures": len(scene.textures)}, f)
     if dist:
         dist.barrier()
     if rank != 0:
         ps = PreparedScene(path=prepared_path)
         ps.set_samples_per_pixel(spp)
         with open(meta_path) as f:
-            m = json.load(f)
-        eye, cdir, up = (np.array(m[k], np.float32) for k in ("eye", "dir", "up"))
-        fovy = m["fovy"]
+            meta = json.load(f)
+    eye, cdir, up = (np.array(meta[k], np.float32) for k in ("eye", "dir", "up"))
+    fovy = meta["fovy"]
 
     # a dedicated (non-default) torch stream: the legacy default stream serialises against every
     # other stream of the process, which RCCL's internal streams do not like
@@ -292,18 +331,21 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
-            "data": "real" if scene.name.startswith("real:") else "synthetic",
-            "config": {"workload": f"{args.workload} {scene.name} {width}x{height}" +
-                                   ("" if scene.name.startswith("real:") else " (synthetic stand-in, SURVEY 8d)"),
-                       "spp_per_frame": spp, "triangles": scene.total_tris(), "instances": len(scene.instances),
-                       "textures": len(scene.textures), "materials": len(scene.materials),
+            "data": "real" if meta["name"].startswith("real:") else "synthetic",
+            "config": {"workload": f"{args.workload} {meta['name']} {width}x{height}" +
+                                   ("" if meta["name"].startswith("real:") else " (synthetic stand-in, SURVEY 8d)"),
+                       "spp_per_frame": spp, "triangles": meta["triangles"], "instances": meta["instances"],
+                       "textures": meta["textures"], "materials": meta["materials"],
                        "pixel_samples_per_step": width * height * spp, "rays_per_step": total_rays // args.steps,
                        "schedule": args.schedule,
                        "acceleration_structure": {0: "one BVH4 (single instance)", 1: "two-level: top-level BVH4 over instances + one BVH4 per mesh",
                                                   2: "world tree: one BVH4 in world space over per-instance triangle records"}[bvh_levels],
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
                                       (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist else ""),
-                       "scene_gen_s": round(t_gen, 2), "set_scene_host_s": round(t_prep, 2),
+                       "scene_gen_s": meta["scene_gen_s"], "set_scene_host_s": meta["set_scene_host_s"],
+                       "bvh_builder": "device linear BVH (CRT_HIP_BUILD=device)" if build_on_device else "host binned SAH",
+                       "prepared_scene_cache": "hit: the prepared arrays of an earlier run on this box (scene_gen_s / set_scene_host_s are that run's)"
+                                               if cache_hit else "miss",
                        "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},
         }
 
@@ -474,7 +516,7 @@ def main():
         from tests.parity import compare_images
         cores = usable_cores()
         tiles, ntiles = sample_tiles(width, height, spp)
-        o = OracleRenderer(scene, width, height, cores)
+        o = OracleRenderer(the_scene(), width, height, cores)
         stc = o.render_tiles(eye, cdir, up, fovy, True, tiles)
         out["cpu_baseline"] = {"value": round(stc.rays_per_second / 1e6, 3), "unit": "MRay/s", "cores": cores,
                                "kind": "port",
@@ -501,9 +543,10 @@ def main():
     if dist:
         dist.barrier()
     if rank == 0:
-        for p in (prepared_path, meta_path):
-            if os.path.exists(p):
-                os.remove(p)
+        if args.no_cache:
+            for p in (prepared_path, meta_path):
+                if os.path.exists(p):
+                    os.remove(p)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
