@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cache", action="store_true", help="do not keep / reuse the prepared scene under /dev/shm between runs")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-schedule", action="store_true", help="N = 1: do not also time the other launch schedule")
+    ap.add_argument("--no-speed-mode", action="store_true", help="N = 1: do not also time the opt-in fast-math build")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
     return ap.parse_args()
@@ -364,6 +365,16 @@ def main():
                             other_sched: {"ms_per_step": round(e2 / args.steps * 1e3, 4), "value": round(rays2 / e2 / 1e6, 2)},
                             "note": "serial: the 17 launches of a frame one after the other (headline: per-kernel spans are execution "
                                     "times); overlap: occlusion(b) next to closest-hit(b+1) on a second stream, the library's default"}
+
+    # ---- N = 1: the opt-in SPEED MODE build (fast-math, as the reference builds its own ISPC kernels: backends/embree/
+    # CMakeLists.txt:12) on the same prepared scene, in a child process; reported next to the headline, never as it ----
+    if world == 1 and rank == 0 and not args.no_speed_mode and os.path.exists(prepared_path):
+        from chameleonrt_amd import build as crt_build, pmc as pmc_mod
+        if os.path.exists(crt_build.FAST_LIB):
+            sm = pmc_mod.time_frames(prepared_path, meta_path, frames=10, env_overrides={"CRT_HIP_SPEED": "1"})
+            sm["note"] = ("fast-math build of the same sources (approximate division / sqrt / transcendentals, FMA contraction), "
+                          f"{args.schedule} schedule; NOT the build the parity tests and the headline are about")
+            out["speed_mode"] = sm
 
     # ---- N > 1: the weak-scaling figure next to the strong-scaling headline (or the other way round) ----
     if world > 1:

@@ -41,6 +41,35 @@ def build(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+# SPEED MODE: the same sources with fast-math -- approximate division / sqrt / transcendentals, FMA contraction
+# -- as the reference ships its own Embree backend (backends/embree/CMakeLists.txt:12: ispc --opt=fast-math). Opt-in
+# (CRT_HIP_SPEED=1, chameleonrt_amd/core.py); every parity statement of this repository is about the default build.
+FAST_LIB = os.path.join(HERE, "libcrt_hip_core_fast.so")
+FAST_ONLY = ["kernels.hip"]  # the frame's kernels; the host code and the BVH builders (conservative quantisation) stay IEEE
+FAST_FLAGS = ["-ffast-math", "-fno-finite-math-only", "-ffp-contract=fast", "-fgpu-approx-transcendentals", "-DCRT_SPEED_MODE=1"]
+
+
+def build_fast(force=False):
+    if not force and os.path.exists(FAST_LIB):
+        t = os.path.getmtime(FAST_LIB)
+        deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return FAST_LIB
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    base = [f for f in FLAGS if f != "-shared"]
+    precise = base + ["-DCRT_SPEED_MODE=1"]
+    fast = [f for f in base if f not in ("-ffp-contract=off", "-fno-fast-math")] + FAST_FLAGS
+    with tempfile.TemporaryDirectory() as tmp:
+        objs = []
+        for src in SOURCES:
+            obj = os.path.join(tmp, src + ".o")
+            subprocess.check_call([hipcc] + (fast if src in FAST_ONLY else precise) + ["-c", os.path.join(CSRC, src), "-o", obj])
+            objs.append(obj)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", FAST_LIB])
+    return FAST_LIB
+
+
 IO_LIB = os.path.join(HERE, "libcrt_scene_io.so")
 IO_SOURCES = ["obj_reader.cpp"]
 
@@ -57,5 +86,6 @@ def build_scene_io(force=False):
 
 if __name__ == "__main__":
     build_scene_io(force="--force" in sys.argv)
+    build_fast(force="--force" in sys.argv)
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -12,8 +12,11 @@ import numpy as np
 from .scene import SceneDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CRT_HIP_LIB selects a tuning-variant build of the same library (tools/variants.py)
-LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(_HERE, "libcrt_hip_core.so")
+# CRT_HIP_LIB selects a tuning-variant build of the same library (tools/variants.py); CRT_HIP_SPEED=1 the fast-math
+# "speed mode" build (chameleonrt_amd/build.py build_fast: what the reference's --opt=fast-math ISPC build is to its
+# kernels; NOT the build any parity statement is about)
+LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(
+    _HERE, "libcrt_hip_core_fast.so" if os.environ.get("CRT_HIP_SPEED") == "1" else "libcrt_hip_core.so")
 
 FLAG_COUNTERS = 1
 FLAG_TIMING = 2

@@ -165,9 +165,10 @@ struct crt_hip_ctx {
             (void)hipStreamDestroy(own_stream);
         }
     }
-    // bounces traced a wave at a time (packet.h): CRT_HIP_PACKET_BOUNCES, default 1 = the camera rays and their occlusion
-    // rays; 0 when the scene's tree is deeper than a wave's stack
-    int packet_bounces = 1;
+    // bounces traced a wave at a time (packet.h): CRT_HIP_PACKET_BOUNCES, default 0 -- measured on C4 with packets for the
+    // camera rays and their occlusion rays: closest-hit -0.9 ms, occlusion +1.6 ms per frame, and slower on C2 / C3
+    // (DESIGN.md section 6); forced to 0 when the scene's tree is deeper than a wave's stack
+    int packet_bounces = 0;
     bool packet_ok = true;
     LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, packet_ok ? packet_bounces : 0}; }
 };
@@ -334,6 +335,9 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
         c->n_cus = prop.multiProcessorCount;
         c->name = std::string("HIP wavefront path tracer (") + prop.name + ", " + prop.gcnArchName + ")";
+#if defined(CRT_SPEED_MODE)
+        c->name += " [speed mode: fast-math build]";
+#endif
         HIP_CHECK(hipStreamCreate(&c->own_stream));
         c->overlap = true; // CRT_HIP_OVERLAP=0: strictly serial launches
         if (const char *e = std::getenv("CRT_HIP_OVERLAP")) {

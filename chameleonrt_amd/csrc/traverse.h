@@ -60,8 +60,8 @@ template <int LDS_STACK> struct TraversalStack {
     TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
+    TV_LDS float *cold_wave; // the same array at this WAVE's first lane: an LDS-DMA load writes lane l's dword at cold_wave[k * stride + l]
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
-    TV_LDS uint32_t *junk; // 256 bytes of the block's LDS nobody reads: where prefetch_leaf()'s LDS-DMA loads land
     int sp;
     CRT_DEV void push(int32_t x)
     {
@@ -195,9 +195,10 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_ANYHIT_SORT
 #define CRT_ANYHIT_SORT 1
 #endif
-// 1: a lane starts fetching a leaf slot's line the moment the leaf becomes its next reference (prefetch_leaf below)
-#ifndef CRT_LEAF_PREFETCH
-#define CRT_LEAF_PREFETCH 1
+// 1: the first ray of a lane's next queue item is fetched into its cold LDS slots by LDS-DMA loads WHILE the lane's
+// finished ray is retired (trace_wavefront "FUSED REFILL"), instead of in a refill step of its own
+#ifndef CRT_FUSED_REFILL
+#define CRT_FUSED_REFILL 1
 #endif
 #ifndef CRT_DEFER_RETIRE
 #define CRT_DEFER_RETIRE 1
@@ -223,6 +224,8 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 // Source: struct with
 //   static constexpr bool CONST_TFAR;                          every ray of the source ends at RAY_TFAR (load's tfar is ignored)
 //   static constexpr bool MULTI_RAY;                           retire() may hand the lane a follow-up ray (uses stage / carry)
+//   static constexpr bool ASYNC_LOAD;                          load_async(i, wave_cold, stride): origin / direction of item i's first ray
+//                                                              into cold slots 0..5 of the calling lane by LDS-DMA loads (no VGPRs)
 //   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   first ray of queue item i
 //   bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const;
 //        consume a finished ray's result (h.tri < 0: miss / unoccluded; h.inst is maintained by the two-level kernels
@@ -385,23 +388,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         cur = sc.root;
     };
 
-    // LEAF PREFETCH. A leaf slot is touched by few rays, so its line usually comes from HBM (the nodes above it mostly from
-    // L2): a leaf step used to take 12 000 cycles against 3 700 for an inner-node step -- 34 % of the closest-hit kernel's wave
-    // time on C4 spent with 29 lanes waiting for memory (profiles/r03_wave_phase_profile.txt). The moment a lane KNOWS it
-    // will visit a leaf -- the reference has become its `cur` -- it starts fetching the slot's line; the lane then usually
-    // sits through a few more inner-node iterations of its wave before the leaf phase comes round, and finds the line in
-    // the L2 (or L1). gfx950 has no prefetch instruction; an LDS-DMA load (global_load_lds_dword: HBM -> LDS, no VGPR
-    // written, so nothing for a late return to clobber) of the slot's first dword into 256 bytes of LDS that nobody reads
-    // is one: one extra request per leaf visit, to the line the visit needs anyway.
-    auto prefetch_leaf = [&](int32_t ref) {
-#if CRT_LEAF_PREFETCH
-        if (ref < 0 && ref != CUR_DONE && ref != CUR_EXIT && ref != STACK_SENTINEL && !(TWO_LEVEL && !in_blas && is_instance_leaf(ref))) {
-            const LeafSlot *slot = sc.slots + ((~(uint32_t)ref) >> 3);
-            __builtin_amdgcn_global_load_lds((const TV_HBM void *)slot, (TV_LDS void *)st.junk, 4, 0, 0);
-        }
-#endif
-    };
-
     // Take the next reference off the stack (or finish). Popping the instance-exit sentinel only MARKS the lane
     // (CUR_EXIT): restoring the world-space ray and its frame (three reciprocals, a dozen multiplies, six LDS reads)
     // is done by the leaf phase, like entering an instance, so that the inner-node loop -- which most iterations
@@ -415,8 +401,38 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         if (TWO_LEVEL && cur == STACK_SENTINEL) {
             cur = CUR_EXIT;
         }
-        prefetch_leaf(cur);
     };
+
+    // up to `want` ray indices [pool_next, pool_next + take) of the wave's pool, which is topped up from the queue cursor
+    // (one atomic per CRT_POOL_CHUNK rays) when it is empty; the caller advances pool_next by what it uses
+    auto pool_take = [&](uint32_t want) -> uint32_t {
+        if (pool_next == pool_end && !exhausted) {
+            uint32_t base = 0;
+            if (tv_lane_id() == 0) {
+                base = atomicAdd(cursor, (uint32_t)CRT_POOL_CHUNK);
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n) {
+                if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
+                    atomicMin(&t_marks[MAX_PATH_DEPTH], (unsigned long long)wall_clock64());
+                }
+                exhausted = true;
+                pool_next = pool_end = 0;
+            } else {
+                pool_next = base;
+                pool_end = min(base + (uint32_t)CRT_POOL_CHUNK, n);
+            }
+        }
+        return min(want, pool_end - pool_next);
+    };
+    // FUSED REFILL (sources whose first ray can be fetched straight into the lane's cold LDS slots: Source::ASYNC_LOAD, in the
+    // kernels that keep the world-space ray there). A separate refill step stalls the whole wave for an HBM round trip
+    // -- the queue entries were written by the previous kernel and are read once -- three times per 64 rays: 12-14 % of
+    // the closest-hit kernel's wave time on C4 (profiles/r03_wave_phase_profile_quads.txt). Here a lane that retires its
+    // ray is handed its next queue index first, LDS-DMA loads (global_load_lds_dword: no VGPR involved) start fetching
+    // that ray into the lane's cold slots, and the retire path -- the hit slot's re-fetch, the instance record, the
+    // material id, the record stores: two or three dependent round trips of its own -- runs while they are in flight.
+    constexpr bool FUSED_REFILL = CRT_FUSED_REFILL && Source::ASYNC_LOAD && !Source::MULTI_RAY && (TWO_LEVEL || INST_TRIS);
 
     for (;;) {
         // ---- refill idle lanes --------------------------------------------------------------
@@ -425,24 +441,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             const uint64_t idle_mask = __ballot(idle);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
             if (n_idle >= CRT_REFILL_MIN && !exhausted) {
-                if (pool_next == pool_end) {
-                    uint32_t base = 0;
-                    if (tv_lane_id() == 0) {
-                        base = atomicAdd(cursor, (uint32_t)CRT_POOL_CHUNK);
-                    }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n) {
-                        if (COUNTERS && t_marks != nullptr && !exhausted && tv_lane_id() == 0) {
-                            atomicMin(&t_marks[MAX_PATH_DEPTH], (unsigned long long)wall_clock64());
-                        }
-                        exhausted = true;
-                        pool_next = pool_end = 0;
-                    } else {
-                        pool_next = base;
-                        pool_end = min(base + (uint32_t)CRT_POOL_CHUNK, n);
-                    }
-                }
-                const uint32_t take = min(n_idle, pool_end - pool_next);
+                const uint32_t take = pool_take(n_idle);
                 if (idle) {
                     const uint32_t rank = tv_lanes_below(idle_mask);
                     if (rank < take) {
@@ -549,7 +548,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                             st.push((int32_t)k1.w);
                         }
                         cur = (int32_t)(first == 0 ? k0.w : first == 1 ? k1.w : first == 2 ? k2.w : k3.w);
-                        prefetch_leaf(cur);
                     }
                 } else if (CRT_CHILD_ORDER == 1) {
                     // nearest child first, the other entered children stacked in slot order: no sort
@@ -571,7 +569,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                             st.push((int32_t)k0.w);
                         }
                         cur = ref_of(nearest);
-                        prefetch_leaf(cur);
                     }
                 } else if (b0 == 0xffffffffu) {
                     pop_next();
@@ -586,7 +583,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                         st.push(ref_of(c1));
                     }
                     cur = ref_of(b0);
-                    prefetch_leaf(cur);
                 }
             }
             pf_mark(1, n_inner);
@@ -719,7 +715,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 } else {
                     --st.sp; // consume the entry read above
                     cur = TWO_LEVEL && next_ref == STACK_SENTINEL ? CUR_EXIT : next_ref;
-                    prefetch_leaf(cur);
                 }
             }
         }
@@ -738,6 +733,36 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(ray < 0));
             const uint32_t n_wait = exhausted ? n_done : n_done + n_idle;
             do_retire = n_wait >= CRT_REFILL_MIN || n_done + n_idle == 64u;
+        }
+        uint64_t fused_mask = 0; // wave-uniform: the lanes handed a new ray by the fused refill, and the first index they share out
+        uint32_t fused_take = 0, fused_base = 0;
+        if constexpr (FUSED_REFILL) if (do_retire) {
+            // the lanes that will be free after this retire step: those retiring now and those idle already
+            const bool free_lane = ray < 0 || cur == CUR_DONE;
+            const uint64_t free_mask = __ballot(free_lane);
+            const uint32_t take = pool_take((uint32_t)__popcll(free_mask));
+            fused_mask = free_mask;
+            fused_take = take;
+            fused_base = pool_next;
+            const int32_t next_ray = free_lane && tv_lanes_below(free_mask) < take ? (int32_t)(pool_next + tv_lanes_below(free_mask)) : -1;
+            pool_next += take;
+            if (COUNTERS && max_ray_nodes != nullptr && ray >= 0 && cur == CUR_DONE && ray_nodes > 2000u) { // (needs the OLD world ray)
+                if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
+                    const V3 org = world_org(), dir = world_dir();
+                    worst_ray[0] = org.x;
+                    worst_ray[1] = org.y;
+                    worst_ray[2] = org.z;
+                    worst_ray[3] = dir.x;
+                    worst_ray[4] = dir.y;
+                    worst_ray[5] = dir.z;
+                    worst_ray[6] = hit.t;
+                    worst_ray[7] = (float)ray_nodes;
+                }
+                ray_nodes = 0;
+            }
+            if (next_ray >= 0) {
+                src.load_async((uint32_t)next_ray, st.cold_wave, st.stride); // -> this lane's cold slots 0..5, in flight from here on
+            }
         }
         if (do_retire && ray >= 0 && cur == CUR_DONE) {
             if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
@@ -774,6 +799,14 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 begin_ray();
             } else {
                 ray = -1;
+            }
+        }
+        if constexpr (FUSED_REFILL) if (do_retire) {
+            // (the index is worked out again from wave-uniform values rather than carried in a register across the retire path)
+            if (ray < 0 && ((fused_mask >> tv_lane_id()) & 1ull) != 0ull && tv_lanes_below(fused_mask) < fused_take) {
+                ray = (int32_t)(fused_base + tv_lanes_below(fused_mask));
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the LDS-DMA loads have landed in the cold slots
+                begin_ray();
             }
         }
         if (COUNTERS) {

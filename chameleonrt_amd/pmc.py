@@ -88,7 +88,24 @@ def measure(prepared_path, meta_path, frames=3, passes=("fetch", "write", "sq", 
     return res
 
 
-def _child(prepared_path, meta_path, frames):
+def time_frames(prepared_path, meta_path, frames=10, env_overrides=None, timeout=240):
+    """ms per frame and rays per frame of a few frames of the prepared scene rendered by a CHILD process (another build
+    of the library -- CRT_HIP_SPEED=1 -- or other environment settings than this process was started with)."""
+    env = dict(os.environ, TMPDIR="/tmp", **(env_overrides or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, "-m", "chameleonrt_amd.pmc", prepared_path, meta_path, str(frames), "--time"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return {"error": str(ex)[:300]}
+
+
+def _child(prepared_path, meta_path, frames, timed=False):
     import numpy as np
     from chameleonrt_amd.render_hip import PreparedScene, RenderHIP
     with open(meta_path) as f:
@@ -99,10 +116,16 @@ def _child(prepared_path, meta_path, frames):
     r.set_prepared_scene(ps)
     ps.close()
     e, d, u = (np.array(m[k], np.float32) for k in ("eye", "dir", "up"))
+    ms, rays = [], 0
     for f in range(frames):
-        r.render(e, d, u, m["fovy"], f == 0, False)
+        st = r.render(e, d, u, m["fovy"], f == 0, False)
+        ms.append(st.render_time_ms)
+        rays = int(st.rays)
+    if timed:  # the first two frames are warm-up
+        t = sum(ms[2:]) / max(1, len(ms) - 2)
+        print(json.dumps({"ms_per_frame": round(t, 4), "rays_per_frame": rays, "MRay_per_s": round(rays / t / 1e3, 2), "name": r.name()}))
     r.close()
 
 
 if __name__ == "__main__":
-    _child(sys.argv[1], sys.argv[2], int(sys.argv[3]))
+    _child(sys.argv[1], sys.argv[2], int(sys.argv[3]), "--time" in sys.argv)
