@@ -216,7 +216,7 @@ template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc
 
 // ---- K2 trace_closest ----------------------------------------------------------------------------
 template <int LEVELS> struct ClosestSource { // LEVELS: SceneView::two_level of the scene the kernel is built for
-    static constexpr bool CONST_TFAR = true, MULTI_RAY = false, ASYNC_LOAD = true;
+    static constexpr bool CONST_TFAR = true, MULTI_RAY = false;
     PathQueue q;
     HitBuf hits;
     const LeafSlot *slots;
@@ -227,17 +227,6 @@ template <int LEVELS> struct ClosestSource { // LEVELS: SceneView::two_level of 
         o = v3(q.o[0][i], q.o[1][i], q.o[2][i]);
         d = v3(q.d[0][i], q.d[1][i], q.d[2][i]);
         tfar = RAY_TFAR;
-    }
-    // the same six dwords straight into the calling lane's cold LDS slots 0..5 (origin, direction): global_load_lds_dword writes
-    // lane l's dword at M0 + 4 l, i.e. wave_cold[k * stride + l] -- no VGPR is written, so the loads can stay in flight while
-    // the lane does something else (traverse.h "FUSED REFILL")
-    CRT_DEV void load_async(uint32_t i, TV_LDS float *wave_cold, int stride) const
-    {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            __builtin_amdgcn_global_load_lds((const TV_HBM void *)(q.o[a] + i), (TV_LDS void *)(wave_cold + a * stride), 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((const TV_HBM void *)(q.d[a] + i), (TV_LDS void *)(wave_cold + (3 + a) * stride), 4, 0, 0);
-        }
     }
     // One 32-byte record per ray (wavefront.h HitBuf), two 16-byte stores by the retiring lane. The surface normal of
     // the reference -- normalize(hit.Ng), then normalize(transpose(world_to_object) * n), render_embree.ispc:269-270,
@@ -297,7 +286,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.cold_wave = (TV_LDS float *)&lds.cold[0][threadIdx.x & ~63u];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
@@ -321,7 +309,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
 // evaluates  illum += tp * (cA*visA + cB*visB)  in the reference's order (ispc:117,151,175,301):
 // one thread per path and stream order between kernels, so no atomics on the radiance.
 struct ShadowSource {
-    static constexpr bool CONST_TFAR = false, MULTI_RAY = true, ASYNC_LOAD = false;
+    static constexpr bool CONST_TFAR = false, MULTI_RAY = true;
     ShadowQueueA sa;
     ShadowQueueB sb;
     float4 *radiance;
@@ -383,7 +371,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.cold_wave = (TV_LDS float *)&lds.cold[0][threadIdx.x & ~63u];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
@@ -756,7 +743,7 @@ __global__ void k_assemble(const uint32_t *gathered, uint32_t slab_pixels, int w
 
 // ---- diagnostics: explicit rays through the production traversal -------------------------------
 template <bool ANY_HIT, int LEVELS> struct DiagSource {
-    static constexpr bool CONST_TFAR = false, MULTI_RAY = false, ASYNC_LOAD = false;
+    static constexpr bool CONST_TFAR = false, MULTI_RAY = false;
     SceneView sc;
     const float *org, *dir, *tmax;
     float *out_t, *out_u, *out_v;
@@ -799,7 +786,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.cold_wave = (TV_LDS float *)&lds.cold[0][threadIdx.x & ~63u];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;

@@ -20,10 +20,11 @@ namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
 // vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 16 for the single-level kernels (22 KB per block), 16 for the two-level ones,
+// budget of 6 blocks per CU allows: 19 for the single-level kernels (26 KB per block; 16 -> 19: C4F -2.2 %, C3 -2 % frame time),
+// 16 for the two-level ones,
 // which also keep 9 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 16
+#define CRT_LDS_STACK 19
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
 #define CRT_LDS_STACK_TWO_LEVEL 16
@@ -60,7 +61,6 @@ template <int LDS_STACK> struct TraversalStack {
     TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
-    TV_LDS float *cold_wave; // the same array at this WAVE's first lane: an LDS-DMA load writes lane l's dword at cold_wave[k * stride + l]
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
     int sp;
     CRT_DEV void push(int32_t x)
@@ -195,11 +195,6 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_ANYHIT_SORT
 #define CRT_ANYHIT_SORT 1
 #endif
-// 1: the first ray of a lane's next queue item is fetched into its cold LDS slots by LDS-DMA loads WHILE the lane's
-// finished ray is retired (trace_wavefront "FUSED REFILL"), instead of in a refill step of its own
-#ifndef CRT_FUSED_REFILL
-#define CRT_FUSED_REFILL 1
-#endif
 #ifndef CRT_DEFER_RETIRE
 #define CRT_DEFER_RETIRE 1
 #endif
@@ -224,8 +219,6 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 // Source: struct with
 //   static constexpr bool CONST_TFAR;                          every ray of the source ends at RAY_TFAR (load's tfar is ignored)
 //   static constexpr bool MULTI_RAY;                           retire() may hand the lane a follow-up ray (uses stage / carry)
-//   static constexpr bool ASYNC_LOAD;                          load_async(i, wave_cold, stride): origin / direction of item i's first ray
-//                                                              into cold slots 0..5 of the calling lane by LDS-DMA loads (no VGPRs)
 //   void load(uint32_t i, V3 &o, V3 &d, float &tfar) const;   first ray of queue item i
 //   bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const;
 //        consume a finished ray's result (h.tri < 0: miss / unoccluded; h.inst is maintained by the two-level kernels
@@ -425,15 +418,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         }
         return min(want, pool_end - pool_next);
     };
-    // FUSED REFILL (sources whose first ray can be fetched straight into the lane's cold LDS slots: Source::ASYNC_LOAD, in the
-    // kernels that keep the world-space ray there). A separate refill step stalls the whole wave for an HBM round trip
-    // -- the queue entries were written by the previous kernel and are read once -- three times per 64 rays: 12-14 % of
-    // the closest-hit kernel's wave time on C4 (profiles/r03_wave_phase_profile_quads.txt). Here a lane that retires its
-    // ray is handed its next queue index first, LDS-DMA loads (global_load_lds_dword: no VGPR involved) start fetching
-    // that ray into the lane's cold slots, and the retire path -- the hit slot's re-fetch, the instance record, the
-    // material id, the record stores: two or three dependent round trips of its own -- runs while they are in flight.
-    constexpr bool FUSED_REFILL = CRT_FUSED_REFILL && Source::ASYNC_LOAD && !Source::MULTI_RAY && (TWO_LEVEL || INST_TRIS);
-
     for (;;) {
         // ---- refill idle lanes --------------------------------------------------------------
         {
@@ -734,36 +718,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             const uint32_t n_wait = exhausted ? n_done : n_done + n_idle;
             do_retire = n_wait >= CRT_REFILL_MIN || n_done + n_idle == 64u;
         }
-        uint64_t fused_mask = 0; // wave-uniform: the lanes handed a new ray by the fused refill, and the first index they share out
-        uint32_t fused_take = 0, fused_base = 0;
-        if constexpr (FUSED_REFILL) if (do_retire) {
-            // the lanes that will be free after this retire step: those retiring now and those idle already
-            const bool free_lane = ray < 0 || cur == CUR_DONE;
-            const uint64_t free_mask = __ballot(free_lane);
-            const uint32_t take = pool_take((uint32_t)__popcll(free_mask));
-            fused_mask = free_mask;
-            fused_take = take;
-            fused_base = pool_next;
-            const int32_t next_ray = free_lane && tv_lanes_below(free_mask) < take ? (int32_t)(pool_next + tv_lanes_below(free_mask)) : -1;
-            pool_next += take;
-            if (COUNTERS && max_ray_nodes != nullptr && ray >= 0 && cur == CUR_DONE && ray_nodes > 2000u) { // (needs the OLD world ray)
-                if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
-                    const V3 org = world_org(), dir = world_dir();
-                    worst_ray[0] = org.x;
-                    worst_ray[1] = org.y;
-                    worst_ray[2] = org.z;
-                    worst_ray[3] = dir.x;
-                    worst_ray[4] = dir.y;
-                    worst_ray[5] = dir.z;
-                    worst_ray[6] = hit.t;
-                    worst_ray[7] = (float)ray_nodes;
-                }
-                ray_nodes = 0;
-            }
-            if (next_ray >= 0) {
-                src.load_async((uint32_t)next_ray, st.cold_wave, st.stride); // -> this lane's cold slots 0..5, in flight from here on
-            }
-        }
         if (do_retire && ray >= 0 && cur == CUR_DONE) {
             if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
                 if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
@@ -799,14 +753,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 begin_ray();
             } else {
                 ray = -1;
-            }
-        }
-        if constexpr (FUSED_REFILL) if (do_retire) {
-            // (the index is worked out again from wave-uniform values rather than carried in a register across the retire path)
-            if (ray < 0 && ((fused_mask >> tv_lane_id()) & 1ull) != 0ull && tv_lanes_below(fused_mask) < fused_take) {
-                ray = (int32_t)(fused_base + tv_lanes_below(fused_mask));
-                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the LDS-DMA loads have landed in the cold slots
-                begin_ray();
             }
         }
         if (COUNTERS) {
