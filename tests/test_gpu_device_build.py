@@ -121,12 +121,16 @@ def test_world_tree_built_on_the_device(oracle, hip_lib, monkeypatch):
     b_sah = sah.bvh()
     assert b_dev["nodes"].shape == b_ref["nodes"].shape and b_dev["stack_need"] == b_ref["stack_need"]
     assert np.array_equal(b_dev["tris"], b_ref["tris"]), "leaf slots: device build vs its serial twin"
-    assert np.array_equal(b_dev["nodes"], b_ref["nodes"]), "quantised nodes: device build vs its serial twin"
+    # (the nodes of one level are allocated with an atomic on the device, so their ORDER inside the level is not the serial
+    # build's: the shape is compared through the walk below, like for a mesh's BLAS)
     o = oracle.OracleScene(sc)
     org, dirs = probe_rays(sc, 30000, seed=43)
     c = o.trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
     w_dev = oracle.walk_product_bvh(b_dev, org, dirs, 0.0, 1e20, closest=True)
     w_sah = oracle.walk_product_bvh(b_sah, org, dirs, 0.0, 1e20, closest=True)
+    w_ref = oracle.walk_product_bvh(b_ref, org, dirs, 0.0, 1e20, closest=True)
+    assert (w_dev["nodes"], w_dev["slots"], w_dev["tris"]) == (w_ref["nodes"], w_ref["slots"], w_ref["tris"]), \
+        "device tree differs in shape from the serial build"
     for k in ("inst", "geom", "prim"):
         assert np.array_equal(w_dev[k], c[k]), k
     hit = c["inst"] >= 0
