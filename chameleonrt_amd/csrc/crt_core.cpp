@@ -498,7 +498,9 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     sv.root = ps.root;
     sv.two_level = ps.two_level;
     sv.world_inst = ps.world_inst;
-    sv.n_top_nodes = ps.n_top;
+    // (the kernels stage at most this many of the BFS-ordered top levels in LDS and test `cur < root + n_top_nodes`
+    // for "is it there": a prepared scene that claims more is clamped, not trusted)
+    sv.n_top_nodes = std::min<uint32_t>(ps.n_top, ps.two_level == 1u ? (uint32_t)CRT_MAX_TOP_NODES_TWO_LEVEL : (uint32_t)CRT_MAX_TOP_NODES);
     ctx->has_scene = true;
 }
 

@@ -245,6 +245,8 @@ struct ScenePreparer {
     bool host_lbvh = false;  // CRT_BVH_BUILDER=lbvh: the device builder's algorithm, run serially on the host
     bool world_tree = false; // several instances, one tree in world space (crt_types.h LEVELS_WORLD_TREE)
     bool two_level = false;  // several instances, a top-level tree over them
+    bool empty_scene = false; // no instance has a triangle: one node without children, every ray misses (like the reference's empty Embree scene)
+    std::vector<uint8_t> mesh_empty; // two-level: meshes without triangles have no BLAS, their instances are not in the top-level tree
     uint64_t instanced_tris = 0;
     // per mesh: its BLAS as built (host: full-precision nodes; device: quantised already), and where it ends up
     std::vector<BuiltBvh> built;
@@ -287,12 +289,17 @@ struct ScenePreparer {
         choose_structure();
         pair_all_geometries();
         phase("triangle pairs");
-        build_mesh_trees();
-        phase("leaf-order triangles");
-        make_instance_records();
-        build_world_tree();
-        build_top_level_tree();
-        append_mesh_trees();
+        if (empty_scene) {
+            make_instance_records();
+            make_empty_tree();
+        } else {
+            build_mesh_trees();
+            phase("leaf-order triangles");
+            make_instance_records();
+            build_world_tree();
+            build_top_level_tree();
+            append_mesh_trees();
+        }
         finish_references();
         phase("TLAS + quantisation");
         linearise_textures();
@@ -319,8 +326,10 @@ struct ScenePreparer {
                 instanced_tris += s->geometries[md.first_geometry + k].n_triangles;
             }
         }
-        world_tree = s->n_instances > 1 && world_tree_wanted(instanced_tris);
-        two_level = s->n_instances > 1 && !world_tree;
+        empty_scene = instanced_tris == 0; // (meshes nobody instances do not count: they are never seen)
+        world_tree = !empty_scene && s->n_instances > 1 && world_tree_wanted(instanced_tris);
+        two_level = !empty_scene && s->n_instances > 1 && !world_tree;
+        mesh_empty.assign(s->n_meshes, 0);
         blas_frame.resize(s->n_meshes);
         blas_root.resize(s->n_meshes);
         blas_bounds.resize(s->n_meshes);
@@ -495,8 +504,12 @@ struct ScenePreparer {
                     }
                 });
             }
-            if (recs.empty()) {
-                throw std::runtime_error("mesh without triangles");
+            if (recs.empty()) { // a mesh without triangles: nothing to build, nothing to hit (its instances stay out of the top-level tree)
+                mesh_empty[m] = 1;
+                blas_root[m] = (int32_t)slots.size();
+                blas_frame[m] = make_frame(Aabb{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
+                blas_bounds[m] = Aabb{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+                continue;
             }
             built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
@@ -557,8 +570,8 @@ struct ScenePreparer {
                 material_ids.push_back(id | (textured ? MATERIAL_TEXTURED : 0u));
             }
             insts[i] = r;
-            if (world_tree) {
-                continue; // no instance boxes: the tree is built over the triangles (below)
+            if (world_tree || empty_scene) {
+                continue; // no instance boxes: the tree is built over the triangles (below), or there is nothing to bound
             }
             const Aabb &mb = blas_bounds[pm.mesh_id];
             Aabb wb;
@@ -760,9 +773,6 @@ struct ScenePreparer {
                     }
                 });
             }
-            if (recs.empty()) {
-                throw std::runtime_error("scene without triangles");
-            }
             BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
                                       : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
             boxes = std::vector<Aabb>();
@@ -886,7 +896,7 @@ struct ScenePreparer {
                 }
             }
             for (uint32_t i = 0; i < s->n_instances; ++i) {
-                if ((int32_t)i != world_inst) {
+                if ((int32_t)i != world_inst && !mesh_empty[s->parameterized_meshes[s->instances[i].parameterized_mesh_id].mesh_id]) {
                     items.push_back(inst_boxes[i]);
                     item_ref.push_back(instance_leaf_ref(i));
                     item_is_cut.push_back(0);
@@ -957,6 +967,30 @@ struct ScenePreparer {
         }
     }
 
+    // A scene none of whose instances has a triangle: one node whose four slots are unused (inverted boxes, which the slab test
+    // rejects by itself), traversed as a single-level tree -- every ray misses, every occlusion ray is unoccluded, the frame
+    // is the miss shader's checkerboard, as from the reference's empty Embree scene.
+    void make_empty_tree()
+    {
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            nd.c[k] = EMPTY_CHILD;
+        }
+        root_frame = make_frame(Aabb{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
+        QNode q = quantise(nd, root_frame);
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            q.child[k].ref = 0; // (never followed: no ray enters an inverted box)
+        }
+        ps->nodes.assign(1, q);
+        root = 0;
+        n_top = 1;
+        blas_depth = 1;
+        for (InstanceRec &r : ps->insts) {
+            r.frame = root_frame;
+        }
+    }
+
     // the meshes' trees behind the top-level nodes: references local to a mesh become global
     void append_mesh_trees()
     {
@@ -1008,13 +1042,13 @@ struct ScenePreparer {
             throw std::runtime_error("too many leaf slots for the 28-bit leaf reference");
         }
         for (InstanceRec &r : insts) {
-            r.blas_root = world_tree ? 0 : blas_root[r.blas_root];
+            r.blas_root = world_tree || empty_scene || mesh_empty[(size_t)r.blas_root] ? 0 : blas_root[r.blas_root];
         }
         if (world_inst >= 0) {
             insts[(size_t)world_inst].blas_root = 0; // never entered: its subtrees hang in the top-level tree (node 0 = its root)
         }
         ps->world_inst = world_inst;
-        if (!two_level && !world_tree) {
+        if (!two_level && !world_tree && !empty_scene) {
             const uint32_t mesh0 = s->parameterized_meshes[s->instances[0].parameterized_mesh_id].mesh_id;
             root = insts[0].blas_root;
             n_top = blas_top[mesh0];
@@ -1319,32 +1353,85 @@ int crt_hip_save_prepared_scene(const crt_hip_prepared_scene *ps, const char *pa
 
 crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
 {
+    // Nothing may crash or throw across the C ABI: a truncated or foreign file is refused with a message. The counts of
+    // the header are checked against the file's size BEFORE anything is allocated from them, and against each other.
     FILE *f = path ? std::fopen(path, "rb") : nullptr;
     if (!f) {
         set_global_error(std::string("cannot read ") + (path ? path : "(null)"));
         return nullptr;
     }
-    std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
-    PrepHeader h{};
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == PREP_MAGIC && h.abi == CRT_HIP_ABI_VERSION;
-    ok = ok && prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->slots, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * 2 * h.n_tris) &&
-         prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
-         prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
-    std::fclose(f);
-    if (!ok) {
-        set_global_error(std::string("not a prepared scene of this build: ") + path);
+    auto refuse = [&](const char *why) -> crt_hip_prepared_scene * {
+        std::fclose(f);
+        set_global_error(std::string("not a prepared scene of this build (") + why + "): " + path);
+        return nullptr;
+    };
+    try {
+        std::unique_ptr<crt_hip_prepared_scene> ps(new crt_hip_prepared_scene);
+        PrepHeader h{};
+        if (std::fread(&h, sizeof(h), 1, f) != 1 || h.magic != PREP_MAGIC || h.abi != CRT_HIP_ABI_VERSION) {
+            return refuse("header");
+        }
+        std::fseek(f, 0, SEEK_END);
+        const uint64_t file_size = (uint64_t)std::ftell(f);
+        std::fseek(f, (long)sizeof(h), SEEK_SET);
+        const uint64_t limit = file_size; // no array can hold more elements than the file has bytes
+        for (uint64_t c : {h.n_nodes, h.n_tris, h.n_insts, h.n_matids, h.n_materials, h.n_lights_f, h.n_tex, h.n_texels}) {
+            if (c > limit) {
+                return refuse("counts");
+            }
+        }
+        const uint64_t expect = sizeof(h) + h.n_nodes * sizeof(QNode) + h.n_tris * sizeof(LeafSlot) + h.n_tris * 2 * TRI_UV_STRIDE * sizeof(float) +
+                                h.n_insts * sizeof(InstanceRec) + h.n_matids * 4 + h.n_materials * 4 + h.n_lights_f * 4 +
+                                h.n_tex * sizeof(TexRec) + h.n_texels;
+        if (expect != file_size) {
+            return refuse("size");
+        }
+        if (h.n_insts != h.n_instances || h.n_instances == 0 || h.two_level > LEVELS_WORLD_TREE || h.n_nodes == 0 || h.n_tris == 0 ||
+            h.root < 0 || (uint64_t)h.root >= h.n_nodes || (uint64_t)h.root + h.n_top > h.n_nodes || h.world_inst < -1 ||
+            (h.world_inst >= 0 && (uint32_t)h.world_inst >= h.n_instances) || h.n_lights == 0 || h.n_lights_f != 20ull * h.n_lights ||
+            h.n_materials == 0 || h.n_materials % 16 != 0 || h.spp == 0 || h.n_tris >= (1ull << 28)) {
+            return refuse("fields");
+        }
+        bool ok = prep_get(f, ps->nodes, h.n_nodes) && prep_get(f, ps->slots, h.n_tris) && prep_get(f, ps->tri_uvs, (uint64_t)TRI_UV_STRIDE * 2 * h.n_tris) &&
+                  prep_get(f, ps->insts, h.n_insts) && prep_get(f, ps->material_ids, h.n_matids) && prep_get(f, ps->materials, h.n_materials) &&
+                  prep_get(f, ps->lights, h.n_lights_f) && prep_get(f, ps->tex, h.n_tex) && prep_get(f, ps->texels, h.n_texels);
+        if (!ok) {
+            return refuse("short read");
+        }
+        // what the kernels index with: material ids, texture extents
+        const uint64_t n_mat = h.n_materials / 16;
+        for (uint32_t id : ps->material_ids) {
+            if ((id & ~MATERIAL_TEXTURED) >= n_mat) {
+                return refuse("material id");
+            }
+        }
+        for (const TexRec &t : ps->tex) {
+            if (t.width <= 0 || t.height <= 0 || t.channels < 1 || t.channels > 4 ||
+                (uint64_t)t.offset16 * 16 + tex_tiled_texels(t.width, t.height) * (uint64_t)t.channels > h.n_texels) {
+                return refuse("texture");
+            }
+        }
+        for (const InstanceRec &r : ps->insts) {
+            if (r.blas_root < 0 || (uint64_t)r.blas_root >= h.n_nodes || (uint64_t)r.mat_base >= h.n_matids) {
+                return refuse("instance");
+            }
+        }
+        std::fclose(f);
+        ps->root_frame = h.root_frame;
+        ps->root = h.root;
+        ps->two_level = h.two_level;
+        ps->n_top = h.n_top;
+        ps->n_lights = h.n_lights;
+        ps->n_instances = h.n_instances;
+        ps->spp = h.spp;
+        ps->stack_need = h.stack_need;
+        ps->world_inst = h.world_inst;
+        return ps.release();
+    } catch (const std::exception &e) { // bad_alloc and friends
+        std::fclose(f);
+        set_global_error(std::string("load_prepared_scene: ") + e.what());
         return nullptr;
     }
-    ps->root_frame = h.root_frame;
-    ps->root = h.root;
-    ps->two_level = h.two_level;
-    ps->n_top = h.n_top;
-    ps->n_lights = h.n_lights;
-    ps->n_instances = h.n_instances;
-    ps->spp = h.spp;
-    ps->stack_need = h.stack_need;
-    ps->world_inst = h.world_inst;
-    return ps.release();
 }
 
 } // extern "C"

@@ -311,10 +311,29 @@ def test_save_load_round_trip(prepared, tmp_path):
     for k in ("root", "n_top_nodes", "stack_need", "n_instances", "two_level", "world_inst"):
         assert bvh[k] == b2[k], k
     back.close()
-    with open(path, "r+b") as f:  # a damaged header must be refused, not crash
-        f.write(b"\0" * 8)
-    with pytest.raises(core.CoreError):
-        PreparedScene(path=path)
+    # damaged files are refused with a message, never a crash or an exception across the C ABI (round-2 advisor finding):
+    # a truncated file, a header whose counts promise more than the file holds, ids that point outside the arrays
+    good = open(path, "rb").read()
+
+    def refused(data, what):
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(core.CoreError, match="prepared scene"):
+            PreparedScene(path=path)
+
+    refused(b"\0" * 8 + good[8:], "magic")
+    refused(good[:len(good) // 2], "truncated")
+    refused(good + b"\0" * 64, "trailing bytes")
+    huge = bytearray(good)
+    huge[16:24] = (2 ** 62).to_bytes(8, "little")  # n_nodes
+    refused(bytes(huge), "absurd count")
+    bad_root = bytearray(good)
+    off_root = 16 + 8 * 8 + 24  # magic, abi, eight counts, the root frame
+    bad_root[off_root:off_root + 4] = (2 ** 30).to_bytes(4, "little")
+    refused(bytes(bad_root), "root outside the node array")
+    with open(path, "wb") as f:
+        f.write(good)
+    PreparedScene(path=path).close()
 
 
 def test_malformed_scenes_are_refused_not_crashed():
