@@ -144,8 +144,6 @@ struct crt_hip_ctx {
     ShadowQueueA sa{};
     ShadowQueueB sb{};
     float4 *radiance = nullptr;
-    uint32_t *deferred = nullptr; // queue indices of the hits k_shade's first launch leaves to its second (kernels.hip k_shade MODE)
-    bool shade_split = true;      // CRT_HIP_SHADE_SPLIT=0: one launch with the full BSDF (rounds 1-2)
     PassCounters *h_pc = nullptr; // pinned, one per pass
     uint32_t h_pc_slots = 0;
     std::vector<hipEvent_t> events;
@@ -172,7 +170,7 @@ struct crt_hip_ctx {
     // (DESIGN.md section 6); forced to 0 when the scene's tree is deeper than a wave's stack
     int packet_bounces = 0;
     bool packet_ok = true;
-    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, shade_split, packet_ok ? packet_bounces : 0}; }
+    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, packet_ok ? packet_bounces : 0}; }
 };
 
 namespace {
@@ -225,7 +223,7 @@ void setup_queues(crt_hip_ctx *c)
         throw std::runtime_error("samples_per_pixel too large: 64 pixels x spp paths must fit one pass of 2^27 paths");
     }
     c->capacity = cap;
-    const size_t n_fields = 2 * 11 + 8 + 12 + 18 + 4 + 1; // PathQueue x 2, HitBuf records, ShadowQueueA, ShadowQueueB, radiance, deferred hits
+    const size_t n_fields = 2 * 11 + 8 + 12 + 18 + 4; // PathQueue x 2, HitBuf records, ShadowQueueA, ShadowQueueB, radiance
     c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
     uint32_t *base = c->d_queue_mem.as<uint32_t>();
     size_t k = 0;
@@ -279,8 +277,6 @@ void setup_queues(crt_hip_ctx *c)
     c->sb.path = u32();
     c->sb.reserved = i32();
     c->radiance = reinterpret_cast<float4 *>(base + k * cap);
-    k += 4;
-    c->deferred = base + k * cap;
     c->d_pc.alloc(sizeof(PassCounters));
     const uint64_t total_paths = total_slots * c->spp;
     const uint32_t n_pass = (uint32_t)((total_paths + cap - 1) / cap);
@@ -351,9 +347,6 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
             HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        if (const char *e = std::getenv("CRT_HIP_SHADE_SPLIT")) {
-            c->shade_split = std::atoi(e) != 0;
         }
         if (const char *e = std::getenv("CRT_HIP_PACKET_BOUNCES")) {
             c->packet_bounces = std::max(0, std::min(std::atoi(e), (int)MAX_PATH_DEPTH));
@@ -776,7 +769,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                 }
                 mark(2, ctx->stream, b);
                 launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
-                             ctx->radiance, d_pc, b, ctx->deferred);
+                             ctx->radiance, d_pc, b);
                 mark_end(ctx->stream);
                 if (overlap) {
                     // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the main stream } -> shade(b+1)

@@ -24,7 +24,6 @@ struct LaunchCfg {
     hipStream_t stream;
     int n_cus;      // compute units of the device (grid sizing)
     bool counters;  // instrumented traversal (CRT_HIP_FLAG_COUNTERS)
-    bool shade_split = true; // k_shade as two launches: common materials without scratch, then the deferred glass / anisotropic hits
     int packet_bounces = 0; // path-loop iterations b < packet_bounces trace their rays a wave at a time (packet.h): coherent by construction
 };
 
@@ -41,10 +40,8 @@ void launch_raygen(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *t
 void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q, HitBuf hits,
                           PassCounters *pc, int bounce);
 // K3: hit shading: material unpack, NEE set-up, BSDF sampling, Russian roulette, compaction.
-// cfg.shade_split: two launches -- the hits on common materials with a kernel that has neither the transmission nor the
-// anisotropic lobe (no scratch), then the deferred rest (queue indices in `deferred`, capacity = the queue's) with the full one.
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
-                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce, uint32_t *deferred);
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce);
 // K4: any-hit traversal of the NEE occlusion rays (light sample, then the rare BSDF-sample ray of
 // the same hit, by the same lane).
 void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,

@@ -53,9 +53,8 @@ CRT_DEV uint32_t lanes_below(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Compacting append over the lanes that CALL it (the ballot sees the active lanes only, and the leader whose atomic
-// reserves the slots is one of them, so it also works inside a divergent branch). Lanes with pred get consecutive
-// slots; one atomic per wave. Returns the slot (undefined if !pred).
+// Compacting append: every lane of the wave must call this (wave-uniform control flow). Lanes
+// with pred get consecutive slots; one atomic per wave. Returns the slot (undefined if !pred).
 CRT_DEV uint32_t wave_append(uint32_t *counter, bool pred)
 {
     const uint64_t mask = __ballot(pred);
@@ -470,20 +469,9 @@ CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &
     __syncthreads();
 }
 
-// MODE 0: every item of the queue, every lobe of the BSDF (the kernel of rounds 1-2).
-// MODE 1 ("common materials"): the same, except that a hit whose material has specular_transmission != 0 or anisotropy != 0
-//        -- known once the material is unpacked, before the path's RNG is touched -- is not shaded here: its queue index
-//        goes to the `deferred` list, and for every other hit the two parameters are the LITERAL 0 they hold, so the
-//        transmission lobe, the anisotropic microfacet lobe and their samplers are not in this kernel at all. That is what
-//        takes it from 128 VGPRs + 60 bytes of scratch per lane to 128 VGPRs and none -- and scratch is what k_shade pays
-//        most for (profiles/r03_shade_occupancy_ab.txt: +136 B of scratch: +37 % kernel time).
-// MODE 2: the deferred items (indices from the list), with the full BSDF: MODE 0's code on the few hits MODE 1 left.
-// Same expressions per hit in every mode (x * (1 - 0) and sqrt(1 - 0 * 0.9) are exact), so frames are bit-identical with the
-// split on or off (tests/test_gpu_edge_cases.py); only the order of the entries in the next queues changes.
-template <int MODE>
 __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
-                                                       PassCounters *pc, int bounce, uint32_t *deferred)
+                                                       PassCounters *pc, int bounce)
 {
     __shared__ ShadeStage stage;
     if (threadIdx.x == 0) {
@@ -491,11 +479,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         stage.n_a = 0;
     }
     __syncthreads();
-    const uint32_t n = MODE == 2 ? pc->n_deferred[bounce] : pc->n_queue[bounce];
+    const uint32_t n = pc->n_queue[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
-        const bool valid = base + threadIdx.x < n;
-        const uint32_t i = MODE == 2 ? (valid ? deferred[base + threadIdx.x] : 0u) : base + threadIdx.x;
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
         // Phase 1 (per lane): hit -> surface, next-event estimation (sample_direct_light, ispc:105-181).
         // Its outputs are staged immediately (phase 2) so their registers are free again before the
         // BSDF is sampled for the continuation ray (phase 3).
@@ -545,80 +533,66 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                     uv = (1.f - bu - bv) * v2(ab.x, ab.y) + bu * v2(ab.z, ab.w) + bv * v2(cz.x, cz.y);
                 }
                 unpack_material(sc, mat, sc.materials + 16 * (size_t)mat_id, uv);
-                if (MODE == 1) {
-                    // (ballot + one atomic per wave over the lanes that are in this branch; the deferred hits are a scene's
-                    // glass and brushed metal: 12 % of the hits on C4, none on C2 / C3)
-                    const bool defer = mat.specular_transmission != 0.f || mat.anisotropy != 0.f;
-                    const uint32_t slot_d = wave_append(&pc->n_deferred[bounce], defer);
-                    if (defer) {
-                        deferred[slot_d] = i;
-                        is_hit = false; // shaded by the MODE 2 launch of this bounce
-                    }
-                    mat.specular_transmission = 0.f; // literally: the lobes these two switch on are compiled out
-                    mat.anisotropy = 0.f;
+                if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
+                    normal = -normal;
                 }
-                if (MODE != 1 || is_hit) {
-                    if (mat.specular_transmission == 0.f && dot3(w_o, normal) < 0.f) { // ispc:297-299
-                        normal = -normal;
-                    }
-                    V3 v_x, v_y;
-                    ortho_basis(v_x, v_y, normal);
+                V3 v_x, v_y;
+                ortho_basis(v_x, v_y, normal);
 
-                    // -- sample_direct_light, ispc:105-181 --
-                    uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
-                    light_id = min(light_id, sc.n_lights - 1u);
-                    // every OBJ / glTF scene has exactly one light (scene.cpp:218-227, 406-414): its 20 floats then sit at a
-                    // wave-uniform address and are fetched once per wave by the scalar unit instead of 5 vector requests per lane
-                    const QuadLight light = sc.n_lights == 1u ? load_light(sc.lights) : load_light(sc.lights + 20 * (size_t)light_id);
-                    {
-                        V2 ls;
-                        ls.x = rng_nextf(rng);
-                        ls.y = rng_nextf(rng);
-                        const V3 light_pos = light_sample_position(light, ls);
-                        light_dir = light_pos - hit_p;
-                        light_dist = len3(light_dir);
-                        light_dir = unit(light_dir);
-                        const float l_pdf = light_pdf(light, light_pos, light_dir);
-                        const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
-                        if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
-                            const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
-                            const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
-                            c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
-                        }
+                // -- sample_direct_light, ispc:105-181 --
+                uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
+                light_id = min(light_id, sc.n_lights - 1u);
+                // every OBJ / glTF scene has exactly one light (scene.cpp:218-227, 406-414): its 20 floats then sit at a
+                // wave-uniform address and are fetched once per wave by the scalar unit instead of 5 vector requests per lane
+                const QuadLight light = sc.n_lights == 1u ? load_light(sc.lights) : load_light(sc.lights + 20 * (size_t)light_id);
+                {
+                    V2 ls;
+                    ls.x = rng_nextf(rng);
+                    ls.y = rng_nextf(rng);
+                    const V3 light_pos = light_sample_position(light, ls);
+                    light_dir = light_pos - hit_p;
+                    light_dist = len3(light_dir);
+                    light_dir = unit(light_dir);
+                    const float l_pdf = light_pdf(light, light_pos, light_dir);
+                    const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
+                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
+                        const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
+                        const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
+                        c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
                     }
-                    {
-                        // ispc:156-179. The reference evaluates the BSDF first and tests the light quad
-                        // second; the quad test is the cheap and rarely-true one, so it goes first here
-                        // (pure functions: same value, ~1/3 of the shading ALU work saved).
-                        V3 light_pos;
-                        if (disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i_b) &&
-                            light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
-                            const float b_pdf = disney_pdf(mat, normal, w_o, w_i_b, v_x, v_y);
-                            const V3 bsdf = disney_eval(mat, normal, w_o, w_i_b, v_x, v_y);
-                            if (!is_black(bsdf) && b_pdf >= RAY_EPS) {
-                                const float l_pdf = light_pdf(light, light_pos, w_i_b);
-                                if (l_pdf >= RAY_EPS) {
-                                    const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
-                                    c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
-                                    has_b = true;
-                                }
+                }
+                {
+                    // ispc:156-179. The reference evaluates the BSDF first and tests the light quad
+                    // second; the quad test is the cheap and rarely-true one, so it goes first here
+                    // (pure functions: same value, ~1/3 of the shading ALU work saved).
+                    V3 light_pos;
+                    if (disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i_b) &&
+                        light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
+                        const float b_pdf = disney_pdf(mat, normal, w_o, w_i_b, v_x, v_y);
+                        const V3 bsdf = disney_eval(mat, normal, w_o, w_i_b, v_x, v_y);
+                        if (!is_black(bsdf) && b_pdf >= RAY_EPS) {
+                            const float l_pdf = light_pdf(light, light_pos, w_i_b);
+                            if (l_pdf >= RAY_EPS) {
+                                const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
+                                c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
+                                has_b = true;
                             }
                         }
                     }
-                    n_rays += has_b ? 2u : 1u; // the occlusion rays (ispc:145-147, 171-173)
-                    // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
-                    // non-finite throughput (the reference's glass pdfs can be negative or overflow)
-                    // turns the pixel into NaN there, so it must here too. For a finite throughput the
-                    // term is a zero whose addition changes no bit of L (L is never -0), so only the
-                    // non-finite case touches the radiance here.
-                    const V3 poison = tp_in * 0.f;
-                    if (!(poison.x == 0.f && poison.y == 0.f && poison.z == 0.f)) {
-                        float4 L = radiance[path];
-                        L.x = L.x + poison.x;
-                        L.y = L.y + poison.y;
-                        L.z = L.z + poison.z;
-                        radiance[path] = L;
-                    }
+                }
+                n_rays += has_b ? 2u : 1u; // the occlusion rays (ispc:145-147, 171-173)
+                // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
+                // non-finite throughput (the reference's glass pdfs can be negative or overflow)
+                // turns the pixel into NaN there, so it must here too. For a finite throughput the
+                // term is a zero whose addition changes no bit of L (L is never -0), so only the
+                // non-finite case touches the radiance here.
+                const V3 poison = tp_in * 0.f;
+                if (!(poison.x == 0.f && poison.y == 0.f && poison.z == 0.f)) {
+                    float4 L = radiance[path];
+                    L.x = L.x + poison.x;
+                    L.y = L.y + poison.y;
+                    L.z = L.z + poison.z;
+                    radiance[path] = L;
                 }
             }
         }
@@ -1015,15 +989,10 @@ void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA
 }
 
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
-                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce, uint32_t *deferred)
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce)
 {
-    if (cfg.shade_split && deferred != nullptr) {
-        // the common materials without scratch, then the few hits on glass / anisotropic metal with the full BSDF
-        k_shade<1><<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce, deferred);
-        k_shade<2><<<persistent_grid(cfg, 2), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce, deferred);
-        return;
-    }
-    k_shade<0><<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce, deferred);
+    k_shade<<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc,
+                                                                     bounce);
 }
 
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,

@@ -69,7 +69,6 @@ struct PassCounters {
     uint32_t n_queue[MAX_PATH_DEPTH + 1]; // closest-hit rays entering bounce b
     uint32_t n_shadow_a[MAX_PATH_DEPTH];
     uint32_t n_shadow_b[MAX_PATH_DEPTH];
-    uint32_t n_deferred[MAX_PATH_DEPTH]; // hits k_shade's common-material launch left to the full-BSDF launch of the same bounce
     uint32_t cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
     uint32_t cur_shadow_a[MAX_PATH_DEPTH];
     uint32_t cur_shadow_b[MAX_PATH_DEPTH];

@@ -152,30 +152,3 @@ def test_tile_buffer_alternates_with_a_moving_camera(hip_lib):
     # and each buffer holds the frame that was rendered into it last (the four cameras give four different images)
     assert not np.array_equal(images[0], images[1]) and not np.array_equal(images[1], images[2])
     r.close()
-
-
-@pytest.mark.parametrize("name", ["grove", "sanmiguel_small"])
-def test_shade_split_is_bit_identical(name, hip_lib, monkeypatch):
-    """k_shade as two launches per bounce (the default: hits on common materials with a kernel that has neither the
-    transmission nor the anisotropic lobe, then the deferred hits on glass / anisotropic metal with the full BSDF) against
-    the single launch of rounds 1-2 (CRT_HIP_SHADE_SPLIT=0): every hit runs the same expressions either way, so the
-    accumulated radiance, the ray counts and the 8-bit image are the same bits. Both scenes have dielectric AND anisotropic
-    materials on screen, so the second launch has work."""
-    sc = scenes.instanced_grove() if name == "grove" else scenes.sanmiguel_like(
-        spp=2, detail=0.05, tex_size=64, n_trees=120, leaves_per_tree=600, n_instanced=60, glass=True)
-    assert any(m[13] > 0 for m in sc.materials) and any(m[7] != 0 for m in sc.materials)
-    w, h = 200, 120
-    e, d, u, fovy = camera_of(sc)
-    out = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("CRT_HIP_SHADE_SPLIT", split)  # read when the context is created
-        r = RenderHIP()
-        r.initialize(w, h)
-        r.set_scene(sc)
-        for f in range(3):
-            st = r.render(e, d, u, fovy, f == 0, True)
-        out.append((r.accum().copy(), r.ray_counts().copy(), r.img.copy(), int(st.rays)))
-        r.close()
-    a, b = out
-    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
