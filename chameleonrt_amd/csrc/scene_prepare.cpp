@@ -217,11 +217,25 @@ bool world_tree_wanted(uint64_t instanced_tris)
     if (levels != nullptr && std::strcmp(levels, "world") == 0) {
         return true;
     }
-    // ~95 bytes per triangle in HBM (record, uv record, its share of the nodes): 2^26 triangles are 6.4 GB of a 288 GB
-    // part. The budget is set by the HOST: the SAH build over them needs ~300 bytes per triangle while it runs (records,
-    // boxes, the builder's items and temporary nodes) -- 20 GB for 2^26.
-    const char *cap = std::getenv("CRT_HIP_WORLD_TREE_MAX_TRIS");
-    const uint64_t budget = cap != nullptr ? std::strtoull(cap, nullptr, 10) : (1ull << 26);
+    // ~100 bytes per triangle in HBM (its half of a 64-byte slot, two uv records, its share of the nodes): 2^26 triangles
+    // are under 7 GB of a 288 GB part. What bounds the budget is the HOST: the SAH build over the slots needs ~300 bytes per
+    // triangle while it runs (records, boxes, the builder's items and temporary nodes) -- 20 GB for 2^26 -- so the default
+    // is what a third of the memory the host has AVAILABLE right now covers, at most 2^26 (the two-level structure, which
+    // costs O(instances) like the reference's rtcCommitScene, takes over beyond that).
+    uint64_t budget = 1ull << 26;
+    if (const char *cap = std::getenv("CRT_HIP_WORLD_TREE_MAX_TRIS")) {
+        budget = std::strtoull(cap, nullptr, 10);
+    } else if (FILE *f = std::fopen("/proc/meminfo", "r")) {
+        char line[128];
+        while (std::fgets(line, sizeof(line), f)) {
+            unsigned long long kb = 0;
+            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) {
+                budget = std::min<uint64_t>(budget, kb * 1024ull / 3ull / 300ull);
+                break;
+            }
+        }
+        std::fclose(f);
+    }
     return CRT_WORLD_TREE_DEFAULT && instanced_tris <= budget;
 }
 

@@ -152,3 +152,23 @@ def test_tile_buffer_alternates_with_a_moving_camera(hip_lib):
     # and each buffer holds the frame that was rendered into it last (the four cameras give four different images)
     assert not np.array_equal(images[0], images[1]) and not np.array_equal(images[1], images[2])
     r.close()
+
+
+@pytest.mark.parametrize("all_empty", [True, False])
+@pytest.mark.parametrize("levels", ["two", "world"])
+def test_meshes_without_triangles_render(all_empty, levels, oracle, hip_lib, monkeypatch):
+    """Instances of a mesh without triangles hit nothing, and a scene in which no instance has a triangle renders the miss
+    shader's checkerboard (one ray per path) -- in both structures for scenes with several instances, like the oracle."""
+    from tests.test_prepared_scene import _scene_with_empty_meshes
+    monkeypatch.setenv("CRT_HIP_LEVELS", levels)
+    sc = _scene_with_empty_meshes(all_empty)
+    w, h = 96, 64
+    r = RenderHIP()
+    r.initialize(w, h)
+    r.set_scene(sc)
+    o = oracle.OracleRenderer(sc, w, h)
+    e, d, u, fovy = camera_of(sc)
+    st = _check(r, o, e, d, u, fovy, frames=2)
+    if all_empty:
+        assert int(st.rays) == w * h * sc.samples_per_pixel
+    r.close()
