@@ -165,12 +165,7 @@ struct crt_hip_ctx {
             (void)hipStreamDestroy(own_stream);
         }
     }
-    // bounces traced a wave at a time (packet.h): CRT_HIP_PACKET_BOUNCES, default 0 -- measured on C4 with packets for the
-    // camera rays and their occlusion rays: closest-hit -0.9 ms, occlusion +1.6 ms per frame, and slower on C2 / C3
-    // (DESIGN.md section 6); forced to 0 when the scene's tree is deeper than a wave's stack
-    int packet_bounces = 0;
-    bool packet_ok = true;
-    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, packet_ok ? packet_bounces : 0}; }
+    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0}; }
 };
 
 namespace {
@@ -348,9 +343,6 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
-        if (const char *e = std::getenv("CRT_HIP_PACKET_BOUNCES")) {
-            c->packet_bounces = std::max(0, std::min(std::atoi(e), (int)MAX_PATH_DEPTH));
-        }
         c->stream = c->own_stream;
     } catch (const HipError &err) {
         set_global_error(err.msg);
@@ -465,7 +457,6 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->n_nodes = ps.nodes.size();
     ctx->n_tris = ps.slots.size(); // leaf slots (one or two triangles each)
     ctx->stack_need = ps.stack_need;
-    ctx->packet_ok = ps.stack_need <= packet_stack_entries();
 
     SceneView &sv = ctx->sv;
     sv.nodes = ctx->d_nodes.as<QNode>();

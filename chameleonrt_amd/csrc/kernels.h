@@ -24,13 +24,11 @@ struct LaunchCfg {
     hipStream_t stream;
     int n_cus;      // compute units of the device (grid sizing)
     bool counters;  // instrumented traversal (CRT_HIP_FLAG_COUNTERS)
-    int packet_bounces = 0; // path-loop iterations b < packet_bounces trace their rays a wave at a time (packet.h): coherent by construction
 };
 
 // Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).
 uint32_t traversal_grid_threads(int n_cus);
 uint32_t traversal_lds_stack(uint32_t levels); // per-lane stack entries kept in LDS; deeper ones go to the HBM slab
-uint32_t packet_stack_entries(); // entries of a wave's traversal stack in the packet kernels: deeper trees keep the per-lane kernels
 int traversal_child_order();    // the build's CRT_CHILD_ORDER (the oracle's BVH walker mirrors the rule)
 
 // K1: primary rays for `n_paths` pixel-samples starting at local pixel slot `slot0`.

@@ -25,7 +25,6 @@
 #include "../../include/crt_kat.h"
 #include "kernels.h"
 #include "pt_device.h"
-#include "packet.h"
 #include "traverse.h"
 
 namespace crt {
@@ -383,30 +382,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
         atomicAdd(&pc->tris_shadow, (unsigned long long)n_tris);
         atomicAdd(&pc->slots_shadow, (unsigned long long)n_slots);
     }
-}
-
-// ---- K2p / K4p: the same two traversals for launches of coherent rays, a wave at a time (packet.h) ----------------
-#ifndef CRT_PKT_MIN_WAVES
-#define CRT_PKT_MIN_WAVES 5 // 87-96 VGPRs without scratch (node + slot + matrix live in SGPRs, the lane keeps two rays, slab terms and its hit); 6 and 8 waves spill
-#endif
-#ifndef CRT_PKT_BLOCKS_PER_CU
-#define CRT_PKT_BLOCKS_PER_CU 5
-#endif
-template <bool INST_TRIS>
-__global__ __launch_bounds__(TRACE_BLOCK, CRT_PKT_MIN_WAVES) void k_trace_closest_packet(SceneView sc, PathQueue q, HitBuf hits, PassCounters *pc, int bounce)
-{
-    __shared__ int32_t wstack[TRACE_BLOCK / 64][CRT_PKT_STACK];
-    const float tnear = bounce == 0 ? 0.f : RAY_EPS;
-    const ClosestSource<INST_TRIS ? 2 : 0> src{q, hits, sc.slots, sc.instances, sc.material_ids};
-    trace_packets<false, INST_TRIS>(sc, (TV_LDS int32_t *)&wstack[threadIdx.x / 64][0], pc->n_queue[bounce], &pc->cur_closest[bounce], tnear, src);
-}
-template <bool INST_TRIS>
-__global__ __launch_bounds__(TRACE_BLOCK, CRT_PKT_MIN_WAVES) void k_trace_shadow_packet(SceneView sc, ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
-                                                                                        PassCounters *pc, int bounce)
-{
-    __shared__ int32_t wstack[TRACE_BLOCK / 64][CRT_PKT_STACK];
-    const ShadowSource src{sa, sb, radiance};
-    trace_packets<true, INST_TRIS>(sc, (TV_LDS int32_t *)&wstack[threadIdx.x / 64][0], pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce], RAY_EPS, src);
 }
 
 // ---- K3 shade: render_embree.ispc:251-335 + sample_direct_light :105-181 -----------------------
@@ -954,22 +929,10 @@ template <typename... Args> static void launch6(uint32_t levels, bool counters, 
     k<<<grid, TRACE_BLOCK, 0, stream>>>(args...);
 }
 
-// wave packets (packet.h) for the launches the context asks them for: not the instrumented kernels (the counters belong to
-// the per-lane walk, which the oracle's walker mirrors), not scenes with a top-level tree over instances
-static inline bool use_packets(const LaunchCfg &cfg, const SceneView &sc, int bounce)
-{
-    return bounce < cfg.packet_bounces && !cfg.counters && sc.two_level != 1u;
-}
-uint32_t packet_stack_entries() { return CRT_PKT_STACK; }
-
 void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q, HitBuf hits, PassCounters *pc,
                           int bounce)
 {
-    if (use_packets(cfg, sc, bounce)) {
-        auto k = sc.two_level == LEVELS_WORLD_TREE ? k_trace_closest_packet<true> : k_trace_closest_packet<false>;
-        k<<<persistent_grid(cfg, CRT_PKT_BLOCKS_PER_CU), TRACE_BLOCK, 0, cfg.stream>>>(sc, q, hits, pc, bounce);
-        return;
-    }
+
     launch6(sc.two_level, cfg.counters, k_trace_closest<false, false>, k_trace_closest<false, true>, k_trace_closest<true, false>,
             k_trace_closest<true, true>, k_trace_closest<false, false, true>, k_trace_closest<false, true, true>,
             persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, q, hits, pc, bounce);
@@ -978,11 +941,7 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
 void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
                          float4 *radiance, PassCounters *pc, int bounce)
 {
-    if (use_packets(cfg, sc, bounce)) {
-        auto k = sc.two_level == LEVELS_WORLD_TREE ? k_trace_shadow_packet<true> : k_trace_shadow_packet<false>;
-        k<<<persistent_grid(cfg, CRT_PKT_BLOCKS_PER_CU), TRACE_BLOCK, 0, cfg.stream>>>(sc, sa, sb, radiance, pc, bounce);
-        return;
-    }
+
     launch6(sc.two_level, cfg.counters, k_trace_shadow<false, false>, k_trace_shadow<false, true>, k_trace_shadow<true, false>,
             k_trace_shadow<true, true>, k_trace_shadow<false, false, true>, k_trace_shadow<false, true, true>,
             persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa, sb, radiance, pc, bounce);
