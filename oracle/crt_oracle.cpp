@@ -1903,8 +1903,13 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0), ne_t(nthreads, 0), nb_t(nthreads, 0), ls_t(nthreads, 0);
     std::vector<uint32_t> ms_t(nthreads, 0);
     std::vector<int> bad_t(nthreads, 0);
+    // diagnostic (tools/tree_cost.py): ORC_WALK_SPILL_DEPTH=K counts the pops of entries above the K-th, i.e. what a
+    // K-entry on-chip stack sends through memory
+    const char *sd_env = std::getenv("ORC_WALK_SPILL_DEPTH");
+    const size_t spill_depth = sd_env ? (size_t)std::atol(sd_env) : 0;
+    std::vector<uint64_t> sp_t(nthreads, 0), pop_t(nthreads, 0);
     auto work = [&](int tid) {
-        uint64_t nv = 0, tt = 0, ne = 0, nb = 0, ls = 0;
+        uint64_t nv = 0, tt = 0, ne = 0, nb = 0, ls = 0, spill_pops = 0, pops = 0;
         uint32_t ms = 0;
         std::vector<int32_t> stack(1024);
         for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
@@ -2121,6 +2126,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                         break;
                     }
                     cur = stack[--sp];
+                    ++pops;
+                    spill_pops += sp >= spill_depth;
                     if (two_level && cur == F_SENTINEL) {
                         o = worg;
                         d = wdir;
@@ -2146,6 +2153,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         nb_t[tid] = nb;
         ls_t[tid] = ls;
         ms_t[tid] = ms;
+        sp_t[tid] = spill_pops;
+        pop_t[tid] = pops;
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < nthreads; ++t) {
@@ -2164,6 +2173,15 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         ne += ne_t[t];
         ms = std::max(ms, ms_t[t]);
         bad |= bad_t[t];
+    }
+    if (sd_env) {
+        uint64_t a = 0, b = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            a += sp_t[t];
+            b += pop_t[t];
+        }
+        std::fprintf(stderr, "[orc walk] %.3f pops per ray, %.3f of them above entry %zu; deepest %u\n", (double)b / (double)std::max<uint64_t>(n, 1),
+                     (double)a / (double)std::max<uint64_t>(n, 1), spill_depth, ms);
     }
     *nodes_visited = nv;
     *tris_tested = tt;
