@@ -28,26 +28,6 @@ def test_builder_and_quantiser(exe, n, threads, seed, mode):
     assert "errors 0" in p.stdout
 
 
-@pytest.fixture(scope="module")
-def exe8(tmp_path_factory):
-    out = os.path.join(tmp_path_factory.mktemp("bvh8"), "bvh8_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-ffp-contract=off", "-I", CSRC,
-                           os.path.join(ROOT, "tests", "native", "bvh8_check.cpp"), os.path.join(CSRC, "bvh_builder.cpp"),
-                           "-o", out])
-    return out
-
-
-@pytest.mark.parametrize("n,threads,seed,mode", [(1, 1, 1, 0), (2, 1, 1, 0), (9, 2, 2, 0), (1000, 1, 3, 0),
-                                                  (200000, 4, 4, 0), (100000, 4, 5, 1), (30000, 2, 6, 2)])
-def test_eight_wide_build_and_quantiser(exe8, n, threads, seed, mode):
-    """The 8-wide tree of single-tree scenes (crt_types.h QNode8): block layout, containment, both quantisations outward."""
-    p = subprocess.run([exe8, str(n), str(threads), str(seed), str(mode)], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout + p.stderr
-    assert "errors 0" in p.stdout
-    outs = [subprocess.run([exe8, "20000", str(t), "7", "0"], capture_output=True, text=True, timeout=600).stdout for t in (1, 5)]
-    assert outs[0] == outs[1], "thread count changes the tree"
-
-
 def test_thread_count_does_not_change_the_tree(exe):
     outs = [subprocess.run([exe, "50000", str(t), "7", "0"], capture_output=True, text=True, timeout=600).stdout
             for t in (1, 3, 8)]
