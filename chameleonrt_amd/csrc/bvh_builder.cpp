@@ -66,7 +66,7 @@ struct TNode { // no default member initialisers: the node pool is raw storage u
     // Collapse to 4-wide nodes (see build_bvh): cheapest summed surface area of the wide nodes below
     // this node if it may use 1 (= it is the root of a wide node), 2 or 3 child slots of its
     // parent's wide node. Filled when both children are complete, i.e. inside the parallel build.
-    double slot_cost[7]; // [j - 1], j = 1 .. width - 1 (width <= 8)
+    double slot_cost[3];
 };
 
 // One item as the builder moves it around: 32 B, partitioned IN PLACE so every pass streams
@@ -112,7 +112,6 @@ struct Builder {
     int max_leaf;
     int n_threads = 1;
     int n_bins = MAX_BINS;
-    int width = BVH_WIDTH; // of the wide nodes the binary tree will be collapsed to (4 or 8): sizes the slot_cost table
 
     int32_t alloc()
     {
@@ -120,9 +119,7 @@ struct Builder {
         TNode &t = tn[i];
         t.left = t.right = -1;
         t.first = t.count = t.depth = 0;
-        for (double &c : t.slot_cost) {
-            c = 0.0;
-        }
+        t.slot_cost[0] = t.slot_cost[1] = t.slot_cost[2] = 0.0;
         return i;
     }
 
@@ -386,11 +383,10 @@ struct Builder {
             const Aabb &x = tn[me].box;
             const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
             int a;
-            const double as_root = (dx * dy + dy * dz + dz * dx) + best_split(me, width, a);
+            const double as_root = (dx * dy + dy * dz + dz * dx) + best_split(me, 4, a);
             tn[me].slot_cost[0] = as_root;
-            for (int j = 2; j < width; ++j) {
-                tn[me].slot_cost[j - 1] = std::min(as_root, best_split(me, j, a));
-            }
+            tn[me].slot_cost[1] = std::min(as_root, best_split(me, 2, a));
+            tn[me].slot_cost[2] = std::min(as_root, best_split(me, 3, a));
         }
         return me;
     }
@@ -402,7 +398,7 @@ struct Builder {
         const int32_t l = tn[t].left, r = tn[t].right;
         double best = std::numeric_limits<double>::infinity();
         for (int a = 1; a < j; ++a) {
-            const double c = slots(l, std::min(a, width - 1)) + slots(r, std::min(j - a, width - 1));
+            const double c = slots(l, std::min(a, 3)) + slots(r, std::min(j - a, 3));
             if (c < best) {
                 best = c;
                 a_out = a;
@@ -417,14 +413,8 @@ inline int32_t leaf_ref(uint32_t first, uint32_t count) { return (int32_t)~((fir
 } // namespace
 
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
-                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads, int width)
+                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads)
 {
-    if (width != BVH_WIDTH && width != BVH8_WIDTH) {
-        throw std::runtime_error("build_bvh: width must be 4 or 8");
-    }
-    if (width == BVH8_WIDTH && (max_leaf != 1 || leaf_holds_item_id)) {
-        throw std::runtime_error("build_bvh: an 8-wide tree has leaves of one item and no item-id leaves");
-    }
     if (n == 0) {
         throw std::runtime_error("build_bvh: no items");
     }
@@ -447,7 +437,6 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     Builder b;
     b.max_leaf = max_leaf;
     b.n_threads = std::max(1, n_threads);
-    b.width = width;
     // (the top-level tree over instance boxes keeps 16 bins: with 64 the two-level C4 walks 13 % MORE lines per ray and
     // renders 8 % slower -- greedy SAH over a few thousand overlapping boxes is that fickle; the finer bins pay for
     // triangles, see CRT_BVH_BINS)
@@ -498,14 +487,14 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     // CRT_BVH_COLLAPSE=greedy selects the earlier heuristic (expand the inner child of largest
     // surface area until the node is full) for comparison.
     struct Wide {
-        int32_t kid[BVH8_WIDTH];
+        int32_t kid[BVH_WIDTH];
         int n;
     };
     static const bool greedy_collapse = [] {
         const char *e = std::getenv("CRT_BVH_COLLAPSE");
         return e != nullptr && std::strcmp(e, "greedy") == 0;
     }();
-    // (written for any width up to 8: TNode::slot_cost has width - 1 entries)
+    static_assert(BVH_WIDTH == 4, "the collapse below is written for 4-wide nodes");
     // The table slots(n, j) is TNode::slot_cost, filled bottom-up inside the (parallel) build.
     auto slots = [&](int32_t t, int j) { return b.slots(t, j); };
     auto best_split = [&](int32_t t, int j, int &a_out) { return b.best_split(t, j, a_out); };
@@ -529,7 +518,7 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
             w.kid[0] = b.tn[t].left;
             w.kid[1] = b.tn[t].right;
             w.n = 2;
-            while (w.n < width) {
+            while (w.n < BVH_WIDTH) {
                 int best = -1;
                 double best_area = -1.0;
                 for (int k = 0; k < w.n; ++k) {
@@ -555,11 +544,11 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
             int32_t x;
             int j;
         };
-        Item work[2 * BVH8_WIDTH];
+        Item work[8];
         int nw = 0;
         int a = 2;
-        best_split(t, width, a);
-        work[nw++] = Item{b.tn[t].right, width - a};
+        best_split(t, 4, a);
+        work[nw++] = Item{b.tn[t].right, 4 - a};
         work[nw++] = Item{b.tn[t].left, a};
         while (nw > 0) {
             const Item it = work[--nw];
@@ -578,112 +567,6 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
         }
         return w;
     };
-    if (width == BVH8_WIDTH) {
-        // ---- 8-wide layout: no per-child references (crt_types.h QNode8). When a node is laid out, its inner children get a
-        // BLOCK of consecutive node indices and its leaf children a block of consecutive positions of the item order; the
-        // first max_top_nodes nodes are laid out breadth-first (they are the ones the kernels stage in LDS: indices
-        // [0, n_top) whatever the order the rest is processed in), the remainder depth-first so that a subtree stays
-        // together in memory. Inner children come first in a node, in the collapse's order; then the leaves.
-        auto empty8 = [] {
-            BvhNode8 nd;
-            std::memset(&nd, 0, sizeof(nd));
-            for (int k = 0; k < BVH8_WIDTH; ++k) {
-                nd.c[k] = EMPTY_CHILD;
-            }
-            return nd;
-        };
-        auto set_child8 = [&](BvhNode8 &nd, int k, int32_t t, int32_t ref) {
-            for (int a = 0; a < 3; ++a) {
-                nd.lo[k][a] = b.tn[t].box.lo[a];
-                nd.hi[k][a] = b.tn[t].box.hi[a];
-            }
-            nd.c[k] = ref;
-        };
-        out.order.assign(n, 0u);
-        if (!is_inner(root)) { // a single item: one node with one leaf child
-            BvhNode8 nd = empty8();
-            set_child8(nd, 0, root, leaf_ref(item_base, 1));
-            out.order[0] = b.prims[b.tn[root].first].id;
-            out.nodes8.push_back(nd);
-            out.n_top = 1;
-            out.max_depth = 1;
-            return out;
-        }
-        struct Todo {
-            int32_t t;     // binary node the wide node is rooted at
-            uint32_t idx;  // its final index
-            uint32_t depth;
-        };
-        std::vector<Todo> stack;
-        std::queue<Todo> bfs;
-        bfs.push(Todo{root, 0u, 1u});
-        uint32_t next_node = 1, next_item = 0, done = 0, max_depth8 = 1;
-        out.nodes8.reserve((size_t)n_tn / 4 + 1);
-        auto lay_out = [&](const Todo &me, bool breadth_first) {
-            if (out.nodes8.size() <= me.idx) {
-                out.nodes8.resize((size_t)me.idx + 1, empty8());
-            }
-            max_depth8 = std::max(max_depth8, me.depth);
-            const Wide w = wide_children(me.t);
-            BvhNode8 nd = empty8();
-            int k = 0;
-            const uint32_t first_child = next_node;
-            for (int c = 0; c < w.n; ++c) {
-                if (is_inner(w.kid[c])) {
-                    set_child8(nd, k++, w.kid[c], (int32_t)next_node + node_base);
-                    ++next_node;
-                }
-            }
-            const int n_inner = k;
-            for (int c = 0; c < w.n; ++c) {
-                if (!is_inner(w.kid[c])) {
-                    set_child8(nd, k++, w.kid[c], leaf_ref(next_item + item_base, 1));
-                    out.order[next_item++] = b.prims[b.tn[w.kid[c]].first].id;
-                }
-            }
-            out.nodes8[me.idx] = nd;
-            // children to lay out later: breadth-first ones queue up, depth-first ones go on the stack (first child on top)
-            int at = 0;
-            std::vector<Todo> kids;
-            for (int c = 0; c < w.n; ++c) {
-                if (is_inner(w.kid[c])) {
-                    kids.push_back(Todo{w.kid[c], first_child + (uint32_t)at++, me.depth + 1});
-                }
-            }
-            (void)n_inner;
-            if (breadth_first) {
-                for (const Todo &kd : kids) {
-                    bfs.push(kd);
-                }
-            } else {
-                for (size_t i = kids.size(); i-- > 0;) {
-                    stack.push_back(kids[i]);
-                }
-            }
-        };
-        while (!bfs.empty() && done < max_top_nodes) {
-            const Todo me = bfs.front();
-            bfs.pop();
-            lay_out(me, true);
-            ++done;
-        }
-        while (!bfs.empty()) { // the subtrees below the breadth-first part, each depth-first
-            stack.push_back(bfs.front());
-            bfs.pop();
-            while (!stack.empty()) {
-                const Todo me = stack.back();
-                stack.pop_back();
-                lay_out(me, false);
-            }
-        }
-        if (next_item != n || out.nodes8.size() != next_node) {
-            throw std::runtime_error("build_bvh: 8-wide layout lost items or nodes");
-        }
-        out.n_top = std::min<uint32_t>(next_node, max_top_nodes);
-        out.max_depth = max_depth8;
-        phase("node order + emit (8-wide)");
-        return out;
-    }
     // final index of every wide node (keyed by the temp node it is rooted at): BFS for the first
     // max_top_nodes, then DFS pre-order per remaining subtree (children of a node end up close to
     // it in memory)
@@ -782,7 +665,7 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
 }
 
 // ---- linear BVH on the host: the device builder's algorithm (lbvh.h), run serially ---------------------
-BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes, int width)
+BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes)
 {
     BuiltBvh out;
     box_reset(out.bounds);
@@ -790,7 +673,7 @@ BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max
         box_grow(out.bounds, boxes[i]);
     }
     if (n < 3) { // degenerate sizes: the SAH builder's single-node forms
-        return build_bvh(boxes, n, max_leaf, 0, 0, false, max_top_nodes, 1, width);
+        return build_bvh(boxes, n, max_leaf, 0, 0, false, max_top_nodes, 1);
     }
     std::vector<uint64_t> keys(n);
     std::vector<Aabb> pbox(n), ibox(n);
@@ -834,49 +717,6 @@ BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max
         build_binary(0);
     }
     const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
-    if (width == BVH8_WIDTH) {
-        // 8-wide: level by level like below; a node's inner children are the next consecutive nodes of the following level,
-        // its single-item children the next consecutive positions of the final item order (bvh_device.hip does the same
-        // with two prefix sums per level, so the device tree is this tree)
-        const std::vector<uint32_t> sorted = out.order;
-        std::vector<int32_t> frontier{0}, next;
-        uint32_t level_base = 0, depth = 0, next_item = 0;
-        while (!frontier.empty()) {
-            next.clear();
-            const uint32_t n_in = (uint32_t)frontier.size();
-            for (uint32_t i = 0; i < n_in; ++i) {
-                int32_t sub[BVH8_WIDTH];
-                int n_inner = 0;
-                const int nc = lbvh_wide_children8(tree, frontier[i], sub, n_inner);
-                BvhNode8 nd;
-                std::memset(&nd, 0, sizeof(nd));
-                for (int c = 0; c < BVH8_WIDTH; ++c) {
-                    nd.c[c] = EMPTY_CHILD;
-                }
-                for (int c = 0; c < nc; ++c) {
-                    if (c < n_inner) {
-                        nd.c[c] = (int32_t)(level_base + n_in + next.size());
-                        next.push_back(sub[c]);
-                    } else {
-                        nd.c[c] = lbvh_leaf_ref(next_item, 1u);
-                        out.order[next_item++] = sorted[(size_t)~sub[c]];
-                    }
-                    const Aabb &b = lbvh_box(tree, sub[c]);
-                    for (int a = 0; a < 3; ++a) {
-                        nd.lo[c][a] = b.lo[a];
-                        nd.hi[c][a] = b.hi[a];
-                    }
-                }
-                out.nodes8.push_back(nd);
-            }
-            level_base += n_in;
-            frontier.swap(next);
-            ++depth;
-        }
-        out.max_depth = depth;
-        out.n_top = std::min<uint32_t>((uint32_t)out.nodes8.size(), max_top_nodes);
-        return out;
-    }
     std::vector<int32_t> frontier{0}, next;
     uint32_t level_base = 0, depth = 0;
     while (!frontier.empty()) {
@@ -950,51 +790,6 @@ QNode quantise(const BvhNode &n, const QFrame &f)
         }
         q.child[k].ref = used ? n.c[k] : n.c[0]; // slot 0 is always used (used slots come first)
     }
-    return q;
-}
-
-// The 64-byte 8-wide node: every child box first rounded outward to the 16-bit frame exactly like quantise() does, then to the
-// node's own 8-bit grid -- origin = the smallest 16-bit coordinate of any child on the axis, cell = 2^e quanta with the
-// smallest e that lets the largest one fit 8 bits -- outward again (lo: floor, hi: ceil). References become the two bases.
-QNode8 quantise8(const BvhNode8 &n, const QFrame &f)
-{
-    int n_used = 0, n_inner = 0;
-    Aabb boxes[BVH8_WIDTH];
-    while (n_used < BVH8_WIDTH && n.c[n_used] != EMPTY_CHILD) {
-        if (n.c[n_used] >= 0) {
-            if (n_inner != n_used) {
-                throw std::runtime_error("quantise8: inner children must come first");
-            }
-            ++n_inner;
-        }
-        for (int a = 0; a < 3; ++a) {
-            boxes[n_used].lo[a] = n.lo[n_used][a];
-            boxes[n_used].hi[a] = n.hi[n_used][a];
-        }
-        ++n_used;
-    }
-    // the blocks: inner children are consecutive nodes, leaf children consecutive slots (build_bvh laid them out so)
-    uint32_t slot_base = 0u;
-    for (int k = 0; k < n_used; ++k) {
-        if (k < n_inner) {
-            if (n.c[k] != n.c[0] + k) {
-                throw std::runtime_error("quantise8: inner children are not consecutive nodes");
-            }
-        } else {
-            const uint32_t x = ~(uint32_t)n.c[k];
-            if ((x & 7u) != 0u) {
-                throw std::runtime_error("quantise8: a leaf of an 8-wide tree is one slot");
-            }
-            if (k == n_inner) {
-                slot_base = x >> 3;
-            } else if ((x >> 3) != slot_base + (uint32_t)(k - n_inner)) {
-                throw std::runtime_error("quantise8: leaf children are not consecutive slots");
-            }
-        }
-    }
-    QNode8 q;
-    std::memset(&q, 0, sizeof(q));
-    lbvh_node8(q, boxes, n_used, n_inner, n_inner > 0 ? (uint32_t)n.c[0] : 0u, slot_base, f);
     return q;
 }
 

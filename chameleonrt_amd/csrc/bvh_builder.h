@@ -16,8 +16,7 @@ struct Aabb {
 };
 
 struct BuiltBvh {
-    std::vector<BvhNode> nodes;  // width 4: nodes[0] is the root; the first n_top nodes are the top levels in BFS order
-    std::vector<BvhNode8> nodes8; // width 8 instead: a node's inner children are consecutive nodes, its leaf children consecutive items
+    std::vector<BvhNode> nodes;  // nodes[0] is the root; the first n_top nodes are the top levels in BFS order
     std::vector<uint32_t> order; // item ids in leaf order (leaf `first` indexes this array)
     uint32_t n_top = 0;
     Aabb bounds;
@@ -30,14 +29,12 @@ struct BuiltBvh {
 // node_base / item_base are added to the inner-node indices / leaf `first` values so several
 // BVHs can be concatenated into one array. If leaf_holds_item_id is set (TLAS), max_leaf must
 // be 1 and a leaf's `first` is the item id itself instead of its position in `order`.
-// width: 4 (BvhNode, explicit child references) or 8 (BvhNode8: leaves of ONE item, children in consecutive blocks).
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
-                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads, int width = BVH_WIDTH);
+                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads);
 
 // Fixed-point frame of a BVH with bounds b, and the outward-rounded 64-byte form of a node in it
 // (crt_types.h QFrame / QNode): what the traversal kernels actually read.
 QFrame make_frame(const Aabb &b);
 QNode quantise(const BvhNode &n, const QFrame &f);
-QNode8 quantise8(const BvhNode8 &n, const QFrame &f);
 
 } // namespace crt

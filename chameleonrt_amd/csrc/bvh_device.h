@@ -27,9 +27,8 @@ struct DeviceBuiltMesh {
 // alone) for meshes too small to be worth it -- the caller then uses the host builder. Throws std::runtime_error on
 // HIP errors. The caller's current device is left as it was.
 struct SlotTris;
-// width: 4 (QNode records: a BLAS under a top-level tree) or 8 (QNode8 records in `nodes`: the tree of a single-instance scene).
 bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
-                       uint32_t max_leaf, uint32_t max_top_nodes, int width, DeviceBuiltMesh &out);
+                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out);
 
 // The WORLD TREE of a scene with several instances (crt_types.h LEVELS_WORLD_TREE) built the same way: one item per
 // (instance, leaf slot of its mesh), the slot record in the mesh's object space with tag = (instance << 1) | identity, the
@@ -41,6 +40,6 @@ bool device_build_world(int device, const crt_scene_desc *scene, const std::vect
 
 // The same algorithm run serially on the host (shares lbvh.h with the kernels): what the CPU tests
 // check, and the reference the device result is compared against (CRT_BVH_BUILDER=lbvh).
-BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes, int width = BVH_WIDTH);
+BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes);
 
 } // namespace crt

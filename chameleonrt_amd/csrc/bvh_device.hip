@@ -297,57 +297,16 @@ __global__ __launch_bounds__(256) void k_collapse(LbvhTree t, const int32_t *fro
     nodes[level_base + i] = node;
 }
 
-// ---- 8-wide collapse (crt_types.h QNode8), level by level like k_collapse, but a node's inner children must be CONSECUTIVE
-// nodes of the next level and its single-item children consecutive positions of the final slot order: per level, count
-// (inner, leaf) per frontier node, two exclusive prefix sums, then emit. Deterministic: the tree is build_lbvh_host's.
-__global__ __launch_bounds__(256) void k_collapse8_count(LbvhTree t, const int32_t *frontier_in, uint32_t n_in, uint32_t *cnt_inner, uint32_t *cnt_leaf)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) {
-        return;
-    }
-    int32_t sub[BVH8_WIDTH];
-    int n_inner = 0;
-    const int n = lbvh_wide_children8(t, frontier_in[i], sub, n_inner);
-    cnt_inner[i] = (uint32_t)n_inner;
-    cnt_leaf[i] = (uint32_t)(n - n_inner);
-}
-__global__ __launch_bounds__(256) void k_collapse8_emit(LbvhTree t, const int32_t *frontier_in, uint32_t n_in, const uint32_t *off_inner,
-                                                        const uint32_t *off_leaf, int32_t *frontier_out, uint32_t level_base, uint32_t item_base,
-                                                        QNode8 *nodes, uint32_t *final_pos, QFrame frame)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) {
-        return;
-    }
-    int32_t sub[BVH8_WIDTH];
-    int n_inner = 0;
-    const int n = lbvh_wide_children8(t, frontier_in[i], sub, n_inner);
-    Aabb boxes[BVH8_WIDTH];
-    for (int c = 0; c < n; ++c) {
-        boxes[c] = lbvh_box(t, sub[c]);
-        if (c < n_inner) {
-            frontier_out[off_inner[i] + (uint32_t)c] = sub[c];
-        } else {
-            final_pos[~sub[c]] = item_base + off_leaf[i] + (uint32_t)(c - n_inner); // sorted position -> position in the slot array
-        }
-    }
-    QNode8 q;
-    lbvh_node8(q, boxes, n, n_inner, level_base + n_in + off_inner[i], item_base + off_leaf[i], frame);
-    nodes[level_base + i] = q;
-}
-
 __global__ __launch_bounds__(256) void k_emit(uint32_t n, const LeafSlot *recs, const uint32_t *idx, const GeomDev *geoms, const SlotDev *table,
-                                              const uint32_t *indices, const float *uvs, const uint32_t *final_pos, LeafSlot *slots, float *tri_uvs)
+                                              const uint32_t *indices, const float *uvs, LeafSlot *slots, float *tri_uvs)
 {
-    const uint32_t sorted_p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sorted_p >= n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) {
         return;
     }
-    const uint32_t p = final_pos != nullptr ? final_pos[sorted_p] : sorted_p; // (4-wide: leaf order = sorted order)
-    const LeafSlot r = recs[idx[sorted_p]];
+    const LeafSlot r = recs[idx[p]];
     slots[p] = r;
-    const GeomDev g = geoms[table[idx[sorted_p]].geom];
+    const GeomDev g = geoms[table[idx[p]].geom];
     for (int which = 0; which < 2; ++which) {
         const uint32_t prim = which == 0 ? r.prim0 : r.prim1;
         float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -373,7 +332,7 @@ namespace {
 // The pipeline behind both entry points: geometry upload, k_setup over the slot table, keys / sort / radix tree / refit with
 // both key normalisations, collapse, emit.
 bool build_on_device(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotDev> &table,
-                     const std::vector<InstDev> &inst_table, uint32_t max_leaf, uint32_t max_top_nodes, int width, DeviceBuiltMesh &out)
+                     const std::vector<InstDev> &inst_table, uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
 {
     uint64_t n_tris = 0, n_verts = 0, n_uvs = 0;
     for (uint32_t g = 0; g < n_geoms; ++g) {
@@ -529,42 +488,7 @@ bool build_on_device(int device, const crt_geometry_desc *geoms, uint32_t n_geom
     BD_CHECK(hipMemcpyAsync(d_front_a.p, &root, 4, hipMemcpyHostToDevice, s));
     uint32_t n_in = 1, level_base = 0, depth = 0;
     int32_t *fin = d_front_a.as<int32_t>(), *fout = d_front_b.as<int32_t>();
-    Buf d_cnt_i, d_cnt_l, d_off_i, d_off_l, d_final_pos, d_scan_tmp;
-    if (width == BVH8_WIDTH) {
-        for (Buf *b : {&d_cnt_i, &d_cnt_l, &d_off_i, &d_off_l, &d_final_pos}) {
-            b->alloc((size_t)n * 4);
-        }
-        size_t scan_bytes = 0;
-        BD_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, d_cnt_i.as<uint32_t>(), d_off_i.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-        d_scan_tmp.alloc(scan_bytes);
-        uint32_t item_base = 0;
-        while (n_in > 0) {
-            k_collapse8_count<<<grid_for(n_in), 256, 0, s>>>(tree, fin, n_in, d_cnt_i.as<uint32_t>(), d_cnt_l.as<uint32_t>());
-            BD_CHECK(rocprim::exclusive_scan(d_scan_tmp.p, scan_bytes, d_cnt_i.as<uint32_t>(), d_off_i.as<uint32_t>(), 0u, (size_t)n_in,
-                                             rocprim::plus<uint32_t>(), s));
-            BD_CHECK(rocprim::exclusive_scan(d_scan_tmp.p, scan_bytes, d_cnt_l.as<uint32_t>(), d_off_l.as<uint32_t>(), 0u, (size_t)n_in,
-                                             rocprim::plus<uint32_t>(), s));
-            k_collapse8_emit<<<grid_for(n_in), 256, 0, s>>>(tree, fin, n_in, d_off_i.as<uint32_t>(), d_off_l.as<uint32_t>(), fout, level_base, item_base,
-                                                            reinterpret_cast<QNode8 *>(d_nodes.as<QNode>()), d_final_pos.as<uint32_t>(), frame);
-            uint32_t last[4]; // last count and last offset of both scans: the level's totals
-            BD_CHECK(hipMemcpyAsync(&last[0], d_cnt_i.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, s));
-            BD_CHECK(hipMemcpyAsync(&last[1], d_off_i.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, s));
-            BD_CHECK(hipMemcpyAsync(&last[2], d_cnt_l.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, s));
-            BD_CHECK(hipMemcpyAsync(&last[3], d_off_l.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, s));
-            BD_CHECK(hipStreamSynchronize(s));
-            level_base += n_in;
-            item_base += last[2] + last[3];
-            n_in = last[0] + last[1];
-            std::swap(fin, fout);
-            if (++depth > 4096) {
-                throw std::runtime_error("device BVH build: collapse does not terminate");
-            }
-        }
-        if (item_base != n) {
-            throw std::runtime_error("device BVH build: the 8-wide collapse lost items");
-        }
-    }
-    while (width != BVH8_WIDTH && n_in > 0) {
+    while (n_in > 0) {
         BD_CHECK(hipMemsetAsync(d_count.p, 0, 4, s));
         k_collapse<<<grid_for(n_in), 256, 0, s>>>(tree, fin, n_in, fout, d_count.as<uint32_t>(), level_base, d_nodes.as<QNode>(), frame,
                                                   max_leaf);
@@ -586,7 +510,7 @@ bool build_on_device(int device, const crt_geometry_desc *geoms, uint32_t n_geom
     d_slots.alloc((size_t)n * sizeof(LeafSlot));
     d_tuv.alloc((size_t)n * 2 * TRI_UV_STRIDE * 4);
     k_emit<<<grid_for(n), 256, 0, s>>>(n, d_recs.as<LeafSlot>(), idx, d_geoms.as<GeomDev>(), d_table.as<SlotDev>(), d_indices.as<uint32_t>(), d_uvs.as<float>(),
-                                       width == BVH8_WIDTH ? d_final_pos.as<uint32_t>() : nullptr, d_slots.as<LeafSlot>(), d_tuv.as<float>());
+                                       d_slots.as<LeafSlot>(), d_tuv.as<float>());
     BD_CHECK(hipGetLastError());
     out.nodes.resize(n_nodes);
     out.slots.resize(n);
@@ -604,7 +528,7 @@ bool build_on_device(int device, const crt_geometry_desc *geoms, uint32_t n_geom
 } // namespace
 
 bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_geoms, const std::vector<SlotTris> *geom_slots,
-                       uint32_t max_leaf, uint32_t max_top_nodes, int width, DeviceBuiltMesh &out)
+                       uint32_t max_leaf, uint32_t max_top_nodes, DeviceBuiltMesh &out)
 {
     std::vector<SlotDev> table;
     for (uint32_t g = 0; g < n_geoms; ++g) {
@@ -612,7 +536,7 @@ bool device_build_mesh(int device, const crt_geometry_desc *geoms, uint32_t n_ge
             table.push_back(SlotDev{g, st.a, st.b, NO_INSTANCE});
         }
     }
-    return build_on_device(device, geoms, n_geoms, table, {}, max_leaf, max_top_nodes, width, out);
+    return build_on_device(device, geoms, n_geoms, table, {}, max_leaf, max_top_nodes, out);
 }
 
 bool device_build_world(int device, const crt_scene_desc *scene, const std::vector<SlotTris> *geom_slots, const uint32_t *inst_identity,
@@ -635,7 +559,7 @@ bool device_build_world(int device, const crt_scene_desc *scene, const std::vect
             }
         }
     }
-    return build_on_device(device, scene->geometries, scene->n_geometries, table, insts, max_leaf, max_top_nodes, BVH8_WIDTH, out);
+    return build_on_device(device, scene->geometries, scene->n_geometries, table, insts, max_leaf, max_top_nodes, out);
 }
 
 } // namespace crt

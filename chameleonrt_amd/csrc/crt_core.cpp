@@ -138,7 +138,7 @@ struct crt_hip_ctx {
 
     // wavefront state
     uint64_t capacity = 0; // paths per pass
-    DeviceBuffer d_queue_mem, d_pc, d_sb; // d_sb: the ShadowQueueB struct (its field pointers) for k_trace_shadow
+    DeviceBuffer d_queue_mem, d_pc;
     PathQueue q[2]{};
     HitBuf hits{};
     ShadowQueueA sa{};
@@ -273,8 +273,6 @@ void setup_queues(crt_hip_ctx *c)
     c->sb.reserved = i32();
     c->radiance = reinterpret_cast<float4 *>(base + k * cap);
     c->d_pc.alloc(sizeof(PassCounters));
-    c->d_sb.alloc(sizeof(ShadowQueueB));
-    HIP_CHECK(hipMemcpy(c->d_sb.ptr, &c->sb, sizeof(ShadowQueueB), hipMemcpyHostToDevice));
     const uint64_t total_paths = total_slots * c->spp;
     const uint32_t n_pass = (uint32_t)((total_paths + cap - 1) / cap);
     if (c->h_pc) {
@@ -597,13 +595,11 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
         sa.tmax = base + 6 * n;
         sa.path = reinterpret_cast<uint32_t *>(x + 3 * n);
         sa.bslot = reinterpret_cast<int32_t *>(x + 4 * n);
-        DeviceBuffer d_sbq; // (no item of this batch has a second ray: an all-NULL struct, never dereferenced)
-        d_sbq.alloc(sizeof(ShadowQueueB));
-        HIP_CHECK(hipMemsetAsync(d_sbq.ptr, 0, sizeof(ShadowQueueB), s));
+        ShadowQueueB sb{};
         d_out.alloc(n * sizeof(float4));
         HIP_CHECK(hipMemsetAsync(d_out.ptr, 0, d_out.bytes, s));
         HIP_CHECK(hipEventRecord(e0, s));
-        launch_trace_shadow(cfg, ctx->sv, sa, d_sbq.as<ShadowQueueB>(), d_out.as<float4>(), d_pc.as<PassCounters>(), bounce);
+        launch_trace_shadow(cfg, ctx->sv, sa, sb, d_out.as<float4>(), d_pc.as<PassCounters>(), bounce);
         HIP_CHECK(hipEventRecord(e1, s));
         HIP_CHECK(hipGetLastError());
         std::vector<float4> rad(n);
@@ -771,7 +767,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                     HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
                     HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
                     mark(1, ctx->aux_stream, b);
-                    launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->d_sb.as<ShadowQueueB>(), ctx->radiance, d_pc, b);
+                    launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
                     mark_end(ctx->aux_stream);
                     HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
                     if (b + 1 < MAX_PATH_DEPTH) {
@@ -782,7 +778,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                     HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 } else {
                     mark(1, ctx->stream, b);
-                    launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->d_sb.as<ShadowQueueB>(), ctx->radiance, d_pc, b);
+                    launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
                     mark_end(ctx->stream);
                 }
             }

@@ -62,36 +62,6 @@ struct alignas(16) QNode {
 };
 static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 
-// ---- 8-wide nodes (scenes traversed as ONE tree: a single instance, or a world tree) ---------------------------------------
-// What bounds the traversal kernels is the number of cache lines a ray touches -- one L2 -> L1 line fill per lane and
-// node visit, ~2.9 CU-cycles each, whatever the visit requests -- so a node should decide as many
-// children as one 64-byte line can hold. Eight: the children's boxes as 8-bit offsets on a per-node grid inside the BVH's
-// 16-bit frame (Ylitie, Karras, Laine 2017, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"),
-// and no per-child reference at all: a node's inner children are consecutive node records, its leaf children consecutive
-// leaf slots, inner children first. The same binary SAH tree collapsed 8-wide has 0.62-0.66 x the node visits of the
-// 4-wide collapse (SAH estimate on C2 / C3 / C4).
-//   plane of child k on axis a:  org[a] + (lo[a][k] << e_a)  ...  org[a] + (hi[a][k] << e_a)   quanta of the QFrame
-//   an unused slot:              lo = 255, hi = 0 on every axis (inverted: the sign-ordered slab test rejects it by itself)
-//   child k < n_inner:           inner node  node_base + k
-//   child k >= n_inner (used):   leaf slot   slot_base + (k - n_inner)     (one slot per leaf)
-// Boxes are rounded OUTWARD twice (16-bit frame, then the 8-bit grid): conservative, so results do not depend on them.
-// Scenes with a top-level tree over instances (two_level == 1) keep the 4-wide QNode below for TLAS and BLASes alike:
-// their top-level leaves are arbitrary references (instances, grafted subtrees), not consecutive records.
-constexpr int BVH8_WIDTH = 8;
-struct alignas(16) BvhNode8 { // what the host builder emits: full-precision boxes, explicit references (c as in BvhNode)
-    float lo[BVH8_WIDTH][3], hi[BVH8_WIDTH][3];
-    int32_t c[BVH8_WIDTH]; // inner children first, then leaves, then EMPTY_CHILD
-};
-struct alignas(16) QNode8 {
-    uint16_t org[3];
-    uint16_t meta;      // bits 0-3, 4-7, 8-11: e_x, e_y, e_z (0..8); bits 12-15: n_inner
-    uint32_t node_base;
-    uint32_t slot_base;
-    uint8_t lo[3][BVH8_WIDTH];
-    uint8_t hi[3][BVH8_WIDTH];
-};
-static_assert(sizeof(QNode8) == 64, "QNode8 must be 64 bytes");
-
 // One LEAF of a BVH = one 64-byte slot = 4 x dwordx4 in ONE cache line: a triangle, or two triangles of one geometry
 // (and one instance) that share an edge -- a quad, Embree's own leaf form for triangle meshes -- stored as the four
 // distinct vertices in full precision plus the ids. A leaf visit is a dependent step that costs a line fill whatever

@@ -42,8 +42,7 @@ void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitB
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce);
 // K4: any-hit traversal of the NEE occlusion rays (light sample, then the rare BSDF-sample ray of
 // the same hit, by the same lane).
-// (sb: the second queue's field pointers as a struct IN DEVICE MEMORY -- few items use it)
-void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, const ShadowQueueB *sb,
+void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
                          float4 *radiance, PassCounters *pc, int bounce);
 // K5: per-pixel sample sum, running mean over frames, sRGB8, ray statistics.
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,

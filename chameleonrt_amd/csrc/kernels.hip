@@ -310,9 +310,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
 struct ShadowSource {
     static constexpr bool CONST_TFAR = false, MULTI_RAY = true;
     ShadowQueueA sa;
-    // the second queue is touched by the few items that have a BSDF-sample ray: its 18 field pointers live in HBM and are
-    // fetched when one comes along, instead of occupying 36 of the kernel's ~100 scalar registers throughout
-    const ShadowQueueB *sbp;
+    ShadowQueueB sb;
     float4 *radiance;
     CRT_DEV void load(uint32_t i, V3 &o, V3 &d, float &tfar) const
     {
@@ -337,7 +335,6 @@ struct ShadowSource {
                 return false;
             }
             carry = visible ? 1u : 0u;
-            const ShadowQueueB &sb = *sbp;
             o = v3(sb.o[0][b], sb.o[1][b], sb.o[2][b]); // same origin, BSDF-sampled direction
             d = v3(sb.d[0][b], sb.d[1][b], sb.d[2][b]);
             tfar = sb.tmax[b];
@@ -345,7 +342,6 @@ struct ShadowSource {
             return true;
         }
         // sample_direct_light's return value: illum = 0; [illum = cA;] [illum = illum + cB]
-        const ShadowQueueB &sb = *sbp;
         V3 nee = v3(0.f);
         if (carry) {
             nee = v3(sb.ca[0][b], sb.ca[1][b], sb.ca[2][b]);
@@ -365,7 +361,7 @@ struct ShadowSource {
 };
 
 template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
-__global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, const ShadowQueueB *sb,
+__global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
@@ -942,7 +938,7 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
             persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, q, hits, pc, bounce);
 }
 
-void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, const ShadowQueueB *sb,
+void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,
                          float4 *radiance, PassCounters *pc, int bounce)
 {
 

@@ -137,15 +137,15 @@ struct LbvhTree {
 CRT_HD uint32_t lbvh_count(const LbvhTree &t, int32_t sub) { return sub >= 0 ? (uint32_t)(t.hi[sub] - t.lo[sub] + 1) : 1u; }
 CRT_HD const Aabb &lbvh_box(const LbvhTree &t, int32_t sub) { return sub >= 0 ? t.ibox[sub] : t.pbox[~sub]; }
 
-// The up to W subtrees that become the children of the wide node rooted at binary node k:
+// The up to four subtrees that become the children of the wide node rooted at binary node k:
 // k's two children, then repeatedly the child with the largest surface area that is not yet a
 // leaf of the wide tree (more than max_leaf items) is replaced by ITS two children.
-template <int W> CRT_HD int lbvh_wide_children_w(const LbvhTree &t, int32_t k, uint32_t max_leaf, int32_t sub[W])
+CRT_HD int lbvh_wide_children(const LbvhTree &t, int32_t k, uint32_t max_leaf, int32_t sub[BVH_WIDTH])
 {
     int n = 2;
     sub[0] = t.left[k];
     sub[1] = t.right[k];
-    while (n < W) {
+    while (n < BVH_WIDTH) {
         int best = -1;
         float best_area = -1.f;
         for (int c = 0; c < n; ++c) {
@@ -165,69 +165,6 @@ template <int W> CRT_HD int lbvh_wide_children_w(const LbvhTree &t, int32_t k, u
         sub[n++] = t.right[b];
     }
     return n;
-}
-CRT_HD int lbvh_wide_children(const LbvhTree &t, int32_t k, uint32_t max_leaf, int32_t sub[BVH_WIDTH])
-{
-    return lbvh_wide_children_w<BVH_WIDTH>(t, k, max_leaf, sub);
-}
-// 8-wide (crt_types.h QNode8; leaves of one item): the same subtrees with the inner ones first -- they become consecutive
-// node records -- and the single items behind them, both in the order the expansion produced them. Returns the number of
-// children, n_inner the number of inner ones.
-CRT_HD int lbvh_wide_children8(const LbvhTree &t, int32_t k, int32_t sub[BVH8_WIDTH], int &n_inner)
-{
-    int32_t raw[BVH8_WIDTH];
-    const int n = lbvh_wide_children_w<BVH8_WIDTH>(t, k, 1u, raw);
-    n_inner = 0;
-    for (int c = 0; c < n; ++c) {
-        if (raw[c] >= 0) {
-            sub[n_inner++] = raw[c];
-        }
-    }
-    int at = n_inner;
-    for (int c = 0; c < n; ++c) {
-        if (raw[c] < 0) {
-            sub[at++] = raw[c];
-        }
-    }
-    return n;
-}
-
-// The 64-byte 8-wide node from its children's full-precision boxes: each box rounded outward to the 16-bit frame (lo one
-// quantum below floor(), hi one above ceil(), like lbvh_quantise_child), then to the node's own 8-bit grid -- origin = the
-// smallest 16-bit coordinate of any child on the axis, cell = 2^e quanta with the smallest e that fits the largest one into
-// 8 bits -- outward again. ONE implementation for the host SAH builder, the serial linear build and the device kernels, so
-// the same tree is the same bytes wherever it was made.
-CRT_HD void lbvh_node8(QNode8 &q, const Aabb *boxes, int n_used, int n_inner, uint32_t node_base, uint32_t slot_base, const QFrame &f)
-{
-    uint32_t meta = (uint32_t)n_inner << 12;
-    for (int a = 0; a < 3; ++a) {
-        uint32_t lo[BVH8_WIDTH], hi[BVH8_WIDTH], org = 65535u, top = 0u;
-        for (int k = 0; k < n_used; ++k) {
-            double x = __builtin_floor(((double)boxes[k].lo[a] - (double)f.base[a]) / (double)f.step[a]) - 1.0;
-            lo[k] = (uint32_t)(x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x));
-            x = __builtin_ceil(((double)boxes[k].hi[a] - (double)f.base[a]) / (double)f.step[a]) + 1.0;
-            hi[k] = (uint32_t)(x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x));
-            hi[k] = hi[k] < lo[k] ? lo[k] : hi[k];
-            org = lo[k] < org ? lo[k] : org;
-            top = hi[k] > top ? hi[k] : top;
-        }
-        if (n_used == 0) {
-            org = 0u;
-        }
-        uint32_t e = 0;
-        while ((((top - org) + (1u << e) - 1u) >> e) > 255u) {
-            ++e;
-        }
-        q.org[a] = (uint16_t)org;
-        meta |= e << (4 * a);
-        for (int k = 0; k < BVH8_WIDTH; ++k) {
-            q.lo[a][k] = k < n_used ? (uint8_t)((lo[k] - org) >> e) : (uint8_t)255; // unused: inverted
-            q.hi[a][k] = k < n_used ? (uint8_t)(((hi[k] - org) + (1u << e) - 1u) >> e) : (uint8_t)0;
-        }
-    }
-    q.meta = (uint16_t)meta;
-    q.node_base = node_base;
-    q.slot_base = slot_base;
 }
 
 // One child quarter of a quantised node: the outward-rounded 16-bit box (bvh_builder.cpp quantise():

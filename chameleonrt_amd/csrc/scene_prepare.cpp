@@ -285,10 +285,6 @@ struct ScenePreparer {
     {
     }
 
-    // Scenes traversed as ONE tree (a single instance, a world tree) get 8-wide nodes; a top-level tree over instances and the
-    // BLASes under it stay 4-wide (crt_types.h QNode8: its top-level leaves are arbitrary references).
-    int tree_width() const { return two_level ? BVH_WIDTH : BVH8_WIDTH; }
-
     void phase(const char *what)
     {
         const auto now = std::chrono::high_resolution_clock::now();
@@ -483,7 +479,7 @@ struct ScenePreparer {
                 try {
                     built_on_device = device_build_mesh(build_device, s->geometries + md.first_geometry, md.n_geometries,
                                                         geom_slots.data() + md.first_geometry, (uint32_t)max_leaf,
-                                                        two_level ? 0 : MAX_TOP_NODES_HOST, tree_width(), db);
+                                                        two_level ? 0 : MAX_TOP_NODES_HOST, db);
                 } catch (const std::exception &e) { // e.g. out of device memory: the host builder still can
                     std::fprintf(stderr, "[crt_hip] %s -- building mesh %u on the host instead\n", e.what(), m);
                     (void)hipGetLastError();
@@ -529,10 +525,9 @@ struct ScenePreparer {
                 blas_bounds[m] = Aabb{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
                 continue;
             }
-            // one instance: the mesh's tree IS the scene's, 8-wide (crt_types.h QNode8); BLASes under a top-level tree: 4-wide
-            built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST, tree_width())
+            built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
-                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads, tree_width());
+                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
             blas_depth = std::max(blas_depth, built[m].max_depth);
             // slots in leaf order
             const size_t slot_base = slots.size();
@@ -792,8 +787,8 @@ struct ScenePreparer {
                     }
                 });
             }
-            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST, BVH8_WIDTH)
-                                      : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads, BVH8_WIDTH);
+            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
+                                      : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
             boxes = std::vector<Aabb>();
             blas_depth = tree.max_depth;
             slots.resize(recs.size());
@@ -806,11 +801,10 @@ struct ScenePreparer {
                 }
             });
             root_frame = make_frame(tree.bounds);
-            nodes.resize(tree.nodes8.size());
-            parallel_for(tree.nodes8.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
+            nodes.resize(tree.nodes.size());
+            parallel_for(tree.nodes.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; ++i) {
-                    const QNode8 q = quantise8(tree.nodes8[i], root_frame);
-                    std::memcpy(&nodes[i], &q, sizeof(q)); // (one array of 64-byte records, read as QNode8 by these scenes' kernels)
+                    nodes[i] = quantise(tree.nodes[i], root_frame);
                 }
             });
             n_top = tree.n_top;
@@ -992,15 +986,17 @@ struct ScenePreparer {
     // is the miss shader's checkerboard, as from the reference's empty Embree scene.
     void make_empty_tree()
     {
-        BvhNode8 nd;
+        BvhNode nd;
         std::memset(&nd, 0, sizeof(nd));
-        for (int k = 0; k < BVH8_WIDTH; ++k) {
+        for (int k = 0; k < BVH_WIDTH; ++k) {
             nd.c[k] = EMPTY_CHILD;
         }
         root_frame = make_frame(Aabb{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
-        const QNode8 q = quantise8(nd, root_frame); // eight unused slots: no ray enters an inverted box
-        ps->nodes.assign(1, QNode{});
-        std::memcpy(&ps->nodes[0], &q, sizeof(q));
+        QNode q = quantise(nd, root_frame);
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            q.child[k].ref = 0; // (never followed: no ray enters an inverted box)
+        }
+        ps->nodes.assign(1, q);
         root = 0;
         n_top = 1;
         blas_depth = 1;
@@ -1024,34 +1020,10 @@ struct ScenePreparer {
                 return (int32_t)~((((x >> 3) + tri_base) << 3) | (x & 7u));
             };
             for (QNode q : built_q[m]) { // device-built: quantised already, references local to the mesh
-                if (tree_width() == BVH8_WIDTH) { // 8-wide records: the two block bases
-                    QNode8 q8;
-                    std::memcpy(&q8, &q, sizeof(q8));
-                    q8.node_base += (uint32_t)node_base;
-                    q8.slot_base += tri_base;
-                    std::memcpy(&q, &q8, sizeof(q8));
-                } else {
-                    for (int k = 0; k < BVH_WIDTH; ++k) {
-                        q.child[k].ref = rebase(q.child[k].ref);
-                    }
+                for (int k = 0; k < BVH_WIDTH; ++k) {
+                    q.child[k].ref = rebase(q.child[k].ref);
                 }
                 nodes.push_back(q);
-            }
-            if (!built[m].nodes8.empty()) { // 8-wide (a single-instance scene): references local to the mesh -> global, then the two bases
-                const size_t base8 = nodes.size();
-                nodes.resize(base8 + built[m].nodes8.size());
-                parallel_for(built[m].nodes8.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
-                    for (size_t i = lo; i < hi; ++i) {
-                        BvhNode8 nd = built[m].nodes8[i];
-                        for (int k = 0; k < BVH8_WIDTH; ++k) {
-                            if (nd.c[k] != EMPTY_CHILD) {
-                                nd.c[k] = rebase(nd.c[k]);
-                            }
-                        }
-                        const QNode8 q = quantise8(nd, blas_frame[m]);
-                        std::memcpy(&nodes[base8 + i], &q, sizeof(q));
-                    }
-                });
             }
             const size_t host_base = nodes.size();
             nodes.resize(host_base + built[m].nodes.size());

@@ -20,12 +20,11 @@ namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
 // vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 17 for the single-level kernels next to 3 dwords of cold state (26 KB per block; 16 -> 19
-// entries measured C4F -2.2 %, C3 -2 % frame time before two of them went to the hit's u, v),
+// budget of 6 blocks per CU allows: 19 for the single-level kernels (26 KB per block; 16 -> 19: C4F -2.2 %, C3 -2 % frame time),
 // 16 for the two-level ones,
 // which also keep 9 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 17
+#define CRT_LDS_STACK 19
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
 #define CRT_LDS_STACK_TWO_LEVEL 16
@@ -37,7 +36,7 @@ namespace crt {
 #endif
 // levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
 constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
-constexpr int lds_cold_of(int levels) { return levels == 1 ? 9 : levels == 2 ? 6 : 3; } // dwords of cold per-ray state per lane in LDS
+constexpr int lds_cold_of(int levels) { return levels == 1 ? 9 : levels == 2 ? 6 : 1; } // dwords of cold per-ray state per lane in LDS
 constexpr int levels_of(bool two_level, bool inst_tris) { return two_level ? 1 : inst_tris ? 2 : 0; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
 // and compact per wave, so deep traversals stay within a few pages. Its depth is a property of the
@@ -286,18 +285,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     V3 o = v3(0.f), d = v3(0.f);                 // ray in the space being traversed
     SlabRay sr;                                  // that ray in the fixed-point frame of the current BVH
     sr.qa[0] = sr.qa[1] = sr.qa[2] = sr.qb[0] = sr.qb[1] = sr.qb[2] = 0.f;
-    // the ray's far end: a constant for the closest-hit rays of a frame; a register -- or, in the occlusion kernel of a single
-    // tree, which the 8-wide inner step leaves no register for, a cold LDS slot read once per leaf step (slot 1: no u, v there)
-    constexpr bool TFAR_IN_LDS = ANY_HIT && !TWO_LEVEL && !INST_TRIS && !Source::CONST_TFAR;
-    float tfar_reg = 0.f;
-    auto tfar_of_ray = [&]() -> float { return TFAR_IN_LDS ? st.cold[1 * st.stride] : tfar_reg; };
-    auto set_tfar_of_ray = [&](float x) {
-        if (TFAR_IN_LDS) {
-            st.cold[1 * st.stride] = x;
-        } else {
-            tfar_reg = x;
-        }
-    };
+    float tfar_var = 0.f;
     RayHit hit;
     hit.t = 0.f;
     hit.u = hit.v = 0.f;
@@ -306,14 +294,10 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     // retires: cold state, kept in LDS next to the world-space ray (slots 6, 7). Its geomID / primID are only ever
     // needed on an EXACT tie in t between two hits of one instance -- two coincident triangles -- and are then read back
     // from the best hit's leaf slot rather than carried in two registers through every step of every ray.
-    // (one instance: the same, slots 1 and 2 -- with the 8-wide inner step the kernels of a single tree need the two registers.
-    // A world tree's kernels keep u, v in registers: their LDS is full and they fit the register budget as they are.)
-    constexpr bool UV_IN_LDS = TWO_LEVEL || !INST_TRIS;
-    constexpr int UV_SLOT = TWO_LEVEL ? 6 : 1;
     auto store_hit_cold = [&](float u, float v) {
-        if (UV_IN_LDS) {
-            st.cold[UV_SLOT * st.stride] = u;
-            st.cold[(UV_SLOT + 1) * st.stride] = v;
+        if (TWO_LEVEL) {
+            st.cold[6 * st.stride] = u;
+            st.cold[7 * st.stride] = v;
         } else {
             hit.u = u;
             hit.v = v;
@@ -389,7 +373,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             xf_space = 1u;
         }
         set_frame(sc.root_frame);
-        hit.t = Source::CONST_TFAR ? RAY_TFAR : tfar_of_ray();
+        hit.t = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
         hit.u = hit.v = 0.f;
         hit.tri = -1;
         hit.inst = -1;
@@ -417,11 +401,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
     auto pool_take = [&](uint32_t want) -> uint32_t {
         if (pool_next == pool_end && !exhausted) {
             uint32_t base = 0;
-            // (the lane id is worked out HERE, by an asm the compiler may not hoist: as a common subexpression it stayed live
-            // through the whole traversal loop for this one use per 128 rays and cost the tightest kernel a scratch slot)
-            uint32_t lane_here;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
-            if (lane_here == 0) {
+            if (tv_lane_id() == 0) {
                 base = atomicAdd(cursor, (uint32_t)CRT_POOL_CHUNK);
             }
             base = __builtin_amdgcn_readfirstlane(base);
@@ -451,9 +431,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     if (rank < take) {
                         ray = (int32_t)(pool_next + rank);
                         V3 wo, wd;
-                        float tfar_new = 0.f;
-                        src.load((uint32_t)ray, wo, wd, tfar_new);
-                        set_tfar_of_ray(tfar_new);
+                        src.load((uint32_t)ray, wo, wd, tfar_var);
                         set_world(wo, wd);
                         if (Source::MULTI_RAY) {
                             set_item_state(0u);
@@ -520,70 +498,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     ++n_nodes;
                     ++ray_nodes;
                 }
-                if constexpr (!TWO_LEVEL) {
-                    // ---- 8-wide node (crt_types.h QNode8): k0 = {org.x | org.y << 16, org.z | meta << 16, node_base, slot_base},
-                    // k1..k3 = the 48 plane bytes: lo[axis][child] then hi[axis][child], four children per dword.
-                    // A plane at byte b of axis a has ray parameter fma(b, sa, ta): ta = the parameter of the node grid's
-                    // origin plane, sa = qa * 2^e (exact scaling). The near plane of an axis is lo for qa >= 0, hi otherwise.
-                    const uint32_t meta = k0.y >> 16, n_inner = meta >> 12;
-                    const float tax = __builtin_fmaf((float)(k0.x & 0xffffu), sr.qa[0], sr.qb[0]);
-                    const float tay = __builtin_fmaf((float)(k0.x >> 16), sr.qa[1], sr.qb[1]);
-                    const float taz = __builtin_fmaf((float)(k0.y & 0xffffu), sr.qa[2], sr.qb[2]);
-                    const float sax = ldexpf(sr.qa[0], (int)(meta & 15u)), say = ldexpf(sr.qa[1], (int)((meta >> 4) & 15u)),
-                                saz = ldexpf(sr.qa[2], (int)((meta >> 8) & 15u));
-                    const bool neg_x = sr.qa[0] < 0.f, neg_y = sr.qa[1] < 0.f, neg_z = sr.qa[2] < 0.f;
-                    // [half]: children 0-3, 4-7
-                    const uint32_t nx[2] = {neg_x ? k2.z : k1.x, neg_x ? k2.w : k1.y}, fx[2] = {neg_x ? k1.x : k2.z, neg_x ? k1.y : k2.w};
-                    const uint32_t ny[2] = {neg_y ? k3.x : k1.z, neg_y ? k3.y : k1.w}, fy[2] = {neg_y ? k1.z : k3.x, neg_y ? k1.w : k3.y};
-                    const uint32_t nz[2] = {neg_z ? k3.z : k2.x, neg_z ? k3.w : k2.y}, fz[2] = {neg_z ? k2.x : k3.z, neg_z ? k2.y : k3.w};
-                    const float tmax = hit.t;
-                    auto ub = [](uint32_t w, int b) -> float { return (float)((w >> (8 * b)) & 0xffu); };
-                    // sort key of child `slot`: its entry distance with the slot in the three lowest mantissa bits, all-ones if missed
-                    auto key8 = [&](int half, int b, uint32_t slot) -> uint32_t {
-                        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ub(nx[half], b), sax, tax), __builtin_fmaf(ub(ny[half], b), say, tay)),
-                                                         __builtin_fmaxf(__builtin_fmaf(ub(nz[half], b), saz, taz), tnear));
-                        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(ub(fx[half], b), sax, tax), __builtin_fmaf(ub(fy[half], b), say, tay)),
-                                                         __builtin_fminf(__builtin_fmaf(ub(fz[half], b), saz, taz), tmax));
-                        return tn <= tf * 1.0000004f ? ((__float_as_uint(tn) & 0x7ffffff8u) | slot) : 0xffffffffu;
-                    };
-                    const uint32_t s0 = key8(0, 0, 0u), s1 = key8(0, 1, 1u), s2 = key8(0, 2, 2u), s3 = key8(0, 3, 3u);
-                    const uint32_t s4 = key8(1, 0, 4u), s5 = key8(1, 1, 5u), s6 = key8(1, 2, 6u), s7 = key8(1, 3, 7u);
-                    const uint32_t nearest = min(min(min(s0, s1), min(s2, s3)), min(min(s4, s5), min(s6, s7)));
-                    if (nearest == 0xffffffffu) {
-                        pop_next();
-                    } else {
-                        // child `slot` of this node: an inner node of its block, or the leaf slot of its block (one slot per leaf)
-                        auto ref8 = [&](uint32_t slot) -> int32_t {
-                            return slot < n_inner ? (int32_t)(k0.z + slot) : (int32_t)~((k0.w + (slot - n_inner)) << 3);
-                        };
-                        // nearest child first; the other entered children are stacked in slot order (lowest slot on top)
-                        if (s7 != 0xffffffffu && s7 != nearest) {
-                            st.push(ref8(7u));
-                        }
-                        if (s6 != 0xffffffffu && s6 != nearest) {
-                            st.push(ref8(6u));
-                        }
-                        if (s5 != 0xffffffffu && s5 != nearest) {
-                            st.push(ref8(5u));
-                        }
-                        if (s4 != 0xffffffffu && s4 != nearest) {
-                            st.push(ref8(4u));
-                        }
-                        if (s3 != 0xffffffffu && s3 != nearest) {
-                            st.push(ref8(3u));
-                        }
-                        if (s2 != 0xffffffffu && s2 != nearest) {
-                            st.push(ref8(2u));
-                        }
-                        if (s1 != 0xffffffffu && s1 != nearest) {
-                            st.push(ref8(1u));
-                        }
-                        if (s0 != 0xffffffffu && s0 != nearest) {
-                            st.push(ref8(0u));
-                        }
-                        cur = ref8(nearest & 7u);
-                    }
-                } else {
                 // Visit order: children whose box the ray enters, nearest entry first. The sort key
                 // is the entry distance with its two lowest mantissa bits replaced by the child
                 // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
@@ -654,7 +568,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     }
                     cur = ref_of(b0);
                 }
-                } // 4-wide node
             }
             pf_mark(1, n_inner);
         }
@@ -703,7 +616,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 const bool have_next = st.sp > 0;
                 const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
                 // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
-                const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_of_ray();
+                const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
                 auto test_slot = [&](uint32_t slot) {
                     if (COUNTERS) {
                         ++n_slots;
@@ -820,9 +733,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 }
             }
             ray_nodes = 0;
-            if (UV_IN_LDS) {
-                hit.u = st.cold[UV_SLOT * st.stride];
-                hit.v = st.cold[(UV_SLOT + 1) * st.stride];
+            if (TWO_LEVEL) {
+                hit.u = st.cold[6 * st.stride];
+                hit.v = st.cold[7 * st.stride];
             }
             V3 wo = world_org(), wd = world_dir();
             uint32_t stage = 0, carry = 0;
@@ -831,11 +744,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 stage = is & 1u;
                 carry = is >> 1;
             }
-            float tfar_next = 0.f;
-            const bool again = src.retire((uint32_t)ray, stage, hit, wo, wd, tfar_next, carry);
-            if (again) {
-                set_tfar_of_ray(tfar_next);
-            }
+            const bool again = src.retire((uint32_t)ray, stage, hit, wo, wd, tfar_var, carry);
             if (Source::MULTI_RAY && again) {
                 set_item_state(stage | (carry << 1));
             }

@@ -1814,8 +1814,7 @@ extern "C" int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, 
 }
 
 // Foreign (product) BVH walk with the product's documented visit rule (DESIGN.md "Traversal
-// rule"). Scenes traversed as ONE tree (levels 0 and 2) have 8-wide nodes (FNode8 below); scenes with a top-level tree
-// over instances (levels 1) 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
+// rule"): 64-byte 4-wide nodes, one 16-byte quarter per child {x: lo|hi, y: lo|hi, z: lo|hi as uint16
 // fixed point, ref}; a plane at fixed-point coordinate q has ray parameter fma(q, step*inv, (base - o)*inv);
 // ref >= 0 inner node index; ref < 0 leaf with x = ~ref, first = x >> 3, count = (x & 7) + 1;
 // an unused slot holds an inverted box (lo > hi) and a copy of slot 0's reference; a leaf is `count`
@@ -1835,16 +1834,6 @@ struct FChild {
 };
 struct FNode {
     FChild child[4];
-};
-// the 8-wide node of scenes traversed as one tree (chameleonrt_amd/csrc/crt_types.h QNode8): the children's boxes as 8-bit
-// offsets on a per-node grid inside the 16-bit frame -- plane = org + (byte << e) quanta -- inner children consecutive node
-// records from node_base (the first n_inner children), leaf children consecutive leaf slots from slot_base, one slot per
-// leaf; an unused child has lo = 255, hi = 0
-struct FNode8 {
-    uint16_t org[3];
-    uint16_t meta; // e_x | e_y << 4 | e_z << 8 | n_inner << 12
-    uint32_t node_base, slot_base;
-    uint8_t lo[3][8], hi[3][8];
 };
 // the product's 64-byte leaf slot (chameleonrt_amd/csrc/crt_types.h LeafSlot): one triangle A = (v[0], v[1], v[2]) or,
 // prim1 != 0xffffffff, also triangle B = (v[s0], v[s1], v[s2]) with the three 2-bit selectors in bits 26..31 of geom_sel
@@ -1871,7 +1860,7 @@ inline f3 fxfm_vector(const float *m, f3 v)
     return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
                m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
-static_assert(sizeof(FNode) == 64 && sizeof(FNode8) == 64 && sizeof(FSlot) == 64 && sizeof(FInst) == 128, "product BVH record sizes");
+static_assert(sizeof(FNode) == 64 && sizeof(FSlot) == 64 && sizeof(FInst) == 128, "product BVH record sizes");
 constexpr int32_t F_SENTINEL = (int32_t)0x80000000;
 inline bool fbox(const uint16_t q[3][2], f3 qa, f3 qb, float tmin, float tmax, float &tn)
 {
@@ -1939,62 +1928,7 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
             int32_t cur = root;
             bool done = false;
             while (!done) {
-                if (cur >= 0 && !two_level) {
-                    // 8-wide node, the kernels' arithmetic (traverse.h): t(byte) = fma(byte, qa * 2^e, fma(org, qa, qb)); the
-                    // near plane of an axis is lo for qa >= 0 and hi otherwise, so an inverted (unused) box rejects itself;
-                    // key = entry distance with the slot in its three lowest bits; nearest first, the rest stacked in slot
-                    // order (the only rule the 8-wide kernels implement: child_order is ignored here)
-                    const FNode8 &nd = reinterpret_cast<const FNode8 *>(nodes)[cur];
-                    ++nv;
-                    const uint32_t n_inner = nd.meta >> 12;
-                    const float qav[3] = {qa.x, qa.y, qa.z}, qbv[3] = {qb.x, qb.y, qb.z};
-                    float ta[3], sa[3];
-                    for (int a = 0; a < 3; ++a) {
-                        ta[a] = std::fma((float)nd.org[a], qav[a], qbv[a]);
-                        sa[a] = std::ldexp(qav[a], (int)((nd.meta >> (4 * a)) & 15u));
-                    }
-                    uint32_t keys[8];
-                    int n_hit = 0;
-                    for (uint32_t k = 0; k < 8; ++k) {
-                        float tn = tmin[i], tf = best;
-                        float tnx[3], tfx[3];
-                        for (int a = 0; a < 3; ++a) {
-                            const bool neg = std::signbit(qav[a]);
-                            tnx[a] = std::fma((float)(neg ? nd.hi[a][k] : nd.lo[a][k]), sa[a], ta[a]);
-                            tfx[a] = std::fma((float)(neg ? nd.lo[a][k] : nd.hi[a][k]), sa[a], ta[a]);
-                        }
-                        tn = std::fmax(std::fmax(tnx[0], tnx[1]), std::fmax(tnx[2], tmin[i]));
-                        tf = std::fmin(std::fmin(tfx[0], tfx[1]), std::fmin(tfx[2], best));
-                        if (tn <= tf * 1.0000004f) {
-                            uint32_t tb;
-                            std::memcpy(&tb, &tn, 4);
-                            keys[n_hit++] = (tb & 0x7ffffff8u) | k;
-                        }
-                    }
-                    if (n_hit > 0) {
-                        auto ref8 = [&](uint32_t slot) -> int32_t {
-                            return slot < n_inner ? (int32_t)(nd.node_base + slot) : (int32_t)~((nd.slot_base + (slot - n_inner)) << 3);
-                        };
-                        int nearest = 0;
-                        for (int k = 1; k < n_hit; ++k) {
-                            if (keys[k] < keys[nearest]) {
-                                nearest = k;
-                            }
-                        }
-                        for (int k = n_hit - 1; k >= 0; --k) {
-                            if (k != nearest) {
-                                stack[sp++] = ref8(keys[k] & 7u);
-                            }
-                        }
-                        cur = ref8(keys[nearest] & 7u);
-                        ms = std::max<uint32_t>(ms, (uint32_t)sp);
-                        if (sp + 16 > stack.size()) {
-                            bad_t[tid] = 1;
-                            done = true;
-                        }
-                        continue;
-                    }
-                } else if (cur >= 0) {
+                if (cur >= 0) {
                     const FNode &nd = nodes[cur];
                     ++nv;
                     if (two_level && in_blas) {

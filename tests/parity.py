@@ -18,17 +18,6 @@ def slot_triangles(bvh):
     return 1 + (bvh["tris"][:, 14].view(np.uint32) != 0xffffffff).astype(np.int64)
 
 
-def wide8_children(bvh):
-    """(inner children, used children) per node of an 8-wide tree (levels 0 / 2; crt_types.h QNode8): bvh["nodes"] rows are the 16
-    dwords {org.x | org.y << 16, org.z | meta << 16, node_base, slot_base, 48 plane bytes: lo[axis][child], hi[axis][child]};
-    an unused child has lo = 255 and hi = 0."""
-    nodes = bvh["nodes"]
-    n_inner = (nodes[:, 1] >> 28).astype(np.int64)
-    planes = nodes[:, 4:].copy().view(np.uint8).reshape(-1, 2, 3, 8)  # [node][lo|hi][axis][child]
-    used = (planes[:, 0, 0, :] <= planes[:, 1, 0, :])
-    return n_inner, used.sum(axis=1).astype(np.int64)
-
-
 def probe_rays(scene, n, seed=0, spread=0.3):
     """Half camera-cone rays, half uniformly random directions from points around the scene."""
     rng = np.random.default_rng(seed)
