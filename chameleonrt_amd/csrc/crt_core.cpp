@@ -106,11 +106,31 @@ struct crt_hip_ctx {
     uint32_t flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // Occlusion rays of bounce b and closest-hit rays of bounce b+1 are independent: with overlap on (the default),
-    // the occlusion launch goes to aux_stream so that its waves fill the CUs the other launch's tail
+    // the occlusion launch goes to the lane's aux stream so that its waves fill the CUs the other launch's tail
     // leaves idle (and vice versa). It needs its own traversal-stack spill slab.
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;
+    // PASS LANES. A frame is a chain of 17 dependent launches per pass, and every traversal launch ends with a few hundred
+    // microseconds in which its longest rays finish on an otherwise idle chip -- a fixed cost per launch that does not
+    // shrink with the ray count (a GPU's share of a frame at N = 8 is mostly that). Passes are independent (disjoint
+    // pixel slots), so with the overlapped schedule a frame is cut into at least n_lanes passes and pass p runs on lane
+    // p % n_lanes: its own queues, counters, streams and spill slabs. The launches of one lane fill the tails of the other's.
+    // Results do not depend on how a frame is cut into passes (tests/test_gpu_edge_cases.py, test_gpu_scale.py).
+    struct PassLane {
+        DeviceBuffer queue_mem, pc;
+        PathQueue q[2]{};
+        HitBuf hits{};
+        ShadowQueueA sa{};
+        ShadowQueueB sb{};
+        float4 *radiance = nullptr;
+        hipStream_t main = nullptr; // lane 0: the context's stream (not owned)
+        hipStream_t aux = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+        bool owns_main = false;
+    };
+    static constexpr int MAX_LANES = 4;
+    PassLane lanes[MAX_LANES];
+    int n_lanes = 1;
+    hipEvent_t ev_begin = nullptr;
     int n_cus = 256;
     std::string name, err;
     int rank = 0, world = 1;
@@ -137,13 +157,7 @@ struct crt_hip_ctx {
     uint32_t stack_need = 0; // traversal-stack entries the deepest path of this scene's BVH can need
 
     // wavefront state
-    uint64_t capacity = 0; // paths per pass
-    DeviceBuffer d_queue_mem, d_pc;
-    PathQueue q[2]{};
-    HitBuf hits{};
-    ShadowQueueA sa{};
-    ShadowQueueB sb{};
-    float4 *radiance = nullptr;
+    uint64_t capacity = 0; // paths per pass (every lane's queues hold that many)
     PassCounters *h_pc = nullptr; // pinned, one per pass
     uint32_t h_pc_slots = 0;
     std::vector<hipEvent_t> events;
@@ -156,10 +170,21 @@ struct crt_hip_ctx {
         if (h_pc) {
             (void)hipHostFree(h_pc);
         }
-        if (aux_stream) {
-            (void)hipStreamDestroy(aux_stream);
-            (void)hipEventDestroy(ev_fork);
-            (void)hipEventDestroy(ev_join);
+        for (PassLane &l : lanes) {
+            if (l.aux) {
+                (void)hipStreamDestroy(l.aux);
+                (void)hipEventDestroy(l.ev_fork);
+                (void)hipEventDestroy(l.ev_join);
+            }
+            if (l.ev_done) {
+                (void)hipEventDestroy(l.ev_done);
+            }
+            if (l.owns_main && l.main) {
+                (void)hipStreamDestroy(l.main);
+            }
+        }
+        if (ev_begin) {
+            (void)hipEventDestroy(ev_begin);
         }
         if (own_stream) {
             (void)hipStreamDestroy(own_stream);
@@ -206,11 +231,76 @@ uint64_t default_capacity()
     return 32ull << 20; // 32 Mi paths ~ 7.7 GiB of queue state, a sliver of 288 GB
 }
 
-// carve the SoA queues out of one allocation
+// carve a lane's SoA queues out of one allocation
+void carve_queues(crt_hip_ctx::PassLane &l, uint64_t cap)
+{
+    const size_t n_fields = 2 * 11 + 8 + 12 + 18 + 4; // PathQueue x 2, HitBuf records, ShadowQueueA, ShadowQueueB, radiance
+    l.queue_mem.alloc(n_fields * cap * sizeof(float));
+    uint32_t *base = l.queue_mem.as<uint32_t>();
+    size_t k = 0;
+    auto f32 = [&]() { return reinterpret_cast<float *>(base + (k++) * cap); };
+    auto u32 = [&]() { return base + (k++) * cap; };
+    auto i32 = [&]() { return reinterpret_cast<int32_t *>(base + (k++) * cap); };
+    for (int qi = 0; qi < 2; ++qi) {
+        for (int a = 0; a < 3; ++a) {
+            l.q[qi].o[a] = f32();
+        }
+        for (int a = 0; a < 3; ++a) {
+            l.q[qi].d[a] = f32();
+        }
+        l.q[qi].path = u32();
+        l.q[qi].rng = u32();
+        for (int a = 0; a < 3; ++a) {
+            l.q[qi].tp[a] = f32();
+        }
+    }
+    l.hits.rec = reinterpret_cast<float4 *>(base + k * cap); // 8 dwords per ray (cap is a multiple of 64: 16-byte aligned)
+    k += 8;
+    l.hits.inst_debug = nullptr;
+    for (int a = 0; a < 3; ++a) {
+        l.sa.o[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        l.sa.d[a] = f32();
+    }
+    l.sa.tmax = f32();
+    for (int a = 0; a < 3; ++a) {
+        l.sa.c[a] = f32();
+    }
+    l.sa.path = u32();
+    l.sa.bslot = i32();
+    for (int a = 0; a < 3; ++a) {
+        l.sb.o[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        l.sb.d[a] = f32();
+    }
+    l.sb.tmax = f32();
+    for (int a = 0; a < 3; ++a) {
+        l.sb.ca[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        l.sb.cb[a] = f32();
+    }
+    for (int a = 0; a < 3; ++a) {
+        l.sb.tp[a] = f32();
+    }
+    l.sb.path = u32();
+    l.sb.reserved = i32();
+    l.radiance = reinterpret_cast<float4 *>(base + k * cap);
+    l.pc.alloc(sizeof(PassCounters));
+}
+
+// Paths per pass, and the queues of every lane. One pass if the frame fits and there is one lane; with several lanes
+// the frame is cut into at least that many passes (when it is large enough for the cut to be worth a launch sequence).
 void setup_queues(crt_hip_ctx *c)
 {
     const uint64_t total_slots = (uint64_t)c->n_local_tiles * TILE_PIXELS;
-    uint64_t cap = std::min<uint64_t>(default_capacity(), total_slots * c->spp);
+    const uint64_t total_paths = total_slots * c->spp;
+    uint64_t cap = std::min<uint64_t>(default_capacity(), total_paths);
+    if (c->n_lanes > 1 && total_paths >= ((uint64_t)c->n_lanes << 18)) {
+        cap = std::min<uint64_t>(cap, (total_paths + (uint64_t)c->n_lanes - 1) / (uint64_t)c->n_lanes + 64ull * c->spp);
+    }
     cap = std::min<uint64_t>(cap, 1ull << PATH_ID_BITS); // a path's index shares its queue word with its ray count (crt_types.h)
     const uint64_t slots_per_pass = std::max<uint64_t>(64, (cap / c->spp) / 64 * 64);
     cap = slots_per_pass * c->spp;
@@ -218,63 +308,16 @@ void setup_queues(crt_hip_ctx *c)
         throw std::runtime_error("samples_per_pixel too large: 64 pixels x spp paths must fit one pass of 2^27 paths");
     }
     c->capacity = cap;
-    const size_t n_fields = 2 * 11 + 8 + 12 + 18 + 4; // PathQueue x 2, HitBuf records, ShadowQueueA, ShadowQueueB, radiance
-    c->d_queue_mem.alloc(n_fields * cap * sizeof(float));
-    uint32_t *base = c->d_queue_mem.as<uint32_t>();
-    size_t k = 0;
-    auto f32 = [&]() { return reinterpret_cast<float *>(base + (k++) * cap); };
-    auto u32 = [&]() { return base + (k++) * cap; };
-    auto i32 = [&]() { return reinterpret_cast<int32_t *>(base + (k++) * cap); };
-    for (int qi = 0; qi < 2; ++qi) {
-        for (int a = 0; a < 3; ++a) {
-            c->q[qi].o[a] = f32();
-        }
-        for (int a = 0; a < 3; ++a) {
-            c->q[qi].d[a] = f32();
-        }
-        c->q[qi].path = u32();
-        c->q[qi].rng = u32();
-        for (int a = 0; a < 3; ++a) {
-            c->q[qi].tp[a] = f32();
-        }
-    }
-    c->hits.rec = reinterpret_cast<float4 *>(base + k * cap); // 8 dwords per ray (cap is a multiple of 64: 16-byte aligned)
-    k += 8;
-    c->hits.inst_debug = nullptr;
-    for (int a = 0; a < 3; ++a) {
-        c->sa.o[a] = f32();
-    }
-    for (int a = 0; a < 3; ++a) {
-        c->sa.d[a] = f32();
-    }
-    c->sa.tmax = f32();
-    for (int a = 0; a < 3; ++a) {
-        c->sa.c[a] = f32();
-    }
-    c->sa.path = u32();
-    c->sa.bslot = i32();
-    for (int a = 0; a < 3; ++a) {
-        c->sb.o[a] = f32();
-    }
-    for (int a = 0; a < 3; ++a) {
-        c->sb.d[a] = f32();
-    }
-    c->sb.tmax = f32();
-    for (int a = 0; a < 3; ++a) {
-        c->sb.ca[a] = f32();
-    }
-    for (int a = 0; a < 3; ++a) {
-        c->sb.cb[a] = f32();
-    }
-    for (int a = 0; a < 3; ++a) {
-        c->sb.tp[a] = f32();
-    }
-    c->sb.path = u32();
-    c->sb.reserved = i32();
-    c->radiance = reinterpret_cast<float4 *>(base + k * cap);
-    c->d_pc.alloc(sizeof(PassCounters));
-    const uint64_t total_paths = total_slots * c->spp;
     const uint32_t n_pass = (uint32_t)((total_paths + cap - 1) / cap);
+    const int used_lanes = (int)std::min<uint32_t>((uint32_t)c->n_lanes, std::max<uint32_t>(1u, n_pass));
+    for (int i = 0; i < crt_hip_ctx::MAX_LANES; ++i) {
+        if (i < used_lanes) {
+            carve_queues(c->lanes[i], cap);
+        } else {
+            c->lanes[i].queue_mem.release();
+            c->lanes[i].pc.release();
+        }
+    }
     if (c->h_pc) {
         (void)hipHostFree(c->h_pc);
         c->h_pc = nullptr;
@@ -338,10 +381,23 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         if (const char *e = std::getenv("CRT_HIP_OVERLAP")) {
             c->overlap = std::atoi(e) != 0;
         }
-        if (c->overlap) {
-            HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        c->n_lanes = c->overlap ? 2 : 1; // CRT_HIP_LANES: passes in flight (1 .. 4)
+        if (const char *e = std::getenv("CRT_HIP_LANES")) {
+            c->n_lanes = std::min(std::max(std::atoi(e), 1), (int)crt_hip_ctx::MAX_LANES);
+        }
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
+        for (int i = 0; i < c->n_lanes; ++i) {
+            crt_hip_ctx::PassLane &l = c->lanes[i];
+            if (i > 0) {
+                HIP_CHECK(hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking));
+                l.owns_main = true;
+                HIP_CHECK(hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
+            }
+            if (c->overlap) {
+                HIP_CHECK(hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming));
+            }
         }
         c->stream = c->own_stream;
     } catch (const HipError &err) {
@@ -477,7 +533,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     sv.spill_depth = std::max<uint32_t>(8u, ps.stack_need > lds_stack ? ps.stack_need - lds_stack : 0u);
     sv.spill_stride = traversal_grid_threads(ctx->n_cus);
     const size_t spill_words = (size_t)sv.spill_stride * sv.spill_depth;
-    ctx->d_spill.alloc((ctx->overlap ? 2 : 1) * spill_words * sizeof(int32_t));
+    ctx->d_spill.alloc((size_t)(ctx->overlap ? 2 : 1) * (size_t)ctx->n_lanes * spill_words * sizeof(int32_t)); // a slab per stream
     sv.stack_spill = ctx->d_spill.as<int32_t>();
     sv.root = ps.root;
     sv.two_level = ps.two_level;
@@ -730,65 +786,79 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         };
 
         const bool overlap = ctx->overlap;
-        LaunchCfg aux_cfg = cfg;
-        aux_cfg.stream = ctx->aux_stream;
-        SceneView aux_sv = ctx->sv;
-        if (overlap) {
-            aux_sv.stack_spill += (size_t)aux_sv.spill_stride * aux_sv.spill_depth;
-        }
         // The compact tile buffer alternates with every RENDERED frame, whatever frame_id does (a moving camera resets
         // frame_id to 0 every frame): the asynchronous gather of the previous frame may still be reading the other one.
         const int tile_buf = ctx->tile_fb_last ^ 1;
         const auto t0 = std::chrono::high_resolution_clock::now();
+        const uint32_t n_pass_frame = (uint32_t)((total_slots + slots_per_pass - 1) / slots_per_pass);
+        const int used_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, std::max<uint32_t>(1u, n_pass_frame));
+        ctx->lanes[0].main = ctx->stream;
+        if (used_lanes > 1) { // the other lanes start where the caller's stream stands
+            HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+            for (int i = 1; i < used_lanes; ++i) {
+                HIP_CHECK(hipStreamWaitEvent(ctx->lanes[i].main, ctx->ev_begin, 0));
+            }
+        }
+        const size_t slab = (size_t)ctx->sv.spill_stride * ctx->sv.spill_depth; // traversal-stack spill slab of one stream
         uint32_t pass = 0;
         for (uint64_t slot0 = 0; slot0 < total_slots; slot0 += slots_per_pass, ++pass) {
+            const int li = (int)(pass % (uint32_t)used_lanes);
+            crt_hip_ctx::PassLane &ln = ctx->lanes[li];
+            LaunchCfg lcfg = cfg, aux_cfg = cfg;
+            lcfg.stream = ln.main;
+            aux_cfg.stream = ln.aux;
+            SceneView sv = ctx->sv, aux_sv = ctx->sv;
+            sv.stack_spill += slab * (size_t)((overlap ? 2 : 1) * li);
+            aux_sv.stack_spill = sv.stack_spill + (overlap ? slab : 0);
             const uint32_t n_slots = (uint32_t)std::min<uint64_t>(slots_per_pass, total_slots - slot0);
             const uint32_t n_paths = n_slots * ctx->spp;
-            PassCounters *d_pc = ctx->d_pc.as<PassCounters>();
-            HIP_CHECK(hipMemsetAsync(d_pc, 0, sizeof(PassCounters), ctx->stream));
+            PassCounters *d_pc = ln.pc.as<PassCounters>();
+            HIP_CHECK(hipMemsetAsync(d_pc, 0, sizeof(PassCounters), ln.main));
             if (cfg.counters) { // atomicMin targets start at all-ones
-                HIP_CHECK(hipMemsetAsync(d_pc->t_start, 0xff, 2 * MAX_PATH_DEPTH * sizeof(unsigned long long), ctx->stream));
+                HIP_CHECK(hipMemsetAsync(d_pc->t_start, 0xff, 2 * MAX_PATH_DEPTH * sizeof(unsigned long long), ln.main));
             }
-            mark(2, ctx->stream, -1);
-            launch_raygen(cfg, vp, d_tiles, (uint32_t)slot0, n_paths, ctx->q[0], ctx->radiance, d_pc);
-            mark_end(ctx->stream);
+            mark(2, ln.main, -1);
+            launch_raygen(lcfg, vp, d_tiles, (uint32_t)slot0, n_paths, ln.q[0], ln.radiance, d_pc);
+            mark_end(ln.main);
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 if (!overlap || b == 0) {
-                    mark(0, ctx->stream, b);
-                    launch_trace_closest(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, d_pc, b);
-                    mark_end(ctx->stream);
+                    mark(0, ln.main, b);
+                    launch_trace_closest(lcfg, sv, ln.q[b & 1], ln.hits, d_pc, b);
+                    mark_end(ln.main);
                 }
-                mark(2, ctx->stream, b);
-                launch_shade(cfg, ctx->sv, ctx->q[b & 1], ctx->hits, ctx->q[(b + 1) & 1], ctx->sa, ctx->sb,
-                             ctx->radiance, d_pc, b);
-                mark_end(ctx->stream);
+                mark(2, ln.main, b);
+                launch_shade(lcfg, sv, ln.q[b & 1], ln.hits, ln.q[(b + 1) & 1], ln.sa, ln.sb, ln.radiance, d_pc, b);
+                mark_end(ln.main);
                 if (overlap) {
-                    // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the main stream } -> shade(b+1)
-                    HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
-                    HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-                    mark(1, ctx->aux_stream, b);
-                    launch_trace_shadow(aux_cfg, aux_sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
-                    mark_end(ctx->aux_stream);
-                    HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+                    // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the lane's main stream } -> shade(b+1)
+                    HIP_CHECK(hipEventRecord(ln.ev_fork, ln.main));
+                    HIP_CHECK(hipStreamWaitEvent(ln.aux, ln.ev_fork, 0));
+                    mark(1, ln.aux, b);
+                    launch_trace_shadow(aux_cfg, aux_sv, ln.sa, ln.sb, ln.radiance, d_pc, b);
+                    mark_end(ln.aux);
+                    HIP_CHECK(hipEventRecord(ln.ev_join, ln.aux));
                     if (b + 1 < MAX_PATH_DEPTH) {
-                        mark(0, ctx->stream, b + 1);
-                        launch_trace_closest(cfg, ctx->sv, ctx->q[(b + 1) & 1], ctx->hits, d_pc, b + 1);
-                        mark_end(ctx->stream);
+                        mark(0, ln.main, b + 1);
+                        launch_trace_closest(lcfg, sv, ln.q[(b + 1) & 1], ln.hits, d_pc, b + 1);
+                        mark_end(ln.main);
                     }
-                    HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                    HIP_CHECK(hipStreamWaitEvent(ln.main, ln.ev_join, 0));
                 } else {
-                    mark(1, ctx->stream, b);
-                    launch_trace_shadow(cfg, ctx->sv, ctx->sa, ctx->sb, ctx->radiance, d_pc, b);
-                    mark_end(ctx->stream);
+                    mark(1, ln.main, b);
+                    launch_trace_shadow(lcfg, sv, ln.sa, ln.sb, ln.radiance, d_pc, b);
+                    mark_end(ln.main);
                 }
             }
-            mark(2, ctx->stream, -2);
-            launch_accumulate(cfg, vp, d_tiles, (uint32_t)slot0, n_slots, ctx->radiance, ctx->d_accum.as<float4>(),
+            mark(2, ln.main, -2);
+            launch_accumulate(lcfg, vp, d_tiles, (uint32_t)slot0, n_slots, ln.radiance, ctx->d_accum.as<float4>(),
                               ctx->d_tile_fb[tile_buf].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
                               ctx->d_ray_counts.as<uint32_t>());
-            mark_end(ctx->stream);
-            HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost,
-                                     ctx->stream));
+            mark_end(ln.main);
+            HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost, ln.main));
+        }
+        for (int i = 1; i < used_lanes; ++i) { // the caller's stream continues when every lane is done
+            HIP_CHECK(hipEventRecord(ctx->lanes[i].ev_done, ctx->lanes[i].main));
+            HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->lanes[i].ev_done, 0));
         }
         HIP_CHECK(hipGetLastError());
         if (readback && ctx->world == 1) {

@@ -106,6 +106,33 @@ def test_overlapped_launch_schedule_is_bit_identical(hip_lib, monkeypatch):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
 
 
+def test_pass_lanes_are_bit_identical(hip_lib, monkeypatch):
+    """With the overlapped schedule a frame is cut into passes that run on independent lanes (own queues, counters,
+    streams, spill slabs: crt_core.cpp PassLane) so that one lane's launches fill the tails of the other's. Pixels are
+    independent and a pass covers whole pixel slots: 1, 2 and 3 lanes, a frame cut in two by the lanes themselves
+    or three by the lanes themselves (1 M paths) and one cut into many small passes, give the same radiance, ray counts
+    and image bit for bit."""
+    sc = scenes.instanced_grove(spp=4)
+    e, d, u, fovy = camera_of(sc)
+    for (w, h), max_paths in (((640, 384), None), ((192, 128), "30000")):
+        if max_paths:
+            monkeypatch.setenv("CRT_HIP_MAX_PATHS", max_paths)
+        out = []
+        for lanes in ("1", "2", "3"):
+            monkeypatch.setenv("CRT_HIP_LANES", lanes)  # read when the context is created
+            r = RenderHIP()
+            r.initialize(w, h)
+            r.set_scene(sc)
+            for f in range(2):
+                st = r.render(e, d, u, fovy, f == 0, True)
+            out.append((r.accum().copy(), r.ray_counts().copy(), r.img.copy(), int(st.rays)))
+            r.close()
+        for b in out[1:]:
+            assert np.array_equal(out[0][0].view(np.uint32), b[0].view(np.uint32))
+            assert np.array_equal(out[0][1], b[1]) and np.array_equal(out[0][2], b[2]) and out[0][3] == b[3]
+        assert out[0][3] > 0
+
+
 def test_device_framebuffer_is_the_image_without_a_host_round_trip(hip_lib):
     """Display interop hand-off: with readback = False nothing reaches the host image, and the
     device pointer holds exactly what readback = True would have delivered."""
