@@ -115,6 +115,10 @@ struct crt_hip_ctx {
     // pixel slots), so with the overlapped schedule a frame is cut into at least n_lanes passes and pass p runs on lane
     // p % n_lanes: its own queues, counters, streams and spill slabs. The launches of one lane fill the tails of the other's.
     // Results do not depend on how a frame is cut into passes (tests/test_gpu_edge_cases.py, test_gpu_scale.py).
+    // Measured (profiles/r03_pass_lanes_ab.txt): C2 (3.7 M paths per frame) 8.60 -> 7.55 ms with two lanes; C4 (33 M) 68.0 ->
+    // 69.6 ms and C3 (16.6 M) 9.9 -> 10.2 ms -- two passes' kernels side by side also share the caches -- so by default only
+    // frames of at most LANES_MAX_PATHS paths are cut; CRT_HIP_LANES=n cuts every frame.
+    static constexpr uint64_t LANES_MAX_PATHS = 8ull << 20;
     struct PassLane {
         DeviceBuffer queue_mem, pc;
         PathQueue q[2]{};
@@ -129,7 +133,8 @@ struct crt_hip_ctx {
     };
     static constexpr int MAX_LANES = 4;
     PassLane lanes[MAX_LANES];
-    int n_lanes = 1;
+    int n_lanes = 1;         // lanes with streams
+    bool lanes_forced = false; // CRT_HIP_LANES given: cut every frame that is large enough; else only small frames (setup_queues)
     hipEvent_t ev_begin = nullptr;
     int n_cus = 256;
     std::string name, err;
@@ -298,7 +303,7 @@ void setup_queues(crt_hip_ctx *c)
     const uint64_t total_slots = (uint64_t)c->n_local_tiles * TILE_PIXELS;
     const uint64_t total_paths = total_slots * c->spp;
     uint64_t cap = std::min<uint64_t>(default_capacity(), total_paths);
-    if (c->n_lanes > 1 && total_paths >= ((uint64_t)c->n_lanes << 18)) {
+    if (c->n_lanes > 1 && total_paths >= ((uint64_t)c->n_lanes << 18) && (c->lanes_forced || total_paths <= crt_hip_ctx::LANES_MAX_PATHS)) {
         cap = std::min<uint64_t>(cap, (total_paths + (uint64_t)c->n_lanes - 1) / (uint64_t)c->n_lanes + 64ull * c->spp);
     }
     cap = std::min<uint64_t>(cap, 1ull << PATH_ID_BITS); // a path's index shares its queue word with its ray count (crt_types.h)
@@ -384,6 +389,7 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         c->n_lanes = c->overlap ? 2 : 1; // CRT_HIP_LANES: passes in flight (1 .. 4)
         if (const char *e = std::getenv("CRT_HIP_LANES")) {
             c->n_lanes = std::min(std::max(std::atoi(e), 1), (int)crt_hip_ctx::MAX_LANES);
+            c->lanes_forced = true;
         }
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
         for (int i = 0; i < c->n_lanes; ++i) {

@@ -179,8 +179,9 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *scene);
  * prepares and saves, the other ranks load -- same build, same machine, not an exchange format. */
 typedef struct crt_hip_prepared_scene crt_hip_prepared_scene;
 crt_hip_prepared_scene *crt_hip_prepare_scene(const crt_scene_desc *scene, int n_threads);
-/* The same with the BLAS of every large mesh built ON HIP device `build_device` (linear BVH --
- * Morton sort, binary radix tree, bottom-up boxes, collapse to the same 4-wide nodes; bvh_device.hip)
+/* The same with the tree of every large mesh -- and the world tree of an instanced scene -- built ON HIP device
+ * `build_device` (linear BVH -- Morton sort, binary radix tree, bottom-up boxes, collapse to the same
+ * 4-wide nodes; bvh_device.hip)
  * instead of by the host SAH builder: set_scene of a 10 M-triangle scene in a fraction of the time, at
  * a lower tree quality. build_device < 0: host build. crt_hip_set_scene takes this
  * path when CRT_HIP_BUILD=device is set. */
@@ -272,7 +273,8 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
                 float *out, int out_stride);
 
 /* BVH introspection for tests: copy out the traversal arrays the kernels use. Nodes are
- * 64-byte quantised 4-wide records, triangles 48-byte records (DESIGN.md "Data layout in HBM");
+ * 64-byte quantised 4-wide records, leaves 64-byte slots of one or two triangles -- n_tris counts SLOTS
+ * (DESIGN.md "Data layout in HBM");
  * root_frame receives the 6 floats {base.xyz, step.xyz} of the root BVH's fixed-point frame. */
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,
                      uint64_t *n_instances, int32_t *two_level, float *root_frame);
