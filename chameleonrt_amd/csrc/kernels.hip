@@ -384,6 +384,57 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
     }
 }
 
+// ---- sample_direct_light without its two occlusion queries (render_embree.ispc:105-181) -------------------------------
+// What the reference computes around rtcOccluded: the light-sample ray (hit_p, light_dir, EPSILON, light_dist) with its
+// contribution c_a if unoccluded (zero when a pdf is below EPSILON: the ray is traced and counted all the same,
+// ispc:144-147), and -- when the BSDF sample lands on the light with both pdfs >= EPSILON -- the second ray
+// (hit_p, w_i_b, EPSILON, light_dist_b) with c_b. k_trace_shadow resolves illum = [c_a] [+ c_b] from the visibilities
+// (ShadowSource::retire). Shared by k_shade and the known-answer test CRT_KAT_NEE.
+CRT_DEV void nee_setup(const SceneView &sc, const Surface &mat, V3 normal, V3 w_o, V3 v_x, V3 v_y, V3 hit_p, uint32_t &rng,
+                       V3 &c_a, V3 &light_dir, float &light_dist, bool &has_b, V3 &c_b, V3 &w_i_b, float &light_dist_b)
+{
+    uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
+    light_id = min(light_id, sc.n_lights - 1u);
+    // every OBJ / glTF scene has exactly one light (scene.cpp:218-227, 406-414): its 20 floats then sit at a
+    // wave-uniform address and are fetched once per wave by the scalar unit instead of 5 vector requests per lane
+    const QuadLight light = sc.n_lights == 1u ? load_light(sc.lights) : load_light(sc.lights + 20 * (size_t)light_id);
+    {
+        V2 ls;
+        ls.x = rng_nextf(rng);
+        ls.y = rng_nextf(rng);
+        const V3 light_pos = light_sample_position(light, ls);
+        light_dir = light_pos - hit_p;
+        light_dist = len3(light_dir);
+        light_dir = unit(light_dir);
+        const float l_pdf = light_pdf(light, light_pos, light_dir);
+        const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
+        if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
+            const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
+            const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
+            c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
+        }
+    }
+    {
+        // ispc:156-179. The reference evaluates the BSDF first and tests the light quad
+        // second; the quad test is the cheap and rarely-true one, so it goes first here
+        // (pure functions: same value, ~1/3 of the shading ALU work saved).
+        V3 light_pos;
+        if (disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i_b) &&
+            light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
+            const float b_pdf = disney_pdf(mat, normal, w_o, w_i_b, v_x, v_y);
+            const V3 bsdf = disney_eval(mat, normal, w_o, w_i_b, v_x, v_y);
+            if (!is_black(bsdf) && b_pdf >= RAY_EPS) {
+                const float l_pdf = light_pdf(light, light_pos, w_i_b);
+                if (l_pdf >= RAY_EPS) {
+                    const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
+                    c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
+                    has_b = true;
+                }
+            }
+        }
+    }
+}
+
 // ---- K3 shade: render_embree.ispc:251-335 + sample_direct_light :105-181 -----------------------
 // Output compaction. Survivors are first appended to an LDS staging buffer (wave ballot +
 // LDS atomic); whenever a buffer holds a full block's worth, SHADE_BLOCK entries leave for HBM
@@ -514,47 +565,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 V3 v_x, v_y;
                 ortho_basis(v_x, v_y, normal);
 
-                // -- sample_direct_light, ispc:105-181 --
-                uint32_t light_id = (uint32_t)(rng_nextf(rng) * sc.n_lights);
-                light_id = min(light_id, sc.n_lights - 1u);
-                // every OBJ / glTF scene has exactly one light (scene.cpp:218-227, 406-414): its 20 floats then sit at a
-                // wave-uniform address and are fetched once per wave by the scalar unit instead of 5 vector requests per lane
-                const QuadLight light = sc.n_lights == 1u ? load_light(sc.lights) : load_light(sc.lights + 20 * (size_t)light_id);
-                {
-                    V2 ls;
-                    ls.x = rng_nextf(rng);
-                    ls.y = rng_nextf(rng);
-                    const V3 light_pos = light_sample_position(light, ls);
-                    light_dir = light_pos - hit_p;
-                    light_dist = len3(light_dir);
-                    light_dir = unit(light_dir);
-                    const float l_pdf = light_pdf(light, light_pos, light_dir);
-                    const float b_pdf = disney_pdf(mat, normal, w_o, light_dir, v_x, v_y);
-                    if (l_pdf >= RAY_EPS && b_pdf >= RAY_EPS) {
-                        const V3 bsdf = disney_eval(mat, normal, w_o, light_dir, v_x, v_y);
-                        const float w = mis_power(1.f, l_pdf, 1.f, b_pdf);
-                        c_a = bsdf * light.emission * fabsf(dot3(light_dir, normal)) * w / l_pdf;
-                    }
-                }
-                {
-                    // ispc:156-179. The reference evaluates the BSDF first and tests the light quad
-                    // second; the quad test is the cheap and rarely-true one, so it goes first here
-                    // (pure functions: same value, ~1/3 of the shading ALU work saved).
-                    V3 light_pos;
-                    if (disney_sample_dir(mat, normal, w_o, v_x, v_y, rng, w_i_b) &&
-                        light_intersect(light, hit_p, w_i_b, light_dist_b, light_pos)) {
-                        const float b_pdf = disney_pdf(mat, normal, w_o, w_i_b, v_x, v_y);
-                        const V3 bsdf = disney_eval(mat, normal, w_o, w_i_b, v_x, v_y);
-                        if (!is_black(bsdf) && b_pdf >= RAY_EPS) {
-                            const float l_pdf = light_pdf(light, light_pos, w_i_b);
-                            if (l_pdf >= RAY_EPS) {
-                                const float w = mis_power(1.f, b_pdf, 1.f, l_pdf);
-                                c_b = bsdf * light.emission * fabsf(dot3(w_i_b, normal)) * w / b_pdf;
-                                has_b = true;
-                            }
-                        }
-                    }
-                }
+                nee_setup(sc, mat, normal, w_o, v_x, v_y, hit_p, rng, c_a, light_dir, light_dist, has_b, c_b, w_i_b, light_dist_b);
                 n_rays += has_b ? 2u : 1u; // the occlusion rays (ispc:145-147, 171-173)
                 // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
                 // non-finite throughput (the reference's glass pdfs can be negative or overflow)
@@ -821,6 +832,25 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
         st3(o + 3, w_i);
         o[6] = pdf;
         o[7] = __uint_as_float(rng);
+        break;
+    }
+    case CRT_KAT_NEE: {
+        const Surface m = load_surface(a);
+        const V3 nn = ld3(a + 14), w_o = ld3(a + 17), v_x = ld3(a + 20), v_y = ld3(a + 23), hit_p = ld3(a + 26);
+        uint32_t rng = __float_as_uint(a[29]);
+        V3 c_a = v3(0.f), c_b = v3(0.f), light_dir = v3(0.f), w_i_b = v3(0.f);
+        float light_dist = 0.f, light_dist_b = 0.f;
+        bool has_b = false;
+        nee_setup(sc, m, nn, w_o, v_x, v_y, hit_p, rng, c_a, light_dir, light_dist, has_b, c_b, w_i_b, light_dist_b);
+        st3(o, c_a);
+        st3(o + 3, light_dir);
+        o[6] = light_dist;
+        o[7] = has_b ? 1.f : 0.f;
+        st3(o + 8, has_b ? c_b : v3(0.f));
+        st3(o + 11, has_b ? w_i_b : v3(0.f));
+        o[14] = has_b ? light_dist_b : 0.f;
+        o[15] = __uint_as_float(rng);
+        o[16] = has_b ? 2.f : 1.f;
         break;
     }
     case CRT_KAT_LIGHT: {

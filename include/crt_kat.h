@@ -43,7 +43,14 @@ enum {
     CRT_KAT_RNG = 8,
     /* render_embree.ispc:79-103 unpack_material (needs a scene)
      * in   (3): material_id(bits) u v      out (14): DisneyMaterial fields */
-    CRT_KAT_UNPACK_MATERIAL = 9
+    CRT_KAT_UNPACK_MATERIAL = 9,
+    /* render_embree.ispc:105-181 sample_direct_light around its two occlusion queries (needs a scene: its lights):
+     * light pick, light sample, both pdfs, MIS weights, the BSDF-sample branch; both rays taken as unoccluded
+     * in  (30): mat[14] n[3] w_o[3] v_x[3] v_y[3] hit_p[3] rng_state(bits)
+     * out (17): c_a[3] (contribution of the light-sample ray, 0 if a pdf < EPSILON), light_dir[3], light_dist,
+     *           has_b(0/1), c_b[3], w_i_b[3], light_dist_b (zeros without a second ray), rng_state_after(bits),
+     *           occlusion rays counted (1 or 2) */
+    CRT_KAT_NEE = 10
 };
 
 #define CRT_KAT_MAX_IN 32

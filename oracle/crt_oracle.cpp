@@ -1251,8 +1251,17 @@ inline void unpack_material(Material &mat, const Material &p, const std::vector<
 // render_embree.ispc:105-181. RNG order: light pick, light u, light v, then the three draws
 // of sample_disney_brdf (quirk Q3). The first shadow ray is traced and counted even when its
 // contribution is discarded.
+// (rec != nullptr: the known-answer test CRT_KAT_NEE -- no occlusion query is made, both rays count as unoccluded and
+// what the function computed around them is recorded; the arithmetic is the one every frame runs.)
+struct NeeRecord {
+    f3 c_a = mk3(0.f), light_dir = mk3(0.f);
+    float light_dist = 0.f;
+    bool has_b = false;
+    f3 c_b = mk3(0.f), w_i_b = mk3(0.f);
+    float light_dist_b = 0.f;
+};
 f3 sample_direct_light(const orc_scene &sc, const Material &mat, f3 hit_p, f3 n, f3 v_x, f3 v_y,
-                       f3 w_o, uint32_t &ray_stats, Lcg &rng, TraceCounters &ctr)
+                       f3 w_o, uint32_t &ray_stats, Lcg &rng, TraceCounters &ctr, NeeRecord *rec = nullptr)
 {
     f3 illum = mk3(0.f);
     const uint32_t num_lights = (uint32_t)sc.lights.size();
@@ -1268,13 +1277,18 @@ f3 sample_direct_light(const orc_scene &sc, const Material &mat, f3 hit_p, f3 n,
         light_dir = normalize(light_dir);
         const float light_pdf = quad_light_pdf(light, light_pos, hit_p, light_dir);
         const float bsdf_pdf = disney_pdf(mat, n, w_o, light_dir, v_x, v_y);
-        const bool occluded = scene_occluded(sc, hit_p, light_dir, EPS, light_dist, false, ctr);
+        const bool occluded = rec ? false : scene_occluded(sc, hit_p, light_dir, EPS, light_dist, false, ctr);
         DBG("   neeA light_pdf %.9g bsdf_pdf %.9g occ %d\n", light_pdf, bsdf_pdf, (int)occluded);
         ++ray_stats;
         if (light_pdf >= EPS && bsdf_pdf >= EPS && !occluded) {
             const f3 bsdf = disney_brdf(mat, n, w_o, light_dir, v_x, v_y);
             const float w = power_heuristic(1.f, light_pdf, 1.f, bsdf_pdf);
             illum = bsdf * light.emission * std::fabs(dot(light_dir, n)) * w / light_pdf;
+        }
+        if (rec) {
+            rec->c_a = illum;
+            rec->light_dir = light_dir;
+            rec->light_dist = light_dist;
         }
     }
     {
@@ -1288,8 +1302,14 @@ f3 sample_direct_light(const orc_scene &sc, const Material &mat, f3 hit_p, f3 n,
             const float light_pdf = quad_light_pdf(light, light_pos, hit_p, w_i);
             if (light_pdf >= EPS) {
                 const float w = power_heuristic(1.f, bsdf_pdf, 1.f, light_pdf);
-                const bool occluded = scene_occluded(sc, hit_p, w_i, EPS, light_dist, false, ctr);
+                const bool occluded = rec ? false : scene_occluded(sc, hit_p, w_i, EPS, light_dist, false, ctr);
                 ++ray_stats;
+                if (rec) {
+                    rec->has_b = true;
+                    rec->c_b = bsdf * light.emission * std::fabs(dot(w_i, n)) * w / bsdf_pdf;
+                    rec->w_i_b = w_i;
+                    rec->light_dist_b = light_dist;
+                }
                 if (!occluded) {
                     illum = illum + bsdf * light.emission * std::fabs(dot(w_i, n)) * w / bsdf_pdf;
                 }
@@ -2196,6 +2216,29 @@ extern "C" int orc_kat(const orc_scene *s, int fn, uint64_t n, const float *in, 
             st3(o + 3, w_i);
             o[6] = pdf;
             o[7] = fbits(rng.state);
+            break;
+        }
+        case CRT_KAT_NEE: {
+            if (!s) {
+                return -1;
+            }
+            Material mat;
+            std::memcpy(&mat, a, sizeof(mat));
+            const f3 nn = ld3(a + 14), w_o = ld3(a + 17), v_x = ld3(a + 20), v_y = ld3(a + 23), hit_p = ld3(a + 26);
+            Lcg rng{bits(a[29])};
+            NeeRecord rec;
+            uint32_t n_rays = 0;
+            TraceCounters ctr;
+            (void)sample_direct_light(*s, mat, hit_p, nn, v_x, v_y, w_o, n_rays, rng, ctr, &rec);
+            st3(o, rec.c_a);
+            st3(o + 3, rec.light_dir);
+            o[6] = rec.light_dist;
+            o[7] = rec.has_b ? 1.f : 0.f;
+            st3(o + 8, rec.c_b);
+            st3(o + 11, rec.w_i_b);
+            o[14] = rec.light_dist_b;
+            o[15] = fbits(rng.state);
+            o[16] = (float)n_rays;
             break;
         }
         case CRT_KAT_LIGHT: {

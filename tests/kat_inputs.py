@@ -4,8 +4,8 @@ import numpy as np
 from chameleonrt_amd.scene import ortho_basis, obj_default_light
 
 KAT_DISNEY_EVAL, KAT_DISNEY_SAMPLE, KAT_LIGHT, KAT_TEXTURE, KAT_MISS = 1, 2, 3, 4, 5
-KAT_ORTHO_BASIS, KAT_SRGB8, KAT_RNG, KAT_UNPACK_MATERIAL = 6, 7, 8, 9
-N_OUT = {1: 4, 2: 8, 3: 9, 4: 5, 5: 3, 6: 6, 7: 1, 8: 17, 9: 14}
+KAT_ORTHO_BASIS, KAT_SRGB8, KAT_RNG, KAT_UNPACK_MATERIAL, KAT_NEE = 6, 7, 8, 9, 10
+N_OUT = {1: 4, 2: 8, 3: 9, 4: 5, 5: 3, 6: 6, 7: 1, 8: 17, 9: 14, 10: 17}
 
 
 def _unit(v):
@@ -61,6 +61,32 @@ def disney_sample_records(n, seed=12):
     w_o[flip] *= -1
     state = rng.integers(0, 2**32, size=(n, 1), dtype=np.uint64).astype(np.uint32).view(np.float32)
     return np.concatenate([mat, nrm, w_o, vx, vy, state], axis=1).astype(np.float32)
+
+
+def nee_records(n, light, seed=19):
+    """Surface points around the scene's quad light (20 floats: emission, position, normal, v_x, v_y, each padded to 4; the
+    half-extents ride in v_x.w / v_y.w) at distances from a fraction of its size to 30 times it, most of them facing it --
+    so that light samples have useful pdfs and a share of the BSDF samples lands on the quad (the second ray)."""
+    rng = np.random.default_rng(seed)
+    mat = random_materials(rng, n)
+    mat[: n // 4, 5] = np.clip(mat[: n // 4, 5], 0.5, 1.0)  # a share of rough surfaces: wide lobes find the light
+    light = np.asarray(light, np.float32).reshape(-1)[:20]
+    centre, l_n = light[4:7], light[8:11]
+    size = max(float(abs(light[15])), float(abs(light[19])), 1e-3)
+    d = _unit(rng.normal(size=(n, 3)))
+    front = np.einsum("ij,j->i", d, l_n) < 0
+    d[front & (rng.random(n) < 0.9)] *= -1  # most points on the emitting side
+    dist = (size * np.exp(rng.uniform(np.log(0.3), np.log(30.0), size=n))).astype(np.float32)
+    hit_p = (centre[None, :] + d * dist[:, None]).astype(np.float32)
+    to_l = _unit(centre[None, :] - hit_p)
+    nrm = _unit(to_l + rng.normal(size=(n, 3)).astype(np.float32) * rng.random((n, 1)).astype(np.float32) * 1.5)
+    vx = np.zeros((n, 3), np.float32)
+    vy = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        vx[i], vy[i] = ortho_basis(nrm[i])
+    w_o = _unit(nrm + rng.normal(size=(n, 3)).astype(np.float32))
+    state = rng.integers(0, 2**32, size=(n, 1), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    return np.concatenate([mat, nrm, w_o, vx, vy, hit_p, state], axis=1).astype(np.float32)
 
 
 def light_records(n, seed=13):

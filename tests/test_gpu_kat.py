@@ -60,6 +60,27 @@ def test_disney_sample(pair):
     assert ok.mean() > 0.995, f"{(~ok).sum()} of {len(ok)} records out of tolerance"
 
 
+def test_sample_direct_light_around_its_occlusion_queries(pair):
+    """render_embree.ispc:105-181 without the two rtcOccluded calls (CRT_KAT_NEE): light pick and sample, both pdfs, the
+    MIS weights, the BSDF-sample branch and its test against the quad -- the part of next-event estimation k_shade runs
+    (nee_setup) before k_trace_shadow resolves the visibilities. RNG consumption and the light-sample ray are bit-exact
+    (+ - * / sqrt only); the contributions carry the BSDF's transcendentals."""
+    r, o, sc = pair
+    rec = K.nee_records(20000, sc.lights[0])
+    g, c = r.kat(K.KAT_NEE, rec, 17), o.kat(K.KAT_NEE, rec, 17)
+    assert np.array_equal(g[:, 3:7].view(np.uint32), c[:, 3:7].view(np.uint32)), "light-sample ray (direction, distance)"
+    same_b = g[:, 7] == c[:, 7]
+    assert same_b.mean() > 0.999 and (c[:, 7] == 1).mean() > 0.02, (same_b.mean(), (c[:, 7] == 1).mean())
+    assert np.array_equal(g[same_b, 15].view(np.uint32), c[same_b, 15].view(np.uint32)), "RNG consumption differs"
+    assert np.array_equal(g[same_b, 16], c[same_b, 16]), "occlusion rays counted"
+    assert (c[:, 0:3] != 0).any(axis=1).mean() > 0.3, "too few records with a light-sample contribution"
+    ok = _close(g[:, 0:3], c[:, 0:3], 2e-4, 1e-6).all(axis=1)
+    b = same_b & (c[:, 7] == 1)
+    ok[b] &= _close(g[b, 8:11], c[b, 8:11], 2e-4, 1e-6).all(axis=1) & _close(g[b, 11:14], c[b, 11:14], 0, 1e-5).all(axis=1)
+    ok[b] &= g[b, 14].view(np.uint32) == c[b, 14].view(np.uint32)  # distance to the quad along the sampled direction: exact ops, but
+    assert ok.mean() > 0.995, f"{(~ok).sum()} of {len(ok)} records out of tolerance"  # of a direction that carries sin / cos ulps
+
+
 def test_lights(pair):
     r, o, _ = pair
     rec = K.light_records(5000)
