@@ -134,6 +134,12 @@ struct crt_hip_ctx {
     static constexpr int MAX_LANES = 4;
     PassLane lanes[MAX_LANES];
     int n_lanes = 1;         // lanes with streams
+    // With several lanes in use each lane's launches go strictly in order on ONE stream per lane: the other lane is what
+    // fills the tails, and four streams (two lanes x main + aux) are as many as a process has hardware queues by default --
+    // in a process that holds further streams (torch, a second context) they alias and the frame got 28 % SLOWER
+    // (profiles/r03_pass_lanes_ab.txt: C2 7.45 ms with two streams either way; 7.49 / 9.58 ms with four). CRT_HIP_LANE_AUX=1
+    // restores the per-lane occlusion stream.
+    bool lane_aux = false;
     bool lanes_forced = false; // CRT_HIP_LANES given: cut every frame that is large enough; else only small frames (setup_queues)
     hipEvent_t ev_begin = nullptr;
     int n_cus = 256;
@@ -390,6 +396,9 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
         if (const char *e = std::getenv("CRT_HIP_LANES")) {
             c->n_lanes = std::min(std::max(std::atoi(e), 1), (int)crt_hip_ctx::MAX_LANES);
             c->lanes_forced = true;
+        }
+        if (const char *e = std::getenv("CRT_HIP_LANE_AUX")) {
+            c->lane_aux = std::atoi(e) != 0;
         }
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
         for (int i = 0; i < c->n_lanes; ++i) {
@@ -791,7 +800,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             }
         };
 
-        const bool overlap = ctx->overlap;
+        bool overlap = ctx->overlap;
         // The compact tile buffer alternates with every RENDERED frame, whatever frame_id does (a moving camera resets
         // frame_id to 0 every frame): the asynchronous gather of the previous frame may still be reading the other one.
         const int tile_buf = ctx->tile_fb_last ^ 1;
@@ -799,6 +808,9 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         const uint32_t n_pass_frame = (uint32_t)((total_slots + slots_per_pass - 1) / slots_per_pass);
         const int used_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, std::max<uint32_t>(1u, n_pass_frame));
         ctx->lanes[0].main = ctx->stream;
+        if (used_lanes > 1 && !ctx->lane_aux) {
+            overlap = false;
+        }
         if (used_lanes > 1) { // the other lanes start where the caller's stream stands
             HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
             for (int i = 1; i < used_lanes; ++i) {

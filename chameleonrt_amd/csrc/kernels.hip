@@ -1018,7 +1018,7 @@ void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, co
 int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,
                float *out, int out_stride)
 {
-    if (fn < CRT_KAT_DISNEY_EVAL || fn > CRT_KAT_UNPACK_MATERIAL) {
+    if (fn < CRT_KAT_DISNEY_EVAL || fn > CRT_KAT_NEE) {
         return -1;
     }
     k_kat<<<(n + 63) / 64, 64, 0, cfg.stream>>>(sc, fn, n, in, in_stride, out, out_stride);

@@ -12,7 +12,7 @@
 #   trace[:W]           rocprofv3 --kernel-trace --stats of the bench command    -> kernel_stats_W.md
 #   micro:NAME          build/NAME (a tools/*.hip microbenchmark built beforehand) -> NAME.txt
 #   frames:W:ENV=V,...  tools/gpu_frames.py W with environment settings          -> frames_W_<n>.log
-#   py:NAME[:ARGS]      python tools/NAME.py ARGS                                -> NAME_<n>.log
+#   py:NAME[:ARGS[:ENV=V,...]]  python tools/NAME.py ARGS (with environment settings)   -> NAME_<n>.log
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
@@ -62,7 +62,7 @@ PY
       ( export ${b//,/ }; timeout 300 python tools/gpu_frames.py "$a" 2 6 ) > "$OUT/frames_${a}_$n.log" 2>&1
       grep -E "set_scene|frame 5" "$OUT/frames_${a}_$n.log" | cut -c1-220 ;;
     py)
-      timeout 600 python "tools/$a.py" ${b//,/ } > "$OUT/${a}_$n.log" 2>&1; tail -60 "$OUT/${a}_$n.log" | cut -c1-220 ;;
+      ( [ -n "$c" ] && export ${c//,/ }; timeout 600 python "tools/$a.py" ${b//,/ } ) > "$OUT/${a}_$n.log" 2>&1; tail -60 "$OUT/${a}_$n.log" | cut -c1-220 ;;
     *) echo "unknown step $step" ;;
   esac
 done
