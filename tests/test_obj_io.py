@@ -115,3 +115,83 @@ def test_native_reader_equals_the_python_twin(tmp_path):
     p = os.path.join(tmp_path, "s.obj")
     save_obj(sc, p)
     _same_scene(load_obj(p), load_obj(p, reader="python"))
+
+
+def _random_obj(rng, crlf):
+    """A syntactically valid OBJ in the dialect the importers agree on: positions / texture coordinates in varied number
+    formats, triangles, quads and n-gons with positive and negative indices, `v`, `v/t`, `v//n`, `v/t/n` corners (one
+    kind per object, like real exporters), objects, groups, materials before and after their library, comments, blank
+    lines, tabs and trailing blanks."""
+    def num():
+        x = float(rng.normal()) * 10 ** int(rng.integers(-3, 3))
+        return rng.choice([f"{x:.6g}", f"{x:.3e}", f"{x:+.4f}", f"{x:.5f}".replace("0.", ".", 1) if 0 < x < 1 else f"{x:.2f}"])
+    lines, n_v, n_vt = ["# fuzz"], 0, 0
+    sep = lambda: rng.choice([" ", "  ", "\t"])
+    if rng.random() < 0.7:
+        lines.append("mtllib m.mtl")
+    for o in range(int(rng.integers(1, 5))):
+        for _ in range(int(rng.integers(3, 12))):
+            lines.append("v" + sep() + sep().join(num() for _ in range(3)) + rng.choice(["", " ", "\t "]))
+            n_v += 1
+        for _ in range(int(rng.integers(0, 6))):
+            lines.append("vt" + sep() + sep().join(num() for _ in range(int(rng.integers(1, 4)))))
+            n_vt += 1
+        if rng.random() < 0.3:
+            lines.append("vn 0 1 0")
+        lines.append(rng.choice(["o", "g"]) + f" part{o}" + rng.choice(["", " extra words"]))
+        if rng.random() < 0.8:
+            lines.append("usemtl " + rng.choice(["shiny", "dull stuff", "missing"]))
+        kind = int(rng.integers(0, 4)) if n_vt else int(rng.choice([0, 2]))
+        for _ in range(int(rng.integers(1, 8))):
+            if rng.random() < 0.15:
+                lines.append(rng.choice(["", "   ", "# mid comment", "s off", "usemtl shiny"]))
+            corners = []
+            for _ in range(int(rng.choice([3, 3, 3, 4, 4, 5, 6]))):
+                v = int(rng.integers(1, n_v + 1))
+                v = v if rng.random() < 0.7 else v - n_v - 1
+                t = int(rng.integers(1, n_vt + 1)) if n_vt else 1
+                t = t if rng.random() < 0.7 else t - n_vt - 1
+                corners.append([f"{v}", f"{v}/{t}", f"{v}//1", f"{v}/{t}/1"][kind])
+            lines.append("f" + sep() + sep().join(corners))
+    return ("\r\n" if crlf else "\n").join(lines) + ("" if rng.random() < 0.3 else ("\r\n" if crlf else "\n"))
+
+
+def test_native_reader_equals_the_python_twin_on_generated_files(tmp_path):
+    """60 seeded random OBJ files (Unix and DOS line ends): the two readers agree on every array, or refuse together."""
+    open(os.path.join(tmp_path, "m.mtl"), "w").write("newmtl shiny\nKd 0.2 0.4 0.6\nNs 250\nnewmtl dull stuff\nKd 1 0 0\nNs 0\n")
+    p = os.path.join(tmp_path, "f.obj")
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        with open(p, "w", newline="") as f:
+            f.write(_random_obj(rng, crlf=seed % 3 == 0))
+        res = []
+        for reader in ("native", "python"):
+            try:
+                res.append(load_obj(p, reader=reader))
+            except (ValueError, IndexError) as ex:
+                res.append(type(ex))
+        if isinstance(res[0], type) or isinstance(res[1], type):
+            assert isinstance(res[0], type) and isinstance(res[1], type), (seed, res)
+        else:
+            _same_scene(res[0], res[1])
+
+
+def test_native_reader_refuses_garbage_without_crashing(tmp_path):
+    """Random bytes, a truncated file, absurd indices: an error (ValueError) or an empty result, never a crash."""
+    rng = np.random.default_rng(7)
+    p = os.path.join(tmp_path, "g.obj")
+    blobs = [rng.integers(0, 256, size=4096, dtype=np.uint8).tobytes(),
+             b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 99999999999\n",
+             b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -7\n",
+             b"f 1 2 3\n",
+             b"v 1 2\nv\nf\nf 1\nf 1 2\nvt\nusemtl\nmtllib\n",
+             b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/ 2/ 3/\nf 1/2/3/4 2 3\n",
+             b"v 1e400 -1e400 nan\nv inf 0 0\nv 0 0 0\nf 1 2 3\n" + b"f 1 2 3" * 1]
+    for blob in blobs:
+        open(p, "wb").write(blob)
+        for reader in ("native", "python"):
+            try:
+                sc = load_obj(p, reader=reader)
+                assert sc.total_tris() >= 0
+            except (ValueError, IndexError, UnicodeDecodeError, OverflowError):
+                pass
