@@ -845,7 +845,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                     mark_end(ln.main);
                 }
                 mark(2, ln.main, b);
-                launch_shade(lcfg, sv, ln.q[b & 1], ln.hits, ln.q[(b + 1) & 1], ln.sa, ln.sb, ln.radiance, d_pc, b);
+                launch_shade(lcfg, sv, ln.q[b & 1], ln.hits, ln.q[(b + 1) & 1], ln.sa, ln.sb, ln.radiance, d_pc, b, n_paths);
                 mark_end(ln.main);
                 if (overlap) {
                     // shade(b) -> { shadow(b) on aux  ||  closest(b+1) on the lane's main stream } -> shade(b+1)

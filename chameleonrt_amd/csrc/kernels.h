@@ -39,7 +39,8 @@ void launch_trace_closest(const LaunchCfg &cfg, const SceneView &sc, PathQueue q
                           PassCounters *pc, int bounce);
 // K3: hit shading: material unpack, NEE set-up, BSDF sampling, Russian roulette, compaction.
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
-                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce);
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce,
+                  uint32_t n_paths_max /* paths of the pass: the queue cannot be longer */);
 // K4: any-hit traversal of the NEE occlusion rays (light sample, then the rare BSDF-sample ray of
 // the same hit, by the same lane).
 void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA sa, ShadowQueueB sb,

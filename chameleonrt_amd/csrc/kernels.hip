@@ -44,7 +44,10 @@ namespace crt {
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
 constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each; 85 = 4 full levels)
-constexpr int SHADE_BLOCK = 256;
+#ifndef CRT_SHADE_BLOCK
+#define CRT_SHADE_BLOCK 256 // threads per block of k_raygen / k_shade / k_accumulate (128 and 512 measured: profiles/r03_shade_grid_ab.txt)
+#endif
+constexpr int SHADE_BLOCK = CRT_SHADE_BLOCK;
 
 // ---- wave-level helpers (wave64) -------------------------------------------------------------
 CRT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -442,6 +445,9 @@ CRT_DEV void nee_setup(const SceneView &sc, const Surface &mat, V3 normal, V3 w_
 // counters (a single word each) far below their ~88 atomics/us ceiling.
 #ifndef CRT_SHADE_FLUSH
 #define CRT_SHADE_FLUSH 128 // staged entries that trigger a flush; LDS = (256 + this) * 23 * 4 B
+#endif
+#ifndef CRT_SHADE_GRID
+#define CRT_SHADE_GRID (8 * 256 / CRT_SHADE_BLOCK) // blocks per CU in the grid-stride launch of k_shade
 #endif
 #ifndef CRT_SHADE_WAVES
 #define CRT_SHADE_WAVES 4 // waves per SIMD the register allocator must leave room for
@@ -977,11 +983,27 @@ void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA
             persistent_grid(cfg, CRT_TRACE_BLOCKS_PER_CU), cfg.stream, sc, sa, sb, radiance, pc, bounce);
 }
 
+// The grid of k_shade's grid-stride loop. The queue is in pixel order, so items that are near each other in it touch the
+// same materials, texture tiles and uv records; blocks are dispatched in index order, so the larger the grid, the closer
+// together in the queue the ~1 000 resident blocks work at any time (and the finer the balance between cheap and
+// expensive items). Measured (profiles/r03_shade_grid_ab.txt, blocks per CU): C4 shade 19.5 ms at 8, 18.6 at 16, 18.2 at
+// 32, 18.0 at 128; C3 3.40 -> 3.15 ms; fewer than 8 is slower (20.4 at 4). A block should still have a few iterations to
+// amortise its start and its final partial flush (C2, 1.8 M paths per pass: 8 per CU is best), hence: one block per
+// CRT_SHADE_MIN_ITERS x 256 paths of the pass, between CRT_SHADE_GRID and CRT_SHADE_GRID_MAX blocks per CU. (Handing the steps
+// out in queue order by an atomic cursor instead: C4 shade 17.4 ms with 8 blocks per CU, but C3 +3 % and C2 +25 %: not kept.)
+#ifndef CRT_SHADE_GRID_MAX
+#define CRT_SHADE_GRID_MAX 128
+#endif
+#ifndef CRT_SHADE_MIN_ITERS
+#define CRT_SHADE_MIN_ITERS 4
+#endif
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
-                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce)
+                  ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce, uint32_t n_paths_max)
 {
-    k_shade<<<persistent_grid(cfg, 8), SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc,
-                                                                     bounce);
+    const long want = (long)(n_paths_max / (uint32_t)(SHADE_BLOCK * CRT_SHADE_MIN_ITERS));
+    const long lo = persistent_grid(cfg, CRT_SHADE_GRID), hi = persistent_grid(cfg, CRT_SHADE_GRID_MAX);
+    const int grid = (int)(want < lo ? lo : want > hi ? hi : want);
+    k_shade<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce);
 }
 
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,
