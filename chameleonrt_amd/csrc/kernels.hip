@@ -990,7 +990,8 @@ void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA
 // 32, 18.0 at 128; C3 3.40 -> 3.15 ms; fewer than 8 is slower (20.4 at 4). A block should still have a few iterations to
 // amortise its start and its final partial flush (C2, 1.8 M paths per pass: 8 per CU is best), hence: one block per
 // CRT_SHADE_MIN_ITERS x 256 paths of the pass, between CRT_SHADE_GRID and CRT_SHADE_GRID_MAX blocks per CU. (Handing the steps
-// out in queue order by an atomic cursor instead: C4 shade 17.4 ms with 8 blocks per CU, but C3 +3 % and C2 +25 %: not kept.)
+// out in queue order by an atomic cursor instead: C4 shade 17.4 ms with 8 blocks per CU, but C3 +3 % and C2 +25 %: not kept. Runs of 2 .. 64
+// consecutive steps per XCD (block b runs on XCD b % 8) so that neighbours meet in one L2: no difference on any workload.)
 #ifndef CRT_SHADE_GRID_MAX
 #define CRT_SHADE_GRID_MAX 128
 #endif
