@@ -444,7 +444,7 @@ CRT_DEV void nee_setup(const SceneView &sc, const Surface &mat, V3 normal, V3 w_
 // with ONE memory-side atomic and fully coalesced 1-KiB-per-wave stores. This keeps the queue
 // counters (a single word each) far below their ~88 atomics/us ceiling.
 #ifndef CRT_SHADE_FLUSH
-#define CRT_SHADE_FLUSH 128 // staged entries that trigger a flush; LDS = (256 + this) * 23 * 4 B
+#define CRT_SHADE_FLUSH 64 // staged entries that trigger a flush; LDS = (256 + this) * 23 * 4 B (128: C4 shade +4 %, 256: +9 %; 1 .. 32: as 64)
 #endif
 #ifndef CRT_SHADE_GRID
 #define CRT_SHADE_GRID (8 * 256 / CRT_SHADE_BLOCK) // blocks per CU in the grid-stride launch of k_shade
@@ -989,14 +989,15 @@ void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA
 // expensive items). Measured (profiles/r03_shade_grid_ab.txt, blocks per CU): C4 shade 19.5 ms at 8, 18.6 at 16, 18.2 at
 // 32, 18.0 at 128; C3 3.40 -> 3.15 ms; fewer than 8 is slower (20.4 at 4). A block should still have a few iterations to
 // amortise its start and its final partial flush (C2, 1.8 M paths per pass: 8 per CU is best), hence: one block per
-// CRT_SHADE_MIN_ITERS x 256 paths of the pass, between CRT_SHADE_GRID and CRT_SHADE_GRID_MAX blocks per CU. (Handing the steps
+// CRT_SHADE_MIN_ITERS x 256 paths of the pass, between CRT_SHADE_GRID and CRT_SHADE_GRID_MAX blocks per CU (256 with 2
+// iterations: C4 shade a further -0.3 ms against 128 with 4). (Handing the steps
 // out in queue order by an atomic cursor instead: C4 shade 17.4 ms with 8 blocks per CU, but C3 +3 % and C2 +25 %: not kept. Runs of 2 .. 64
 // consecutive steps per XCD (block b runs on XCD b % 8) so that neighbours meet in one L2: no difference on any workload.)
 #ifndef CRT_SHADE_GRID_MAX
-#define CRT_SHADE_GRID_MAX 128
+#define CRT_SHADE_GRID_MAX 256
 #endif
 #ifndef CRT_SHADE_MIN_ITERS
-#define CRT_SHADE_MIN_ITERS 4
+#define CRT_SHADE_MIN_ITERS 2
 #endif
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce, uint32_t n_paths_max)
