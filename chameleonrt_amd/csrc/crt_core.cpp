@@ -116,9 +116,15 @@ struct crt_hip_ctx {
     // p % n_lanes: its own queues, counters, streams and spill slabs. The launches of one lane fill the tails of the other's.
     // Results do not depend on how a frame is cut into passes (tests/test_gpu_edge_cases.py, test_gpu_scale.py).
     // Measured (profiles/r03_pass_lanes_ab.txt): C2 (3.7 M paths per frame) 8.60 -> 7.55 ms with two lanes; C4 (33 M) 68.0 ->
-    // 69.6 ms and C3 (16.6 M) 9.9 -> 10.2 ms -- two passes' kernels side by side also share the caches -- so by default only
-    // frames of at most LANES_MAX_PATHS paths are cut; CRT_HIP_LANES=n cuts every frame.
+    // 69.6 ms and C3 (16.6 M) 9.9 -> 10.2 ms -- two passes' kernels side by side also share the caches; and one eighth of
+    // C4 (4.1 M paths of expensive rays) 10.1 -> 11.2 ms. Path count alone does not tell, so frames of at most
+    // LANES_MAX_PATHS paths are TRIED both ways: the second frame after a (re)configuration is timed with one lane, the
+    // third with two, and the faster stays (images are bit-identical either way). CRT_HIP_LANES=n cuts every frame.
     static constexpr uint64_t LANES_MAX_PATHS = 8ull << 20;
+    int lane_choice = 1;   // lanes the next setup_queues cuts a tunable frame for
+    int lane_tune = 0;     // frames rendered since the last (re)configuration, up to 3 (tuned)
+    float lane_t1 = 0.f;   // frame time with one lane
+    int lanes_in_use = 1;  // what setup_queues carved queues for
     struct PassLane {
         DeviceBuffer queue_mem, pc;
         PathQueue q[2]{};
@@ -302,6 +308,20 @@ void carve_queues(crt_hip_ctx::PassLane &l, uint64_t cap)
     l.pc.alloc(sizeof(PassCounters));
 }
 
+// May frames of this many paths be cut for the lanes by trial (crt_hip_ctx::PassLane)?
+bool lanes_tunable(const crt_hip_ctx *c, uint64_t total_paths)
+{
+    return c->n_lanes >= 2 && !c->lanes_forced && total_paths >= (2ull << 18) && total_paths <= crt_hip_ctx::LANES_MAX_PATHS;
+}
+
+int lanes_for(const crt_hip_ctx *c, uint64_t total_paths)
+{
+    if (c->lanes_forced) {
+        return c->n_lanes > 1 && total_paths >= ((uint64_t)c->n_lanes << 18) ? c->n_lanes : 1;
+    }
+    return lanes_tunable(c, total_paths) ? c->lane_choice : 1;
+}
+
 // Paths per pass, and the queues of every lane. One pass if the frame fits and there is one lane; with several lanes
 // the frame is cut into at least that many passes (when it is large enough for the cut to be worth a launch sequence).
 void setup_queues(crt_hip_ctx *c)
@@ -309,8 +329,9 @@ void setup_queues(crt_hip_ctx *c)
     const uint64_t total_slots = (uint64_t)c->n_local_tiles * TILE_PIXELS;
     const uint64_t total_paths = total_slots * c->spp;
     uint64_t cap = std::min<uint64_t>(default_capacity(), total_paths);
-    if (c->n_lanes > 1 && total_paths >= ((uint64_t)c->n_lanes << 18) && (c->lanes_forced || total_paths <= crt_hip_ctx::LANES_MAX_PATHS)) {
-        cap = std::min<uint64_t>(cap, (total_paths + (uint64_t)c->n_lanes - 1) / (uint64_t)c->n_lanes + 64ull * c->spp);
+    const int lanes = lanes_for(c, total_paths);
+    if (lanes > 1) {
+        cap = std::min<uint64_t>(cap, (total_paths + (uint64_t)lanes - 1) / (uint64_t)lanes + 64ull * c->spp);
     }
     cap = std::min<uint64_t>(cap, 1ull << PATH_ID_BITS); // a path's index shares its queue word with its ray count (crt_types.h)
     const uint64_t slots_per_pass = std::max<uint64_t>(64, (cap / c->spp) / 64 * 64);
@@ -320,7 +341,8 @@ void setup_queues(crt_hip_ctx *c)
     }
     c->capacity = cap;
     const uint32_t n_pass = (uint32_t)((total_paths + cap - 1) / cap);
-    const int used_lanes = (int)std::min<uint32_t>((uint32_t)c->n_lanes, std::max<uint32_t>(1u, n_pass));
+    const int used_lanes = (int)std::min<uint32_t>((uint32_t)lanes, std::max<uint32_t>(1u, n_pass));
+    c->lanes_in_use = used_lanes;
     for (int i = 0; i < crt_hip_ctx::MAX_LANES; ++i) {
         if (i < used_lanes) {
             carve_queues(c->lanes[i], cap);
@@ -500,6 +522,8 @@ int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
         HIP_CHECK(hipMemsetAsync(ctx->d_img.ptr, 0, ctx->d_img.bytes, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->capacity = 0; // queues are (re)sized lazily: they depend on spp too
+        ctx->lane_tune = 0;
+        ctx->lane_choice = 1;
         return CRT_HIP_OK;
     });
 }
@@ -516,6 +540,8 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->has_scene = false;
     ctx->spp = ps.spp;
     ctx->capacity = 0;
+    ctx->lane_tune = 0;
+    ctx->lane_choice = 1;
     upload(ctx->d_nodes, ps.nodes, ctx->stream);
     upload(ctx->d_slots, ps.slots, ctx->stream);
     upload(ctx->d_tri_uvs, ps.tri_uvs, ctx->stream);
@@ -806,7 +832,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         const int tile_buf = ctx->tile_fb_last ^ 1;
         const auto t0 = std::chrono::high_resolution_clock::now();
         const uint32_t n_pass_frame = (uint32_t)((total_slots + slots_per_pass - 1) / slots_per_pass);
-        const int used_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, std::max<uint32_t>(1u, n_pass_frame));
+        const int used_lanes = (int)std::min<uint32_t>((uint32_t)ctx->lanes_in_use, std::max<uint32_t>(1u, n_pass_frame));
         ctx->lanes[0].main = ctx->stream;
         if (used_lanes > 1 && !ctx->lane_aux) {
             overlap = false;
@@ -934,6 +960,24 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             }
         }
         st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
+        // one lane or two for frames of this size? (crt_hip_ctx::PassLane) frame 1 is timed with one lane, frame 2 with two
+        if (ctx->lane_tune < 3 && lanes_tunable(ctx, total_slots * ctx->spp)) {
+            if (ctx->lane_tune == 1) {
+                ctx->lane_t1 = st.render_time_ms;
+                ctx->lane_choice = 2;
+                ctx->capacity = 0; // the queues are carved again before the next frame
+            } else if (ctx->lane_tune == 2) {
+                if (!(st.render_time_ms < ctx->lane_t1)) {
+                    ctx->lane_choice = 1;
+                    ctx->capacity = 0;
+                }
+                if (std::getenv("CRT_HIP_DEBUG")) {
+                    std::fprintf(stderr, "[crt_hip] pass lanes: %.3f ms with one, %.3f ms with two -> %d\n", ctx->lane_t1, st.render_time_ms,
+                                 ctx->lane_choice);
+                }
+            }
+            ++ctx->lane_tune;
+        }
         st.rays_per_second = (float)(st.rays / (st.render_time_ms * 1.0e-3));
         if (timing) {
             const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
