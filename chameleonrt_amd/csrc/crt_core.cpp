@@ -146,7 +146,7 @@ struct crt_hip_ctx {
     // (profiles/r03_pass_lanes_ab.txt: C2 7.45 ms with two streams either way; 7.49 / 9.58 ms with four). CRT_HIP_LANE_AUX=1
     // restores the per-lane occlusion stream.
     bool lane_aux = false;
-    bool lanes_forced = false; // CRT_HIP_LANES given: cut every frame that is large enough; else only small frames (setup_queues)
+    bool lanes_forced = false; // CRT_HIP_LANES given: cut every frame that is large enough; else small frames by trial
     hipEvent_t ev_begin = nullptr;
     int n_cus = 256;
     std::string name, err;
@@ -430,7 +430,7 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
                 l.owns_main = true;
                 HIP_CHECK(hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
             }
-            if (c->overlap) {
+            if (c->overlap && (i == 0 || c->lane_aux)) { // the occlusion stream: of the single lane, or of every lane on request
                 HIP_CHECK(hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
                 HIP_CHECK(hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming));
