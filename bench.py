@@ -152,6 +152,12 @@ def timed_frames(loop, args, dist, first_frame):
     acc = dict(rays=0, closest_rays=0, shadow_rays=0, closest_ms=0.0, shadow_ms=0.0, shade_ms=0.0, raygen_ms=0.0, accumulate_ms=0.0)
     for k in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
         acc[k] = [0.0] * MAX_PATH_DEPTH
+    if os.environ.get("CRT_HIP_OVERLAP") != "0":
+        # set-up, not warm-up: with the overlapped schedule the library tries frames of up to 8 Mi paths with one pass lane
+        # and with two (frames 1 and 2 after a configuration) and keeps the faster; let it decide
+        # before the W warm-up steps, whatever W is. Each of these restarts the accumulation, like step 0 below.
+        for _ in range(3):
+            loop.step(0)
     for f in range(args.warmup):
         loop.step(first_frame + f)
     loop.drain()
