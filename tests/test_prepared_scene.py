@@ -446,3 +446,37 @@ def test_meshes_and_scenes_without_triangles(levels, oracle, monkeypatch):
     assert (w["inst"] == -1).all() and w["tris"] == 0
     w = oracle.walk_product_bvh(bvh, org, dirs, 1e-4, np.full(len(org), 5.0, np.float32), closest=False)
     assert (w["t"] == 1.0).all()
+
+
+def test_leaf_slots_hold_every_triangle_once_in_its_own_vertex_order():
+    """The 64-byte leaf slots (crt_types.h LeafSlot, leaf_slots.h): triangle A is (v0, v1, v2), triangle B is picked from the
+    four vertices by the 2-bit selectors next to the geomID. Every triangle of a single-instance scene must sit in exactly
+    one slot WITH ITS OWN VERTICES IN ITS OWN ORDER (the kernels form e1 = v0 - v1 and e2 = v2 - v0 from them, and t / u / v
+    keep the reference's bits only for that order); the two triangles of a slot belong to one geometry and share an edge."""
+    sc = scenes.sponza_like(detail=0.05, tex_size=8)
+    assert len(sc.instances) == 1
+    ps = PreparedScene(sc)
+    slots = ps.bvh()["tris"]
+    ps.close()
+    v = slots[:, 0:12].view(np.float32).reshape(-1, 4, 3)
+    geom = slots[:, 12] & ((1 << 26) - 1)
+    sel = slots[:, 12] >> 26
+    prim0, prim1 = slots[:, 13], slots[:, 14]
+    two = prim1 != 0xffffffff
+    assert two.mean() > 0.5, "a tessellated scene is mostly quads"
+    pick = lambda s: v[np.arange(len(v)), s & 3]  # noqa: E731
+    tri_a = np.stack([v[:, 0], v[:, 1], v[:, 2]], axis=1)
+    tri_b = np.stack([pick(sel), pick(sel >> 2), pick(sel >> 4)], axis=1)
+    mesh = sc.meshes[sc.parameterized_meshes[sc.instances[0].parameterized_mesh_id].mesh_id]
+    seen = [np.zeros(len(g.indices), np.int32) for g in mesh.geometries]
+    for g_id, g in enumerate(mesh.geometries):
+        src = np.asarray(g.vertices, np.float32)[np.asarray(g.indices, np.int64)]  # (n, 3, 3): the triangles as the scene has them
+        for prims, tris, mask in ((prim0, tri_a, geom == g_id), (prim1, tri_b, (geom == g_id) & two)):
+            p = prims[mask].astype(np.int64)
+            assert (p < len(src)).all()
+            assert np.array_equal(tris[mask].view(np.uint32), src[p].view(np.uint32)), "vertices or their order differ from the scene's"
+            np.add.at(seen[g_id], p, 1)
+    assert all((s == 1).all() for s in seen), "a triangle is missing from the slots or sits in two"
+    # the pair shares an edge: two of B's three vertices are vertices of A (bit for bit)
+    shared = (tri_b[two][:, :, None, :].view(np.uint32) == tri_a[two][:, None, :, :].view(np.uint32)).all(axis=3).any(axis=2).sum(axis=1)
+    assert (shared >= 2).all()
