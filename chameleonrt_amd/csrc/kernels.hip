@@ -439,67 +439,26 @@ CRT_DEV void nee_setup(const SceneView &sc, const Surface &mat, V3 normal, V3 w_
 }
 
 // ---- K3 shade: render_embree.ispc:251-335 + sample_direct_light :105-181 -----------------------
-// Output compaction. Survivors are first appended to an LDS staging buffer (wave ballot +
-// LDS atomic); whenever a buffer holds a full block's worth, SHADE_BLOCK entries leave for HBM
-// with ONE memory-side atomic and fully coalesced 1-KiB-per-wave stores. This keeps the queue
-// counters (a single word each) far below their ~88 atomics/us ceiling.
-#ifndef CRT_SHADE_FLUSH
-#define CRT_SHADE_FLUSH 64 // staged entries that trigger a flush; LDS = (256 + this) * 23 * 4 B (128: C4 shade +4 %, 256: +9 %; 1 .. 32: as 64)
-#endif
+// Output compaction. Survivors are appended to an LDS staging buffer (wave ballot + LDS atomic) and every step sends
+// what it staged -- at most SHADE_BLOCK entries per queue -- to HBM with ONE memory-side atomic per queue and coalesced
+// stores, three barriers per step. This keeps the queue counters (a single word each) far below their ~88 atomics/us
+// ceiling. (Rounds 1-2 kept up to 128 entries back for a fuller flush and slid the rest down: seven barriers per step,
+// 12 KB more LDS, 16 B more scratch; C4 shade 16.9 -> 16.1 ms without it, profiles/r03_shade_grid_ab.txt.)
 #ifndef CRT_SHADE_GRID
 #define CRT_SHADE_GRID (8 * 256 / CRT_SHADE_BLOCK) // blocks per CU in the grid-stride launch of k_shade
 #endif
 #ifndef CRT_SHADE_WAVES
 #define CRT_SHADE_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int STAGE_CAP = SHADE_BLOCK + CRT_SHADE_FLUSH;
+constexpr int STAGE_CAP = SHADE_BLOCK;
 struct ShadeStage {
     uint32_t next[11][STAGE_CAP]; // PathQueue fields in declaration order
     uint32_t a[12][STAGE_CAP];    // ShadowQueueA fields in declaration order
-    uint32_t n_next, n_a, base;
+    uint32_t cnt_a[2], cnt_next[2]; // entries staged in this step; the counters alternate with the step's parity
+    uint32_t base, base_next;       // where the step's entries go in the global queues
 };
 static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 12 * sizeof(void *),
               "queue structs are arrays of field pointers");
-
-// Block-wide: if the staging buffer holds at least `threshold` entries, move up to SHADE_BLOCK of
-// them to the global SoA queue (what is left is < threshold, so the buffer never overflows when
-// the next iteration appends up to SHADE_BLOCK more). Must be called by every thread of the block.
-template <int NF>
-CRT_DEV void flush_stage(uint32_t (*buf)[STAGE_CAP], uint32_t &count, uint32_t &base_slot, uint32_t *global_counter,
-                         uint32_t *const *fields, uint32_t threshold)
-{
-    uint32_t n = count; // uniform: read after a barrier
-    if (n < threshold || n == 0) {
-        return;
-    }
-    const uint32_t take = min(n, (uint32_t)SHADE_BLOCK);
-    if (threadIdx.x == 0) {
-        base_slot = atomicAdd(global_counter, take);
-    }
-    __syncthreads();
-    const uint32_t base = base_slot;
-    const uint32_t t = threadIdx.x;
-    uint32_t keep[NF];
-    const bool mover = take + t < n; // entries beyond `take` slide down to the front
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-        if (t < take) {
-            fields[k][base + t] = buf[k][t];
-        }
-        keep[k] = mover ? buf[k][take + t] : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-        if (mover) {
-            buf[k][t] = keep[k];
-        }
-    }
-    if (t == 0) {
-        count = n - take;
-    }
-    __syncthreads();
-}
 
 __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
@@ -507,10 +466,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
 {
     __shared__ ShadeStage stage;
     if (threadIdx.x == 0) {
-        stage.n_next = 0;
-        stage.n_a = 0;
+        stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = 0;
     }
     __syncthreads();
+    uint32_t parity = 0;
     const uint32_t n = pc->n_queue[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
@@ -611,7 +570,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             sb.tp[2][slot_b] = tp_in.z;
             sb.path[slot_b] = path;
         }
-        const uint32_t la = wave_append_lds(&stage.n_a, is_hit);
+        const uint32_t la = wave_append_lds(&stage.cnt_a[parity], is_hit);
         if (is_hit) {
             const V3 c = tp_in * c_a;
             stage.a[0][la] = __float_as_uint(hit_p.x);
@@ -657,7 +616,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         }
 
         // Phase 4 (wave-uniform): stage the continuation rays, flush full staging buffers.
-        const uint32_t ln = wave_append_lds(&stage.n_next, alive);
+        const uint32_t ln = wave_append_lds(&stage.cnt_next[parity], alive);
         if (alive) {
             stage.next[0][ln] = __float_as_uint(hit_p.x);
             stage.next[1][ln] = __float_as_uint(hit_p.y);
@@ -672,15 +631,37 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             stage.next[10][ln] = __float_as_uint(tp.z);
         }
         __syncthreads();
-        flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa),
-                        CRT_SHADE_FLUSH);
-        flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
-                        reinterpret_cast<uint32_t *const *>(&qout), CRT_SHADE_FLUSH);
+        // everything staged in this step leaves now: one atomic per queue, coalesced stores, and the counters of the
+        // OTHER parity (last read before the previous step's final barrier) are zeroed for the next step
+        if (threadIdx.x == 0) {
+            const uint32_t na = stage.cnt_a[parity], nn = stage.cnt_next[parity];
+            stage.base = na ? atomicAdd(&pc->n_shadow_a[bounce], na) : 0u;
+            stage.base_next = nn ? atomicAdd(&pc->n_queue[bounce + 1], nn) : 0u;
+            stage.cnt_a[parity ^ 1u] = 0;
+            stage.cnt_next[parity ^ 1u] = 0;
+        }
+        __syncthreads();
+        {
+            const uint32_t t = threadIdx.x, na = stage.cnt_a[parity], nn = stage.cnt_next[parity];
+            const uint32_t ba = stage.base, bn = stage.base_next;
+            uint32_t *const *fa = reinterpret_cast<uint32_t *const *>(&sa);
+            uint32_t *const *fn = reinterpret_cast<uint32_t *const *>(&qout);
+            if (t < na) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    fa[k][ba + t] = stage.a[k][t];
+                }
+            }
+            if (t < nn) {
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    fn[k][bn + t] = stage.next[k][t];
+                }
+            }
+        }
+        __syncthreads(); // the buffers are free again
+        parity ^= 1u;
     }
-    // drain what is left (fewer than CRT_SHADE_FLUSH entries per queue)
-    flush_stage<12>(stage.a, stage.n_a, stage.base, &pc->n_shadow_a[bounce], reinterpret_cast<uint32_t *const *>(&sa), 1);
-    flush_stage<11>(stage.next, stage.n_next, stage.base, &pc->n_queue[bounce + 1],
-                    reinterpret_cast<uint32_t *const *>(&qout), 1);
 }
 
 // ---- K5 accumulate: render_embree.ispc:339-353 + tile_to_uint8 :358-370 ------------------------
