@@ -14,12 +14,8 @@
 #include <string>
 #include <vector>
 
-#ifdef CRT_HIP_STANDIN
-#include "standin/chameleonrt_standin.h" // compile check only: SDL2 / glm are not in this image
-#else
 #include "render_backend.h"
 #include <glm/glm.hpp>
-#endif
 
 struct crt_hip_ctx;
 

@@ -4,8 +4,9 @@
 // (`readback_framebuffer`: screenshots, -validation dumps; main.cpp:306-325).
 #include "render_hip_gl.h"
 
-#include <hip/hip_gl_interop.h>
 #include <hip/hip_runtime_api.h>
+// after hip_runtime_api.h (it uses hipError_t without including it) and after glad (gldisplay.h), which must precede any GL header
+#include <hip/hip_gl_interop.h>
 
 #include <stdexcept>
 

@@ -4,15 +4,16 @@
 // dynamic_cast, gldisplay.cpp:105-124; the OptiX backend is the reference's user of it,
 // backends/optix/render_optix.cpp:104-121,410-426).
 //
-// NOT COMPILED IN THIS REPOSITORY'S IMAGE: it needs the reference's display headers (SDL2, glad) and a
-// GL context; `backends/hip/CMakeLists.txt` builds it with -DCRT_HIP_GL_INTEROP=ON inside a ChameleonRT
-// tree. What it stands on IS tested here: crt_hip_device_framebuffer (the row-major RGBA8 image in HBM,
-// tests/test_gpu_edge_cases.py) and render() with readback = false.
+// Type-checked in this repository against the reference's real gldisplay.h + glad and ROCm's hip_gl_interop.h
+// (`make -C oracle boundary_check`, tests/test_boundary_headers.py); it cannot RUN here -- no GL context exists in
+// the image or on the GPU box -- and `backends/hip/CMakeLists.txt` builds it with -DCRT_HIP_GL_INTEROP=ON inside
+// a ChameleonRT tree. What it stands on IS executed: crt_hip_device_framebuffer (the row-major RGBA8 image in
+// HBM, tests/test_gpu_edge_cases.py) and render() with readback = false.
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include "display/gldisplay.h"
 #include "render_hip.h"
-
-struct hipGraphicsResource;
 
 struct RenderHIPGL : GLNativeRenderer {
     RenderHIPGL();
@@ -30,6 +31,6 @@ struct RenderHIPGL : GLNativeRenderer {
 
 private:
     RenderHIP inner; // all rendering; this class only moves the finished image into the GL texture
-    hipGraphicsResource *hip_display_texture = nullptr;
+    hipGraphicsResource_t hip_display_texture = nullptr;
     int width = 0, height = 0;
 };
