@@ -33,7 +33,7 @@ EXPORTS = [
     "crt_hip_prepared_scene_world_instance", "crt_hip_world_instance",
     "crt_hip_prepare_scene_on", "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
-    "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp",
+    "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp", "crt_hip_debug_copy_queue",
 ]
 
 
@@ -105,6 +105,8 @@ def load():
     L.crt_hip_trace_rays.argtypes = [vp, C.c_uint64, fp, fp, fp, fp, C.c_int, fp, fp, fp, i32p, i32p, i32p,
                                      C.POINTER(RenderStats)]
     L.crt_hip_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
+    L.crt_hip_debug_copy_queue.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, fp]
+    L.crt_hip_debug_copy_queue.restype = C.c_int
     L.crt_hip_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32p, fp]
     L.crt_hip_bvh_copy.argtypes = [vp, vp, vp]
     L.crt_hip_bvh_layout.argtypes = [vp, i32p, u32p, u32p, u32p, i32p]

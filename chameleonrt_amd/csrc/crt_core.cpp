@@ -1203,6 +1203,32 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
     });
 }
 
+// Diagnostics (include/crt_hip.h): the rays a frame left behind in lane 0's queues, AoS on the host side.
+int crt_hip_debug_copy_queue(crt_hip_ctx *ctx, int which, uint64_t first, uint64_t n, float *out)
+{
+    return guarded(ctx, [&]() -> int {
+        if (!out || ctx->capacity == 0 || which < 0 || which > 2 || first + n > ctx->capacity) {
+            return fail(ctx, CRT_HIP_EINVAL, "debug_copy_queue: bad arguments (or no frame rendered yet)");
+        }
+        const crt_hip_ctx::PassLane &l = ctx->lanes[0];
+        const int n_fields = which == 2 ? 7 : 6;
+        const float *src[7];
+        for (int a = 0; a < 3; ++a) {
+            src[a] = which == 2 ? l.sa.o[a] : l.q[which].o[a];
+            src[3 + a] = which == 2 ? l.sa.d[a] : l.q[which].d[a];
+        }
+        src[6] = l.sa.tmax;
+        std::vector<float> field(n);
+        for (int k = 0; k < n_fields; ++k) {
+            HIP_CHECK(hipMemcpy(field.data(), src[k] + first, n * sizeof(float), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n; ++i) {
+                out[i * n_fields + k] = field[i];
+            }
+        }
+        return CRT_HIP_OK;
+    });
+}
+
 int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_stride, float *out, int out_stride)
 {
     return guarded(ctx, [&]() -> int {

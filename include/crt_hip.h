@@ -266,6 +266,13 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
                        int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
                        crt_render_stats *stats);
 
+/* Diagnostics: copy rays out of the queues the last rendered frame left behind (lane 0 of the pass lanes), as
+ * records of floats on the host: which = 0 / 1: PathQueue buffer 0 / 1 (bounce b's closest-hit rays sit in buffer
+ * b & 1), 6 floats per ray {o, d}; which = 2: ShadowQueueA (the last bounces' occlusion rays), 7 floats {o, d, tmax}.
+ * Used by tools/gpu_sort_probe.py to re-trace a frame's real incoherent rays in other orders (crt_hip_trace_rays with
+ * CRT_HIP_TRACE_PRODUCTION). No reference counterpart. */
+int crt_hip_debug_copy_queue(crt_hip_ctx *ctx, int which, uint64_t first, uint64_t n, float *out);
+
 /* Known-answer tests of the device shading functions: run device function `fn` on n
  * input records of in_stride floats, producing out_stride floats each (see
  * include/crt_kat.h for the record layouts). */
