@@ -35,6 +35,9 @@ NODE_BYTES, SLOT_BYTES = 64, 64  # quantised BVH4 node / leaf slot of one or two
 QUEUE_BYTES_CLOSEST = 24 + 32   # o,d read + the 32-byte hit record {t,u,v,tri | normal,material} written per ray
 QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
 MAX_PATH_DEPTH = 5
+# CU-cycles of the vector-memory front end per divergent 64-byte line visit (tools/policy_microbench.hip, `plain`,
+# 100 % of the lanes active, profiles/r04_policy_microbench.txt): working set in L2 (1 MB) / in HBM (128 MB .. 1 GB)
+LINE_VISIT_CYCLES_L2, LINE_VISIT_CYCLES_HBM = 2.93, 10.6
 
 
 def parse():
@@ -62,6 +65,9 @@ def parse():
     ap.add_argument("--no-speed-mode", action="store_true", help="N = 1: do not also time the opt-in fast-math build")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
+    ap.add_argument("--also", default=None, metavar="WxHxSPP",
+                    help="N > 1: after the headline, time the same scene at another resolution / spp too (reported as `c5`); default "
+                         "at --gpus 8 on C4: 3840x2160x64 = BASELINE.json's own 8-GPU configuration C5; 'none' switches it off")
     return ap.parse_args()
 
 
@@ -119,6 +125,13 @@ class FrameLoop:
         self.views = {}
         self.pending = None  # (work handle, gathered tensor) of the previous frame
 
+    @property
+    def lanes_tunable(self):
+        """Does the library try this rank's frames with one pass lane and with two? (crt_core.cpp lanes_tunable: 0.5 .. 8 Mi paths)"""
+        r = self.r
+        local_paths = -(-(-(-r.width // 64) * -(-r.height // 64)) // self.world) * 4096 * r.samples_per_pixel
+        return (1 << 19) <= local_paths <= (8 << 20)
+
     def _finish_pending(self):
         if self.pending is not None:
             work, gathered = self.pending
@@ -154,10 +167,12 @@ def timed_frames(loop, args, dist, first_frame):
         acc[k] = [0.0] * MAX_PATH_DEPTH
     if os.environ.get("CRT_HIP_OVERLAP") != "0":
         # set-up, not warm-up: with the overlapped schedule the library tries frames of up to 8 Mi paths with one pass lane
-        # and with two (frames 1 and 2 after a configuration) and keeps the faster; let it decide
+        # and with two (six frames after a configuration) and keeps the faster; let it decide
         # before the W warm-up steps, whatever W is. Each of these restarts the accumulation, like step 0 below.
-        for _ in range(3):
-            loop.step(0)
+        # Larger frames are never cut: nothing to decide, no set-up frames.
+        if loop.lanes_tunable:
+            for _ in range(6):
+                loop.step(0)
     for f in range(args.warmup):
         loop.step(first_frame + f)
     loop.drain()
@@ -179,6 +194,7 @@ def timed_frames(loop, args, dist, first_frame):
             arr = getattr(st, name)
             for b in range(MAX_PATH_DEPTH):
                 acc[name][b] += arr[b]
+        acc["pass_lanes"], acc["passes"] = int(st.pass_lanes), int(st.passes)
     loop.drain()  # the last frame's gather + assemble belong to the timed region
     torch.cuda.synchronize()
     if dist:
@@ -382,6 +398,38 @@ def main():
                           f"{args.schedule} schedule; NOT the build the parity tests and the headline are about")
             out["speed_mode"] = sm
 
+    # how each rank's frames were cut (the library's one-lane / two-lane trial is per context: say what it chose)
+    lanes_all = [acc.get("pass_lanes", 1)]
+    if dist:
+        gathered_lanes = [None] * world
+        dist.all_gather_object(gathered_lanes, acc.get("pass_lanes", 1))
+        lanes_all = gathered_lanes
+    if rank == 0:
+        out["config"]["passes_per_frame"] = acc.get("passes", 1)
+        out["config"]["pass_lanes"] = lanes_all if world > 1 else lanes_all[0]
+
+    # ---- N > 1: what the per-step collective costs when nothing hides it (in the timed loop the gather of frame f runs
+    # next to the tracing of frame f+1): K isolated gather + K8 assemble rounds of the last frame's tile buffers ----
+    if world > 1:
+        ptr, nbytes = r.tile_buffer()
+        view = loop.views.get(ptr)
+        if view is None:
+            view = wrap_device_buffer(ptr, nbytes)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_iso = 10
+        for _ in range(n_iso):
+            g = loop.multi_gpu.gather_tile_buffers(view.cpu() if share_gpu else view)
+            if rank == 0:
+                r.assemble_tiles((g.cuda() if share_gpu else g).data_ptr(), world, readback=False)
+            torch.cuda.synchronize()
+        iso_ms = (time.perf_counter() - t0) / n_iso * 1e3
+        if rank == 0:
+            out["gather"] = {"isolated_ms": round(iso_ms, 4), "bytes_per_rank": int(nbytes),
+                             "note": "dist.gather of the compact RGBA8 tile buffers to rank 0 + kernel K8, host-synchronised, NOT "
+                                     "overlapped; inside the timed steps it runs next to the next frame's tracing"}
+
     # ---- N > 1: the weak-scaling figure next to the strong-scaling headline (or the other way round) ----
     if world > 1:
         other = "weak" if args.scaling == "strong" else "strong"
@@ -393,6 +441,33 @@ def main():
             out[f"{other}_scaling"] = {"value": round(rays2 / e2 / 1e6, 2), "unit": "MRay/s", "spp_per_frame": spp2,
                                        "ms_per_step": round(e2 / args.steps * 1e3, 4), "steps": args.steps}
         ps.set_samples_per_pixel(spp)
+
+    # ---- N = 8 on C4: BASELINE.json's own 8-GPU configuration next to the strong-scaling headline: C5 = the same scene at
+    # 3840x2160, 64 spp (16x the pixel-samples of C4: each rank renders twice a single GPU's C4 frame per step) ----
+    also = args.also
+    if also is None and world == 8 and args.workload == "C4":
+        _, kw5, w5, h5, spp5 = scenes.WORKLOADS["C5"]
+        assert kw5 == kw
+        also = f"{w5}x{h5}x{spp5}"
+    if world > 1 and also and also != "none":
+        w5, h5, spp5 = (int(x) for x in also.lower().split("x"))
+        ps.set_samples_per_pixel(spp5)
+        r.initialize(w5, h5)
+        r.set_prepared_scene(ps)
+        loop.views.clear()  # the tile buffers were re-allocated
+        import copy
+        a5 = copy.copy(args)
+        a5.steps, a5.warmup = min(args.steps, 4), 1
+        e5, rays5, acc5 = timed_frames(loop, a5, dist, 0)
+        if rank == 0:
+            out["c5"] = {"workload": f"{'C5' if (w5, h5, spp5) == scenes.WORKLOADS['C5'][2:] and args.workload == 'C4' else args.workload} {meta['name']} {w5}x{h5}", "spp_per_frame": spp5, "value": round(rays5 / e5 / 1e6, 2),
+                         "unit": "MRay/s", "ms_per_step": round(e5 / a5.steps * 1e3, 4), "steps": a5.steps, "warmup": a5.warmup,
+                         "rays_per_step": rays5 // a5.steps, "passes_per_frame_rank0": acc5.get("passes"),
+                         "note": "BASELINE.json configs[4]: tile split over 8 GPUs + RCCL gather of the 4K framebuffer every step"}
+        ps.set_samples_per_pixel(spp)
+        r.initialize(width, height)
+        r.set_prepared_scene(ps)
+        loop.views.clear()
 
     # ---- roofline of the traversal kernels (rank 0's share; identical code on every rank) ----
     if rank == 0 and not args.no_roofline:
@@ -482,6 +557,8 @@ def main():
 
         rc = roof("k_trace_closest", bytes_closest, acc["closest_rays"], acc["closest_ms"])
         rs = roof("k_trace_shadow", bytes_shadow, acc["shadow_rays"], acc["shadow_ms"])
+        rc["line_visits_per_ray"] = (cn + csl) / max(1, cr)
+        rs["line_visits_per_ray"] = (sn + ssl) / max(1, sr)
         if args.schedule == "serial":
             dom, other_k = (rc, rs) if acc["closest_ms"] >= acc["shadow_ms"] else (rs, rc)
         else:  # the occlusion spans include queueing: the closest-hit kernel, whose spans are clean, is the one reported first
@@ -500,6 +577,23 @@ def main():
                 # what actually binds the kernel, next to the contract's HBM axis: never above 1 by construction
                 base["binding"] = {"resource": "per-CU vector-memory front end (TA busy cycles / kernel cycles)",
                                    "frac": k["vmem_front_end"]["ta_busy_frac"], "l2_hit_rate": k["vmem_front_end"]["l2_hit_rate"]}
+            # the bound argued for in DESIGN.md section 6, checkable from this line alone: CU-cycles the launch spends per
+            # 64-byte line visit (nodes + leaf slots, counted by the instrumented kernels) against what the microbenchmark
+            # says such a visit costs the front end at this run's L2 hit rate
+            v = k.get("line_visits_per_ray")
+            if v:
+                clock = (k.get("valu") or {}).get("clock_GHz") or CLOCK_GHZ
+                cyc = N_CUS * clock * 1e9 * k["avg_launch_ms"] * 1e-3 / max(1, k["rays_per_launch"]) / v
+                hit = (k.get("vmem_front_end") or {}).get("l2_hit_rate")
+                b = base.setdefault("binding", {})
+                b["line_visits_per_ray"] = round(v, 2)
+                b["cycles_per_line_visit"] = round(cyc, 2)
+                if hit is not None:
+                    ceil = hit * LINE_VISIT_CYCLES_L2 + (1.0 - hit) * LINE_VISIT_CYCLES_HBM
+                    b["ceiling_cycles"] = round(ceil, 2)
+                    b["frac_of_front_end_ceiling"] = round(ceil / cyc, 3)
+                    b["ceiling_note"] = (f"{LINE_VISIT_CYCLES_L2} CU-cycles per divergent 64-byte line visit that hits L2, {LINE_VISIT_CYCLES_HBM} "
+                                         "from HBM (tools/policy_microbench.hip, profiles/r04_policy_microbench.txt), blended by l2_hit_rate")
             return base
 
         out["roofline"] = contract(dom)

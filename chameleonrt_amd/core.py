@@ -47,7 +47,8 @@ class RenderStats(C.Structure):
                 ("closest_rays_bounce", C.c_uint64 * 5), ("shadow_rays_bounce", C.c_uint64 * 5),
                 ("closest_ms_bounce", C.c_float * 5), ("shadow_ms_bounce", C.c_float * 5), ("shade_ms_bounce", C.c_float * 5),
                 ("raygen_ms", C.c_float), ("accumulate_ms", C.c_float),
-                ("closest_slots", C.c_uint64), ("shadow_slots", C.c_uint64)]
+                ("closest_slots", C.c_uint64), ("shadow_slots", C.c_uint64),
+                ("passes", C.c_uint32), ("pass_lanes", C.c_uint32)]  # ABI 3
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

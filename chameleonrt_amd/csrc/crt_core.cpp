@@ -118,12 +118,16 @@ struct crt_hip_ctx {
     // Measured (profiles/r03_pass_lanes_ab.txt): C2 (3.7 M paths per frame) 8.60 -> 7.55 ms with two lanes; C4 (33 M) 68.0 ->
     // 69.6 ms and C3 (16.6 M) 9.9 -> 10.2 ms -- two passes' kernels side by side also share the caches; and one eighth of
     // C4 (4.1 M paths of expensive rays) 10.1 -> 11.2 ms. Path count alone does not tell, so frames of at most
-    // LANES_MAX_PATHS paths are TRIED both ways: the second frame after a (re)configuration is timed with one lane, the
-    // third with two, and the faster stays (images are bit-identical either way). CRT_HIP_LANES=n cuts every frame.
+    // LANES_MAX_PATHS paths are TRIED both ways after a (re)configuration: frame 0 warms up, frames 1-2 run with one lane,
+    // frame 3 warms the re-carved queues up with two, frames 4-5 run with two; the smaller of each setting's two frame
+    // times decides (one noisy frame cannot lock the slower setting in), the choice is reported in crt_render_stats::
+    // pass_lanes and images are bit-identical either way. CRT_HIP_LANES=n cuts every frame (ranks of a multi-GPU job that
+    // must agree set it).
     static constexpr uint64_t LANES_MAX_PATHS = 8ull << 20;
+    static constexpr int LANE_TUNE_FRAMES = 6;
     int lane_choice = 1;   // lanes the next setup_queues cuts a tunable frame for
-    int lane_tune = 0;     // frames rendered since the last (re)configuration, up to 3 (tuned)
-    float lane_t1 = 0.f;   // frame time with one lane
+    int lane_tune = 0;     // frames rendered since the last (re)configuration, up to LANE_TUNE_FRAMES (tuned)
+    float lane_t1 = 0.f, lane_t2 = 0.f; // best frame time with one lane / with two
     int lanes_in_use = 1;  // what setup_queues carved queues for
     struct PassLane {
         DeviceBuffer queue_mem, pc;
@@ -960,19 +964,27 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             }
         }
         st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
-        // one lane or two for frames of this size? (crt_hip_ctx::PassLane) frame 1 is timed with one lane, frame 2 with two
-        if (ctx->lane_tune < 3 && lanes_tunable(ctx, total_slots * ctx->spp)) {
-            if (ctx->lane_tune == 1) {
-                ctx->lane_t1 = st.render_time_ms;
+        // one lane or two for frames of this size? (crt_hip_ctx::PassLane)
+        st.passes = pass;
+        st.pass_lanes = (uint32_t)used_lanes;
+        if (ctx->lane_tune < crt_hip_ctx::LANE_TUNE_FRAMES && lanes_tunable(ctx, total_slots * ctx->spp)) {
+            const int f = ctx->lane_tune;
+            const float t = st.render_time_ms;
+            if (f == 1 || f == 2) {
+                ctx->lane_t1 = f == 1 ? t : std::min(ctx->lane_t1, t);
+            } else if (f == 4 || f == 5) {
+                ctx->lane_t2 = f == 4 ? t : std::min(ctx->lane_t2, t);
+            }
+            if (f == 2) {
                 ctx->lane_choice = 2;
                 ctx->capacity = 0; // the queues are carved again before the next frame
-            } else if (ctx->lane_tune == 2) {
-                if (!(st.render_time_ms < ctx->lane_t1)) {
+            } else if (f == 5) {
+                if (!(ctx->lane_t2 < ctx->lane_t1)) {
                     ctx->lane_choice = 1;
                     ctx->capacity = 0;
                 }
                 if (std::getenv("CRT_HIP_DEBUG")) {
-                    std::fprintf(stderr, "[crt_hip] pass lanes: %.3f ms with one, %.3f ms with two -> %d\n", ctx->lane_t1, st.render_time_ms,
+                    std::fprintf(stderr, "[crt_hip] pass lanes: %.3f ms with one, %.3f ms with two -> %d\n", ctx->lane_t1, ctx->lane_t2,
                                  ctx->lane_choice);
                 }
             }

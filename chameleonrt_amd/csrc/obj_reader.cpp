@@ -133,8 +133,19 @@ struct Parser {
         const auto r = std::from_chars(b, e, out);
         return r.ec == std::errc() && r.ptr == e;
     }
-    // OBJ indices are 1-based; negative = relative to what has been read so far
-    static int32_t resolve(long i, size_t n) { return (int32_t)(i > 0 ? i - 1 : (long)n + i); }
+    // OBJ indices are 1-based; negative = relative to what has been read so far. Checked in `long`, before narrowing: 0 or an
+    // index beyond what has been read (either way) is an error for v and vt -- never a silent "no texcoord". A normal index
+    // is never dereferenced (the hot path reads no normals): it only takes part in the (v, vn, vt)
+    // re-indexing key, like in the reference's reader (tinyobjloader's fixIndex checks 0 only), so beyond 0 it is only
+    // required to fit 32 bits (key_only).
+    static bool resolve(long i, size_t n, int32_t &out, bool key_only = false)
+    {
+        if (i == 0 || (!key_only && (i > (long)n || i < -(long)n)) || i > 0x7fffffffl || i < -0x7fffffffl) {
+            return false;
+        }
+        out = (int32_t)(i > 0 ? i - 1 : (long)n + i);
+        return true;
+    }
 
     bool parse_face()
     {
@@ -150,9 +161,12 @@ struct Parser {
                 return false;
             }
             Corner c;
-            c.v = resolve(vi, pos.size() / 3);
             c.t = -1;
             c.n = -1;
+            if (!resolve(vi, pos.size() / 3, c.v)) {
+                error = "face index out of range";
+                return false;
+            }
             if (s1) {
                 const char *te = s2 ? s2 : q;
                 if (te > s1 + 1) {
@@ -160,19 +174,21 @@ struct Parser {
                         error = "bad face index";
                         return false;
                     }
-                    c.t = resolve(ti, tex.size() / 2);
+                    if (!resolve(ti, tex.size() / 2, c.t)) {
+                        error = "face index out of range";
+                        return false;
+                    }
                 }
                 if (s2 && q > s2 + 1) {
                     if (!parse_int(s2 + 1, q, ni)) {
                         error = "bad face index";
                         return false;
                     }
-                    c.n = resolve(ni, n_normals);
+                    if (!resolve(ni, n_normals, c.n, true)) {
+                        error = "face index out of range";
+                        return false;
+                    }
                 }
-            }
-            if (c.v < 0 || (size_t)c.v >= pos.size() / 3 || (c.t >= 0 && (size_t)c.t >= tex.size() / 2)) {
-                error = "face index out of range";
-                return false;
             }
             p = q;
             if (count == 0) {

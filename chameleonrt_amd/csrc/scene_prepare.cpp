@@ -1400,7 +1400,8 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
         if (expect != file_size) {
             return refuse("size");
         }
-        if (h.n_insts != h.n_instances || h.n_instances == 0 || h.two_level > LEVELS_WORLD_TREE || h.n_nodes == 0 || h.n_tris == 0 ||
+        if (h.n_insts != h.n_instances || h.n_instances == 0 || h.two_level > LEVELS_WORLD_TREE || h.n_nodes == 0 ||
+            (h.n_tris == 0 && h.n_nodes != 1) /* only the empty scene's one-node tree has no leaf slots (make_empty_tree) */ ||
             h.root < 0 || (uint64_t)h.root >= h.n_nodes || (uint64_t)h.root + h.n_top > h.n_nodes || h.world_inst < -1 ||
             (h.world_inst >= 0 && (uint32_t)h.world_inst >= h.n_instances) || h.n_lights == 0 || h.n_lights_f != 20ull * h.n_lights ||
             h.n_materials == 0 || h.n_materials % 16 != 0 || h.spp == 0 || h.n_tris >= (1ull << 28)) {

@@ -15,6 +15,8 @@ a real ChameleonRT build for cross-checking.
 from __future__ import annotations
 
 import os
+import subprocess
+import sys
 from typing import Dict, List
 
 import numpy as np
@@ -49,6 +51,9 @@ def _load_texture(path: str, name: str) -> Image:
     im = PILImage.open(path).convert("RGBA")  # forced to 4 channels
     a = np.asarray(im, dtype=np.uint8)[::-1].copy()  # stbi_set_flip_vertically_on_load(1)
     return Image(a.shape[1], a.shape[0], 4, a, SRGB, name)
+
+
+_warned_native = False
 
 
 def _read_obj_native(path: str):
@@ -100,7 +105,16 @@ def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int =
     if reader == "python":
         return _load_obj_python(path, material_mode, samples_per_pixel)
     base_dir = os.path.dirname(os.path.abspath(path))
-    raw, libs = _read_obj_native(path)
+    try:
+        raw, libs = _read_obj_native(path)
+    except (OSError, subprocess.CalledProcessError) as e:
+        # no C++17 compiler with floating-point std::from_chars (libstdc++ >= 11) on this host, or the library does not
+        # load: the line-by-line twin reads the same arrays, only slower (this is scene ingest, not the render path)
+        global _warned_native
+        if not _warned_native:
+            _warned_native = True
+            print(f"[chameleonrt_amd.obj_io] native OBJ reader unavailable ({e}); using the Python reader", file=sys.stderr)
+        return _load_obj_python(path, material_mode, samples_per_pixel)
     if not raw:
         raise ValueError(f"no faces in {path}")
     obj_materials: List[dict] = []
@@ -135,8 +149,12 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
             shapes.append(cur)
         return cur
 
-    def resolve(i: int, n: int) -> int:
-        return i - 1 if i > 0 else n + i  # OBJ indices are 1-based; negative = relative
+    def resolve(i: int, n: int, key_only: bool = False) -> int:
+        # OBJ indices are 1-based; negative = relative. 0, or (v, vt) beyond what has been read either way: an error. A normal
+        # index is only a re-indexing key (never dereferenced; the reference's tinyobjloader checks it for 0 only).
+        if i == 0 or (not key_only and (i > n or i < -n)) or abs(i) > 0x7fffffff:
+            raise ValueError("face index out of range")
+        return i - 1 if i > 0 else n + i
 
     with open(path) as f:
         for line in f:
@@ -166,7 +184,7 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
                     parts = c.split("/")
                     vi = resolve(int(parts[0]), len(positions))
                     ti = resolve(int(parts[1]), len(texcoords)) if len(parts) > 1 and parts[1] else -1
-                    ni = resolve(int(parts[2]), len(normals)) if len(parts) > 2 and parts[2] else -1
+                    ni = resolve(int(parts[2]), len(normals), True) if len(parts) > 2 and parts[2] else -1
                     corners.append((vi, ni, ti))
                 s = shape()
                 for j in range(1, len(corners) - 1):  # triangulate as a fan

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CRT_HIP_ABI_VERSION 2
+#define CRT_HIP_ABI_VERSION 3
 #define CRT_HIP_MAX_PATH_DEPTH 5 /* MAX_PATH_DEPTH, backends/embree/util.ih:10 */
 
 enum {
@@ -137,6 +137,9 @@ typedef struct crt_render_stats {
     float raygen_ms, accumulate_ms;
     /* only when CRT_HIP_FLAG_COUNTERS: 64-byte leaf slots fetched (each holds one or two triangles) */
     uint64_t closest_slots, shadow_slots;
+    /* (ABI 3) how the frame was cut: passes (each at most the path capacity) and the pass lanes they ran on -- 1, or 2
+     * where the library's trial found two faster for frames of this size (bit-identical images either way) */
+    uint32_t passes, pass_lanes;
 } crt_render_stats;
 
 typedef struct crt_hip_ctx crt_hip_ctx;
@@ -257,8 +260,9 @@ int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered_device_ptr, in
  * diagnostic kernel (counts nodes / triangles into stats); set = the very kernels a frame launches
  * (k_trace_closest / k_trace_shadow without counters, fed through a PathQueue / ShadowQueueA and read back
  * from the HitBuf / radiance buffer like k_shade reads them), which requires tmin = 0 or EPSILON and, for
- * closest hits, tmax = 1e20 (set_ray_hit, util.ih:118) for every ray; out_inst is then -1 for a hit (the
- * frame's hit record does not carry it: K2 resolves normal and material itself) and stats carry no counters. */
+ * closest hits, tmax = 1e20 (set_ray_hit, util.ih:118) for every ray; out_inst is then the hit's instance as K2
+ * resolves it for its normal and material look-up (the frame's 32-byte hit record does not carry it: this call asks
+ * K2's retire for a copy, HitBuf::inst_debug) and stats carry no counters. */
 #define CRT_HIP_TRACE_PRODUCTION 2
 int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org /* n*3 */,
                        const float *dir /* n*3 */, const float *tmin, const float *tmax,

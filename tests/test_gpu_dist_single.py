@@ -32,7 +32,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CRT_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--workload", "C1", "--cpu-seconds", "0"]
+           "--warmup", "1", "--workload", "C1", "--cpu-seconds", "0", "--also", "320x200x3"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -42,6 +42,11 @@ def test_bench_two_ranks_on_one_gpu():
     # Cornell 512 x 512, 1 spp: every pixel-sample traces at least its primary ray, whatever the split
     assert out["config"]["rays_per_step"] >= 512 * 512
     assert "roofline" in out and out["roofline"]["traffic"] is None  # counter passes are a single-GPU leg
+    # what the N > 1 line says about itself: how every rank cut its frames, what the un-hidden collective costs, and the
+    # second configuration of the same scene (at --gpus 8 on C4 that is BASELINE.json's C5)
+    assert out["config"]["pass_lanes"] == [1, 1] and out["config"]["passes_per_frame"] == 1
+    assert out["gather"]["isolated_ms"] > 0 and out["gather"]["bytes_per_rank"] == 32 * 4096 * 4
+    assert out["c5"]["spp_per_frame"] == 3 and out["c5"]["value"] > 0 and out["c5"]["rays_per_step"] >= 320 * 200 * 3
 
 
 def test_gathered_image_equals_direct_image(hip_lib):

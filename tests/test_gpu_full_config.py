@@ -18,8 +18,12 @@ from tests.parity import MAX_DIVERGED, camera_of, compare_images
 
 pytestmark = pytest.mark.gpu
 
-# name: (workload, CRT_HIP_LEVELS or None, number of sampled tiles, expected levels, expected passes per frame)
+# name: (workload, CRT_HIP_LEVELS or None, number of sampled tiles, expected levels, expected passes per frame[, CRT_HIP_LANES])
 CASES = {
+    # Sponza-like 1280x720, 4 spp: the one configuration whose frames (3.7 M paths) the library cuts for two pass lanes by
+    # default (crt_core.cpp lanes_tunable) -- both cuts, forced, as configured
+    "C2_one_lane": ("C2", None, 32, 0, 1, "1"),
+    "C2_two_lanes": ("C2", None, 32, 0, 2, "2"),
     "C3": ("C3", None, 32, 0, 1),
     "C4": ("C4", None, 32, 2, 1),            # the library's choice for the instanced scene: a world tree
     "C4_two_level": ("C4", "two", 32, 1, 1),
@@ -48,15 +52,20 @@ def _tile_sample(w, h, n):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_full_config_tile_parity(case, oracle, hip_lib, monkeypatch):
-    workload, levels, n_tiles, want_levels, want_passes = CASES[case]
+    workload, levels, n_tiles, want_levels, want_passes = CASES[case][:5]
+    lanes = CASES[case][5] if len(CASES[case]) > 5 else None
     monkeypatch.delenv("CRT_HIP_MAX_PATHS", raising=False)  # the DEFAULT path capacity
+    monkeypatch.delenv("CRT_HIP_LANES", raising=False)
+    if lanes:
+        monkeypatch.setenv("CRT_HIP_LANES", lanes)  # read when the context is created
     sc, w, h, spp = _scene(workload)
     if levels:
         monkeypatch.setenv("CRT_HIP_LEVELS", levels)
     ps = PreparedScene(sc)
     assert ps.levels() == want_levels
     total_paths = ((w + 63) // 64) * ((h + 63) // 64) * 4096 * spp
-    assert -(-total_paths // (32 << 20)) == want_passes
+    if not lanes:
+        assert -(-total_paths // (32 << 20)) == want_passes
     r = RenderHIP()
     r.initialize(w, h)
     r.set_prepared_scene(ps)
@@ -71,6 +80,7 @@ def test_full_config_tile_parity(case, oracle, hip_lib, monkeypatch):
         st = r.render(e, d, u, fovy, True, True)
         o.render_tiles(e, d, u, fovy, True, tiles)
         assert st.rays > 2 * w * h * spp  # a real frame: at least a closest-hit and an occlusion ray per path on average
+        assert st.passes == want_passes and st.pass_lanes == (int(lanes) if lanes else 1)
         g, c = r.accum()[mask][:, None, :], o.accum()[mask][:, None, :]
         diverged, mean_rel = compare_images(g, c)
         print(f"\n{case}: {len(tiles)} tiles, {int(mask.sum())} pixels x {spp} spp: {diverged:.6f} diverged, mean rel {mean_rel:.2e}, "

@@ -4,6 +4,7 @@ Q14), texture flip + 4 channels (quirk Q13), default material for material-less 
 import os
 
 import numpy as np
+import pytest
 
 from chameleonrt_amd import scenes
 from chameleonrt_amd.obj_io import load_obj, save_obj
@@ -195,3 +196,28 @@ def test_native_reader_refuses_garbage_without_crashing(tmp_path):
                 assert sc.total_tris() >= 0
             except (ValueError, IndexError, UnicodeDecodeError, OverflowError):
                 pass
+
+
+@pytest.mark.parametrize("face, ok", [
+    ("f 1/1/1 2/2/1 3/3/1", True), ("f -3/-3/-1 -2/-2/-1 -1/-1/-1", True),
+    ("f 0 1 2", False),                     # 0 is not an index
+    ("f 1 2 4", False), ("f 1 2 -4", False),  # position beyond what has been read, either way
+    ("f 1/4 2/1 3/2", False), ("f 1/-5 2/1 3/2", False),  # texcoord: a negative index below the first one is an error, not "no vt"
+    ("f 1//2 2//1 3//1", True), ("f 1//-2 2//1 3//1", True),  # a normal index is only a re-indexing key (tinyobj checks it for 0 only)
+    ("f 1//0 2//1 3//1", False),
+    ("f 4294967297 2 3", False),            # must not wrap to index 0 through a 32-bit narrowing
+])
+def test_native_reader_checks_every_face_index_before_narrowing(tmp_path, face, ok):
+    """0 anywhere, a v / vt index beyond the arrays read so far (positive or negative), or one too large for 32 bits ->
+    'face index out of range', from the native reader and from its Python twin alike (round-3 advisor finding). Three
+    positions, three texcoords, one normal are defined."""
+    path = tmp_path / "idx.obj"
+    path.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\n" + face + "\n")
+    if ok:
+        sc = load_obj(str(path))
+        assert sum(len(g.indices) for g in sc.meshes[0].geometries) == 1
+        assert sum(len(g.indices) for g in load_obj(str(path), reader="python").meshes[0].geometries) == 1
+    else:
+        for reader in ("native", "python"):
+            with pytest.raises(ValueError, match="face index out of range"):
+                load_obj(str(path), reader=reader)

@@ -448,6 +448,22 @@ def test_meshes_and_scenes_without_triangles(levels, oracle, monkeypatch):
     assert (w["t"] == 1.0).all()
 
 
+def test_empty_scene_survives_save_and_load(tmp_path):
+    """The scene without a triangle (a one-node tree, no leaf slots) goes through crt_hip_save / load_prepared_scene like any
+    other: a multi-GPU job's rank 0 saves what the other ranks load, and bench.py caches it (round-3 advisor finding: the
+    loader's field check refused n_tris == 0)."""
+    ps = PreparedScene(_scene_with_empty_meshes(all_empty=True))
+    path = str(tmp_path / "empty.bin")
+    ps.save(path)
+    a = ps.bvh()
+    ps.close()
+    back = PreparedScene(path=path)
+    b = back.bvh()
+    back.close()
+    assert b["nodes"].shape[0] == 1 and b["tris"].shape[0] == 0 and b["levels"] == a["levels"]
+    assert np.array_equal(a["nodes"], b["nodes"])
+
+
 def test_leaf_slots_hold_every_triangle_once_in_its_own_vertex_order():
     """The 64-byte leaf slots (crt_types.h LeafSlot, leaf_slots.h): triangle A is (v0, v1, v2), triangle B is picked from the
     four vertices by the 2-bit selectors next to the geomID. Every triangle of a single-instance scene must sit in exactly
