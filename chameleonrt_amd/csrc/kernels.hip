@@ -515,7 +515,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
                 normal = v3(h1.x, h1.y, h1.z);
                 V2 uv = v2(0.f, 0.f);
+#ifdef CRT_EXP_SHADE_NO_UV // TIMING EXPERIMENT ONLY (wrong image): what the tri_uvs gather costs
+                if (false) {
+#else
                 if (mat_word & MATERIAL_TEXTURED) { // (a material without textures never looks at uv: no record fetched)
+#endif
                     // ispc:277-285. tri_uvs holds the hit triangle's three vertex UVs, gathered per BVH
                     // triangle at set_scene; all zeros for a geometry without UVs, which interpolates
                     // to the reference's uv = (0, 0)

@@ -258,6 +258,11 @@ struct Surface { // DisneyMaterial after unpack_material
 CRT_DEV float scalar_param(const SceneView &sc, float x, V2 uv, TexTaps &taps)
 {
     const uint32_t mask = __float_as_uint(x);
+#ifdef CRT_EXP_SHADE_NO_TEX // TIMING EXPERIMENT ONLY (wrong image): what the descriptor -> texel gathers cost
+    if (mask & 0x80000000u) {
+        return 0.5f;
+    }
+#endif
     if (mask & 0x80000000u) {
         const uint32_t id = mask & 0x1fffffffu;
         const int channel = (int)((mask >> 29) & 0x3u);
@@ -280,6 +285,11 @@ CRT_DEV void unpack_material(const SceneView &sc, Surface &m, const float *p, V2
     taps.t00 = taps.t10 = taps.t01 = taps.t11 = 0u;
     taps.tx = taps.ty = 0.f;
     const uint32_t mask = __float_as_uint(p[0]);
+#ifdef CRT_EXP_SHADE_NO_TEX
+    if (mask & 0x80000000u) {
+        m.base_color = v3(0.5f, 0.5f, 0.5f);
+    } else
+#endif
     if (mask & 0x80000000u) {
         const uint32_t id = mask & 0x1fffffffu;
         const TexRec &t = sc.textures[id];

@@ -201,6 +201,12 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_POOL_CHUNK
 #define CRT_POOL_CHUNK 128
 #endif
+#ifndef CRT_POOL_GUIDED
+#define CRT_POOL_GUIDED 0
+#endif
+#ifndef CRT_POOL_CHUNK_MIN
+#define CRT_POOL_CHUNK_MIN 16
+#endif
 // two-level scenes: 0 = instances are entered in the leaf phase; 1 = in the inner-node phase (see there) -- measured
 // 16 % SLOWER on the instanced C4 (123.2 vs 105.9 ms): the entry's transform and frame change then sit in the hot
 // loop that most iterations run, for the few lanes that need them
@@ -398,11 +404,22 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
 
     // up to `want` ray indices [pool_next, pool_next + take) of the wave's pool, which is topped up from the queue cursor
     // (one atomic per CRT_POOL_CHUNK rays) when it is empty; the caller advances pool_next by what it uses
+    // GUIDED chunks (CRT_POOL_GUIDED): a wave asks for less as the queue runs out -- (what was left when it last asked) /
+    // (the next power of two above 2 x waves of the grid), between CRT_POOL_CHUNK_MIN and CRT_POOL_CHUNK -- so that the last
+    // rays of a launch are spread over all waves instead of sitting two deep in the pools of a few, and a queue smaller
+    // than the grid's appetite (bounce 4: 0.3 M rays for 6 144 waves) is dealt out one ray per lane. The estimate is
+    // one fetch old (n - the end of the wave's previous chunk) and costs no register: the shift is recomputed from the
+    // grid size at each fetch (scalar, once per chunk). Any chunk size gives the same image.
     auto pool_take = [&](uint32_t want) -> uint32_t {
         if (pool_next == pool_end && !exhausted) {
             uint32_t base = 0;
+            uint32_t chunk = (uint32_t)CRT_POOL_CHUNK;
+            if (CRT_POOL_GUIDED) {
+                const uint32_t shift = 32u - (uint32_t)__builtin_clz(2u * gridDim.x * (blockDim.x >> 6) - 1u);
+                chunk = min((uint32_t)CRT_POOL_CHUNK, max((uint32_t)CRT_POOL_CHUNK_MIN, (((n - pool_end) >> shift) + 15u) & ~15u));
+            }
             if (tv_lane_id() == 0) {
-                base = atomicAdd(cursor, (uint32_t)CRT_POOL_CHUNK);
+                base = atomicAdd(cursor, chunk);
             }
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n) {
@@ -413,7 +430,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 pool_next = pool_end = 0;
             } else {
                 pool_next = base;
-                pool_end = min(base + (uint32_t)CRT_POOL_CHUNK, n);
+                pool_end = min(base + chunk, n);
             }
         }
         return min(want, pool_end - pool_next);
