@@ -82,10 +82,50 @@ def write_files():
     return out
 
 
+DECODER_IMAGES = ["a420.jpg", "b444.jpg", "cgray.jpg", "dprog.jpg", "e32rle.tga", "f24.tga", "g24top.tga", "hgray.tga"]
+
+
+def write_decoder_files():
+    """tests/golden/scenes/decoders/: an OBJ whose eight materials name JPEG (4:2:0, 4:4:4, greyscale, progressive) and TGA
+    (32-bit RLE, 24-bit bottom-up and top-down, 8-bit grey) textures -- what real Sponza / San Miguel assets ship. The reference
+    decodes them with its vendored stb_image (util/material.cpp:5-17); tests/test_texture_decoders.py holds our loader to it."""
+    from PIL import Image
+    d = os.path.join(SCENES, "decoders")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(3)
+
+    def pic(w, h, ch):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([(np.sin(x / 7.0 + k) + np.cos(y / 5.0 * (k + 1))) * 60 + 128 + rng.normal(0, 12, (h, w)) for k in range(ch)], -1)
+        return np.clip(a, 0, 255).astype(np.uint8)
+
+    Image.fromarray(pic(67, 45, 3)).save(os.path.join(d, "a420.jpg"), quality=85, subsampling=2)
+    Image.fromarray(pic(64, 64, 3)).save(os.path.join(d, "b444.jpg"), quality=92, subsampling=0)
+    Image.fromarray(pic(50, 33, 1)[..., 0]).save(os.path.join(d, "cgray.jpg"), quality=80)
+    Image.fromarray(pic(40, 24, 3)).save(os.path.join(d, "dprog.jpg"), quality=85, progressive=True)
+    Image.fromarray(pic(37, 29, 4)).save(os.path.join(d, "e32rle.tga"), compression="tga_rle")
+    Image.fromarray(pic(31, 18, 3)).save(os.path.join(d, "f24.tga"))
+    Image.fromarray(pic(31, 18, 3)).save(os.path.join(d, "g24top.tga"), orientation=1)
+    Image.fromarray(pic(21, 11, 1)[..., 0]).save(os.path.join(d, "hgray.tga"))
+    with open(os.path.join(d, "t.mtl"), "w") as f:
+        for i, n in enumerate(DECODER_IMAGES):
+            f.write(f"newmtl m{i}\nKd 1 1 1\nmap_Kd {n}\n")
+    with open(os.path.join(d, "t.obj"), "w") as f:
+        f.write("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n")
+        for i in range(len(DECODER_IMAGES)):
+            f.write(f"o s{i}\nusemtl m{i}\nf 1/1 2/2 3/3\n")
+    return os.path.join(d, "t.obj")
+
+
 def main():
     from tests import ref_scene_lib as R
     if not R.available():
         raise SystemExit("oracle/_ref/libref_scene.so is missing: `make -C oracle ref` (needs /root/reference)")
+    if "--decoders" in sys.argv:  # (the image files are committed: regenerating them needs the same Pillow / libjpeg build)
+        d = R.load(write_decoder_files())
+        np.savez_compressed(os.path.join(HERE, "refdecoders_obj.npz"), **{k: v for k, v in d.items() if k.startswith("tex") or k == "counts"})
+        print("decoders", dict(zip("mesh pmesh inst mat tex light cam".split(), d["counts"])))
+        return
     for name, path in write_files().items():
         for wd in (False, True):
             d = R.load(path, white_diffuse=wd)
