@@ -124,6 +124,7 @@ class FrameLoop:
         self.multi_gpu = multi_gpu
         self.views = {}
         self.pending = None  # (work handle, gathered tensor) of the previous frame
+        self.in_flight = False  # N > 1: a frame has been enqueued and not collected yet
 
     @property
     def lanes_tunable(self):
@@ -143,20 +144,33 @@ class FrameLoop:
             self.pending = None
 
     def step(self, frame):
+        """One step. N = 1: render and return the frame's statistics. N > 1: PIPELINED -- frame f is enqueued before frame
+        f-1 is collected (crt_hip_render_begin / _end), so the GPU goes from one frame into the next without waiting for
+        the host, and the gather + K8 assemble of frame f-1 run next to frame f; returns the statistics of the frame that
+        completed in this step (frame f-1; None in the first step after a drain) -- drain() returns the last frame's."""
         eye, cdir, up, fovy = self.cam
-        st = self.r.render(eye, cdir, up, fovy, frame == 0, False)
-        if self.dist:
-            self._finish_pending()  # frame f-1's image is assembled while nothing else needs the stream
-            ptr, nbytes = self.r.tile_buffer()  # alternates between two buffers by frame parity
-            view = self.views.get(ptr)
-            if view is None:
-                view = self.views[ptr] = wrap_device_buffer(ptr, nbytes)
-            gathered, work = self.multi_gpu.gather_tile_buffers(view.cpu() if self.host_staged else view, async_op=True)
-            self.pending = (work, gathered)
-        return st
+        if not self.dist:
+            return self.r.render(eye, cdir, up, fovy, frame == 0, False)
+        self.r.render_begin(eye, cdir, up, fovy, frame == 0, False)
+        ptr, nbytes = self.r.tile_buffer()  # frame f's compact tile buffer (alternates between two buffers per frame)
+        view = self.views.get(ptr)
+        if view is None:
+            view = self.views[ptr] = wrap_device_buffer(ptr, nbytes)
+        done = self.r.render_end() if self.in_flight else None  # frame f-1: the host waits for it with frame f queued behind it
+        self._finish_pending()  # gather(f-1) is waited for ON THE STREAM, its K8 assemble is enqueued behind frame f
+        gathered, work = self.multi_gpu.gather_tile_buffers(view.cpu() if self.host_staged else view, async_op=True)
+        self.pending = (work, gathered)
+        self.in_flight = True
+        return done
 
     def drain(self):
+        """Collect what is in flight: the last frame's statistics (or None), its gather and assemble."""
+        done = None
+        if self.in_flight:
+            done = self.r.render_end()
+            self.in_flight = False
         self._finish_pending()
+        return done
 
 
 def timed_frames(loop, args, dist, first_frame):
@@ -165,6 +179,23 @@ def timed_frames(loop, args, dist, first_frame):
     acc = dict(rays=0, closest_rays=0, shadow_rays=0, closest_ms=0.0, shadow_ms=0.0, shade_ms=0.0, raygen_ms=0.0, accumulate_ms=0.0)
     for k in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
         acc[k] = [0.0] * MAX_PATH_DEPTH
+    def account(st):
+        if st is None:
+            return
+        acc["rays"] += st.rays
+        acc["closest_rays"] += st.closest_rays
+        acc["shadow_rays"] += st.shadow_rays
+        acc["closest_ms"] += st.closest_ms
+        acc["shadow_ms"] += st.shadow_ms
+        acc["shade_ms"] += st.shade_ms
+        acc["raygen_ms"] += st.raygen_ms
+        acc["accumulate_ms"] += st.accumulate_ms
+        for name in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
+            arr = getattr(st, name)
+            for b in range(MAX_PATH_DEPTH):
+                acc[name][b] += arr[b]
+        acc["pass_lanes"], acc["passes"] = int(st.pass_lanes), int(st.passes)
+
     if os.environ.get("CRT_HIP_OVERLAP") != "0":
         # set-up, not warm-up: with the overlapped schedule the library tries frames of up to 8 Mi paths with one pass lane
         # and with two (six frames after a configuration) and keeps the faster; let it decide
@@ -181,21 +212,8 @@ def timed_frames(loop, args, dist, first_frame):
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for k in range(args.steps):
-        st = loop.step(first_frame + args.warmup + k)
-        acc["rays"] += st.rays
-        acc["closest_rays"] += st.closest_rays
-        acc["shadow_rays"] += st.shadow_rays
-        acc["closest_ms"] += st.closest_ms
-        acc["shadow_ms"] += st.shadow_ms
-        acc["shade_ms"] += st.shade_ms
-        acc["raygen_ms"] += st.raygen_ms
-        acc["accumulate_ms"] += st.accumulate_ms
-        for name in ("closest_rays_bounce", "shadow_rays_bounce", "closest_ms_bounce", "shadow_ms_bounce", "shade_ms_bounce"):
-            arr = getattr(st, name)
-            for b in range(MAX_PATH_DEPTH):
-                acc[name][b] += arr[b]
-        acc["pass_lanes"], acc["passes"] = int(st.pass_lanes), int(st.passes)
-    loop.drain()  # the last frame's gather + assemble belong to the timed region
+        account(loop.step(first_frame + args.warmup + k))  # (N > 1: the statistics of the frame before, see FrameLoop.step)
+    account(loop.drain())  # the last frame's completion, gather + assemble belong to the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

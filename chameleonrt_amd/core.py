@@ -34,6 +34,7 @@ EXPORTS = [
     "crt_hip_prepare_scene_on", "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
     "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp", "crt_hip_debug_copy_queue",
+    "crt_hip_render_begin", "crt_hip_render_end",
 ]
 
 
@@ -93,6 +94,10 @@ def load():
     L.crt_hip_initialize.argtypes = [vp, C.c_int, C.c_int]
     L.crt_hip_set_scene.argtypes = [vp, C.POINTER(SceneDesc)]
     L.crt_hip_render.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.POINTER(RenderStats)]
+    L.crt_hip_render_begin.argtypes = [vp, fp, fp, fp, C.c_float, C.c_int, C.c_int]
+    L.crt_hip_render_begin.restype = C.c_int
+    L.crt_hip_render_end.argtypes = [vp, C.POINTER(RenderStats)]
+    L.crt_hip_render_end.restype = C.c_int
     L.crt_hip_framebuffer.restype = u32p
     L.crt_hip_framebuffer.argtypes = [vp]
     L.crt_hip_device_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

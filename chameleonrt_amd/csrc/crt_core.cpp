@@ -179,17 +179,46 @@ struct crt_hip_ctx {
 
     // wavefront state
     uint64_t capacity = 0; // paths per pass (every lane's queues hold that many)
-    PassCounters *h_pc = nullptr; // pinned, one per pass
-    uint32_t h_pc_slots = 0;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events; // timing events of the diagnostic entry points
+    // A frame is ENQUEUED (crt_hip_render_begin: every launch of it, no host wait) and later COLLECTED (crt_hip_render_end:
+    // wait for its last event, read its counters and timings); crt_hip_render does both. Two slots, so that a caller may
+    // enqueue frame f+1 before it collects frame f and the GPU never waits for the host between frames.
+    struct Span {
+        size_t a, b;
+        int kind;   // 0 closest-hit traversal, 1 any-hit traversal, 2 raygen / shade / accumulate
+        int bounce; // path-loop iteration of the launch; -1 raygen, -2 accumulate
+    };
+    struct FrameSlot {
+        bool pending = false;
+        std::vector<Span> spans;
+        uint32_t passes = 0, used_lanes = 1, frame_id = 0;
+        uint64_t total_paths = 0;
+        std::chrono::high_resolution_clock::time_point t0;
+        hipEvent_t begin = nullptr, done = nullptr;
+        PassCounters *h_pc = nullptr; // pinned host copy of every pass's counters; grown by the frame that needs more
+        uint32_t h_pc_cap = 0;
+        std::vector<hipEvent_t> events; // event pairs around the frame's launches (CRT_HIP_FLAG_TIMING)
+    };
+    FrameSlot slots[2];
+    int next_slot = 0;    // where the next frame is enqueued
+    int oldest_slot = 0;  // the pending frame that is collected next
 
     ~crt_hip_ctx()
     {
         for (hipEvent_t e : events) {
             (void)hipEventDestroy(e);
         }
-        if (h_pc) {
-            (void)hipHostFree(h_pc);
+        for (FrameSlot &f : slots) {
+            if (f.begin) {
+                (void)hipEventDestroy(f.begin);
+                (void)hipEventDestroy(f.done);
+            }
+            for (hipEvent_t e : f.events) {
+                (void)hipEventDestroy(e);
+            }
+            if (f.h_pc) {
+                (void)hipHostFree(f.h_pc);
+            }
         }
         for (PassLane &l : lanes) {
             if (l.aux) {
@@ -355,23 +384,20 @@ void setup_queues(crt_hip_ctx *c)
             c->lanes[i].pc.release();
         }
     }
-    if (c->h_pc) {
-        (void)hipHostFree(c->h_pc);
-        c->h_pc = nullptr;
-    }
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pc), sizeof(PassCounters) * n_pass));
-    c->h_pc_slots = n_pass;
+    (void)n_pass;
 }
 
-hipEvent_t get_event(crt_hip_ctx *c, size_t i)
+hipEvent_t get_event(std::vector<hipEvent_t> &pool, size_t i)
 {
-    while (c->events.size() <= i) {
+    while (pool.size() <= i) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreate(&e));
-        c->events.push_back(e);
+        pool.push_back(e);
     }
-    return c->events[i];
+    return pool[i];
 }
+hipEvent_t get_event(crt_hip_ctx *c, size_t i) { return get_event(c->events, i); }
+bool frames_in_flight(const crt_hip_ctx *c) { return c->slots[0].pending || c->slots[1].pending; }
 
 
 } // namespace
@@ -464,6 +490,9 @@ uint32_t crt_hip_frame_id(const crt_hip_ctx *ctx) { return ctx ? ctx->frame_id :
 int crt_hip_set_stream(crt_hip_ctx *ctx, void *hip_stream)
 {
     return guarded(ctx, [&]() -> int {
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
+        }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
         return CRT_HIP_OK;
@@ -473,6 +502,9 @@ int crt_hip_set_stream(crt_hip_ctx *ctx, void *hip_stream)
 int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world)
 {
     return guarded(ctx, [&]() -> int {
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
+        }
         if (world < 1 || rank < 0 || rank >= world) {
             return fail(ctx, CRT_HIP_EINVAL, "bad rank/world");
         }
@@ -489,6 +521,9 @@ int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world)
 int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height)
 {
     return guarded(ctx, [&]() -> int {
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
+        }
         if (fb_width <= 0 || fb_height <= 0) {
             return fail(ctx, CRT_HIP_EINVAL, "bad framebuffer size");
         }
@@ -730,6 +765,9 @@ extern "C" {
 int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *ps)
 {
     return guarded(ctx, [&]() -> int {
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
+        }
         if (!ps) {
             return fail(ctx, CRT_HIP_EINVAL, "prepared scene is null");
         }
@@ -742,6 +780,9 @@ int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *p
 int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
 {
     return guarded(ctx, [&]() -> int {
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
+        }
         crt_hip_prepared_scene ps;
         const char *where = std::getenv("CRT_HIP_BUILD"); // "device": BLAS of large meshes built on this context's GPU
         prepare_scene(s, &ps, host_threads(), where && std::strcmp(where, "device") == 0 ? ctx->device : -1);
@@ -759,16 +800,26 @@ int32_t crt_hip_world_instance(crt_hip_ctx *ctx) { return ctx && ctx->has_scene 
 int crt_hip_child_order(void) { return traversal_child_order(); }
 uint32_t crt_hip_lds_stack_entries(int two_level) { return traversal_lds_stack((uint32_t)two_level); }
 
-// RenderEmbree::render (render_embree.cpp:135-216)
-int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], const float up_[3], float fovy,
-                   int camera_changed, int readback, crt_render_stats *stats)
+// RenderEmbree::render (render_embree.cpp:135-216), first half: every launch of the frame goes to the stream(s); nothing waits
+int crt_hip_render_begin(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], const float up_[3], float fovy,
+                         int camera_changed, int readback)
 {
     return guarded(ctx, [&]() -> int {
         if (!ctx->has_scene || ctx->width == 0) {
             return fail(ctx, CRT_HIP_ESTATE, "render before initialize + set_scene");
         }
+        crt_hip_ctx::FrameSlot &fs = ctx->slots[ctx->next_slot];
+        if (fs.pending) {
+            return fail(ctx, CRT_HIP_ESTATE, "render_begin: two frames are in flight already; collect one with crt_hip_render_end");
+        }
         if (ctx->capacity == 0) {
+            // the queues are (re)carved: nothing of an earlier frame may still be using them
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
             setup_queues(ctx);
+        }
+        if (!fs.begin) {
+            HIP_CHECK(hipEventCreate(&fs.begin));
+            HIP_CHECK(hipEventCreate(&fs.done));
         }
         if (camera_changed) {
             ctx->frame_id = 0;
@@ -806,18 +857,16 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         const uint64_t total_slots = (uint64_t)ctx->n_local_tiles * TILE_PIXELS;
         const uint64_t slots_per_pass = ctx->capacity / ctx->spp;
         size_t ev = 0;
-        struct Span {
-            size_t a, b;
-            int kind;   // 0 closest-hit traversal, 1 any-hit traversal, 2 raygen / shade / accumulate
-            int bounce; // path-loop iteration of the launch; -1 raygen, -2 accumulate
-        };
-        std::vector<Span> spans;
+        using Span = crt_hip_ctx::Span;
+        std::vector<Span> &spans = fs.spans;
+        spans.clear();
+        PassCounters *h_pc = nullptr; // set below, once the number of passes is known
         // event pairs around each launch, recorded on the stream the launch goes to: with the overlapped
         // schedule the occlusion launches' spans live on the auxiliary stream and run concurrently with the
         // closest-hit spans of the next bounce (so the per-kind sums may add up to more than the frame time)
         auto mark = [&](int kind, hipStream_t on, int bounce) {
             if (timing) {
-                hipEvent_t e0 = get_event(ctx, ev), e1 = get_event(ctx, ev + 1);
+                hipEvent_t e0 = get_event(fs.events, ev), e1 = get_event(fs.events, ev + 1);
                 (void)e1;
                 HIP_CHECK(hipEventRecord(e0, on));
                 spans.push_back(Span{ev, ev + 1, kind, bounce});
@@ -826,7 +875,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         };
         auto mark_end = [&](hipStream_t on) {
             if (timing) {
-                HIP_CHECK(hipEventRecord(get_event(ctx, spans.back().b), on));
+                HIP_CHECK(hipEventRecord(get_event(fs.events, spans.back().b), on));
             }
         };
 
@@ -834,9 +883,19 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         // The compact tile buffer alternates with every RENDERED frame, whatever frame_id does (a moving camera resets
         // frame_id to 0 every frame): the asynchronous gather of the previous frame may still be reading the other one.
         const int tile_buf = ctx->tile_fb_last ^ 1;
-        const auto t0 = std::chrono::high_resolution_clock::now();
+        fs.t0 = std::chrono::high_resolution_clock::now();
+        HIP_CHECK(hipEventRecord(fs.begin, ctx->stream));
         const uint32_t n_pass_frame = (uint32_t)((total_slots + slots_per_pass - 1) / slots_per_pass);
         const int used_lanes = (int)std::min<uint32_t>((uint32_t)ctx->lanes_in_use, std::max<uint32_t>(1u, n_pass_frame));
+        if (fs.h_pc_cap < n_pass_frame) {
+            if (fs.h_pc) {
+                HIP_CHECK(hipHostFree(fs.h_pc));
+                fs.h_pc = nullptr;
+            }
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&fs.h_pc), sizeof(PassCounters) * n_pass_frame));
+            fs.h_pc_cap = n_pass_frame;
+        }
+        h_pc = fs.h_pc;
         ctx->lanes[0].main = ctx->stream;
         if (used_lanes > 1 && !ctx->lane_aux) {
             overlap = false;
@@ -902,7 +961,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                               ctx->d_tile_fb[tile_buf].as<uint32_t>(), ctx->world == 1 ? ctx->d_img.as<uint32_t>() : nullptr,
                               ctx->d_ray_counts.as<uint32_t>());
             mark_end(ln.main);
-            HIP_CHECK(hipMemcpyAsync(&ctx->h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost, ln.main));
+            HIP_CHECK(hipMemcpyAsync(&h_pc[pass], d_pc, sizeof(PassCounters), hipMemcpyDeviceToHost, ln.main));
         }
         for (int i = 1; i < used_lanes; ++i) { // the caller's stream continues when every lane is done
             HIP_CHECK(hipEventRecord(ctx->lanes[i].ev_done, ctx->lanes[i].main));
@@ -913,13 +972,48 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             HIP_CHECK(hipMemcpyAsync(ctx->img.data(), ctx->d_img.ptr, ctx->img.size() * sizeof(uint32_t),
                                      hipMemcpyDeviceToHost, ctx->stream));
         }
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const auto t1 = std::chrono::high_resolution_clock::now();
+        HIP_CHECK(hipEventRecord(fs.done, ctx->stream));
+        fs.pending = true;
+        fs.passes = pass;
+        fs.used_lanes = (uint32_t)used_lanes;
+        fs.frame_id = ctx->frame_id;
+        fs.total_paths = total_slots * ctx->spp;
+        ctx->tile_fb_last = tile_buf;
+        ++ctx->frame_id;
+        ctx->next_slot ^= 1;
+        // while the library is still trying this frame size with one pass lane and with two, the queues may be carved
+        // again after the frame: it is completed here (collected by crt_hip_render_end as usual)
+        if (ctx->lane_tune < crt_hip_ctx::LANE_TUNE_FRAMES && lanes_tunable(ctx, fs.total_paths)) {
+            HIP_CHECK(hipEventSynchronize(fs.done));
+        }
+        return CRT_HIP_OK;
+    });
+}
 
+// ... second half: wait for the OLDEST frame in flight, read its counters and timings. back_to_back: called by crt_hip_render
+// right after render_begin -- the frame time is then the host's wall clock around both, as the reference times its
+// render() (render_embree.cpp:177-211); otherwise the GPU's time between the frame's first and last event.
+static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_back)
+{
+    return guarded(ctx, [&]() -> int {
+        crt_hip_ctx::FrameSlot &fs = ctx->slots[ctx->oldest_slot];
+        if (!fs.pending) {
+            return fail(ctx, CRT_HIP_ESTATE, "render_end without a frame in flight");
+        }
+        using Span = crt_hip_ctx::Span;
+        const std::vector<Span> &spans = fs.spans;
+        const PassCounters *h_pc = fs.h_pc;
+        const uint32_t pass = fs.passes;
+        const bool timing = (ctx->flags & CRT_HIP_FLAG_TIMING) != 0;
+        HIP_CHECK(hipEventSynchronize(fs.done));
+        const auto t1 = std::chrono::high_resolution_clock::now();
+        fs.pending = false;
+        ctx->oldest_slot ^= 1;
+        const uint32_t frame_id = fs.frame_id;
         crt_render_stats st;
         std::memset(&st, 0, sizeof(st));
         for (uint32_t p = 0; p < pass; ++p) {
-            const PassCounters &pc = ctx->h_pc[p];
+            const PassCounters &pc = h_pc[p];
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 st.closest_rays += pc.n_queue[b];
                 st.shadow_rays += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
@@ -935,13 +1029,13 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
         }
         st.rays = st.closest_rays + st.shadow_rays;
         if (std::getenv("CRT_HIP_DEBUG")) { // per-bounce queue sizes of the first pass
-            const PassCounters &pc = ctx->h_pc[0];
+            const PassCounters &pc = h_pc[0];
             std::fprintf(stderr, "[crt_hip] frame %u worst closest ray: %u nodes, o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) t %.9g\n",
-                         ctx->frame_id, pc.max_ray_nodes, pc.worst_ray[0], pc.worst_ray[1], pc.worst_ray[2], pc.worst_ray[3],
+                         frame_id, pc.max_ray_nodes, pc.worst_ray[0], pc.worst_ray[1], pc.worst_ray[2], pc.worst_ray[3],
                          pc.worst_ray[4], pc.worst_ray[5], pc.worst_ray[6]);
             for (int b = 0; b < MAX_PATH_DEPTH && (ctx->flags & CRT_HIP_FLAG_COUNTERS); ++b) {
                 std::fprintf(stderr, "[crt_hip] frame %u closest launch %d: %.1f us total, queue drained after %.1f us (tail %.0f%%)\n",
-                             ctx->frame_id, b, (pc.t_end[b] - pc.t_start[b]) / 100.0, (pc.t_drained[b] - pc.t_start[b]) / 100.0,
+                             frame_id, b, (pc.t_end[b] - pc.t_start[b]) / 100.0, (pc.t_drained[b] - pc.t_start[b]) / 100.0,
                              100.0 * (double)(pc.t_end[b] - pc.t_drained[b]) / (double)(pc.t_end[b] - pc.t_start[b]));
             }
             for (int k = 0; k < 2 && (ctx->flags & CRT_HIP_FLAG_COUNTERS); ++k) {
@@ -953,21 +1047,25 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                 for (int ph = 0; ph < 4; ++ph) {
                     const double it = (double)std::max<unsigned long long>(1ull, pc.prof_iters[k][ph]);
                     std::fprintf(stderr, "[crt_hip] frame %u %s waves, %-6s: %5.1f%% of wave cycles, %.0f cycles/iteration, %.1f lanes/iteration\n",
-                                 ctx->frame_id, k == 0 ? "closest" : "shadow ", names[ph],
+                                 frame_id, k == 0 ? "closest" : "shadow ", names[ph],
                                  100.0 * (double)pc.prof_cycles[k][ph] / std::max(1.0, total),
                                  (double)pc.prof_cycles[k][ph] / it, (double)pc.prof_lanes[k][ph] / it);
                 }
             }
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
-                std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", ctx->frame_id,
+                std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", frame_id,
                              b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);
             }
         }
-        st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (back_to_back) {
+            st.render_time_ms = (float)std::chrono::duration<double, std::milli>(t1 - fs.t0).count();
+        } else {
+            HIP_CHECK(hipEventElapsedTime(&st.render_time_ms, fs.begin, fs.done));
+        }
         // one lane or two for frames of this size? (crt_hip_ctx::PassLane)
         st.passes = pass;
-        st.pass_lanes = (uint32_t)used_lanes;
-        if (ctx->lane_tune < crt_hip_ctx::LANE_TUNE_FRAMES && lanes_tunable(ctx, total_slots * ctx->spp)) {
+        st.pass_lanes = fs.used_lanes;
+        if (ctx->lane_tune < crt_hip_ctx::LANE_TUNE_FRAMES && lanes_tunable(ctx, fs.total_paths)) {
             const int f = ctx->lane_tune;
             const float t = st.render_time_ms;
             if (f == 1 || f == 2) {
@@ -995,7 +1093,7 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
             const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
             for (const Span &sp : spans) {
                 float ms = 0.f;
-                HIP_CHECK(hipEventElapsedTime(&ms, ctx->events[sp.a], ctx->events[sp.b]));
+                HIP_CHECK(hipEventElapsedTime(&ms, fs.events[sp.a], fs.events[sp.b]));
                 (sp.kind == 0 ? st.closest_ms : (sp.kind == 1 ? st.shadow_ms : st.shade_ms)) += ms;
                 if (sp.bounce >= 0) {
                     (sp.kind == 0 ? st.closest_ms_bounce : (sp.kind == 1 ? st.shadow_ms_bounce : st.shade_ms_bounce))[sp.bounce] += ms;
@@ -1003,17 +1101,28 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir_[3], co
                     (sp.bounce == -1 ? st.raygen_ms : st.accumulate_ms) += ms;
                 }
                 if (dbg) {
-                    std::fprintf(stderr, "[crt_hip] frame %u span kind %d: %.3f ms\n", ctx->frame_id, sp.kind, ms);
+                    std::fprintf(stderr, "[crt_hip] frame %u span kind %d: %.3f ms\n", frame_id, sp.kind, ms);
                 }
             }
         }
         if (stats) {
             *stats = st;
         }
-        ctx->tile_fb_last = tile_buf;
-        ++ctx->frame_id;
         return CRT_HIP_OK;
     });
+}
+
+int crt_hip_render_end(crt_hip_ctx *ctx, crt_render_stats *stats) { return render_end(ctx, stats, false); }
+
+// RenderEmbree::render (render_embree.cpp:135-216): enqueue, wait, collect
+int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir[3], const float up[3], float fovy, int camera_changed,
+                   int readback, crt_render_stats *stats)
+{
+    if (ctx && (ctx->slots[0].pending || ctx->slots[1].pending)) {
+        return fail(ctx, CRT_HIP_ESTATE, "render: a frame enqueued with crt_hip_render_begin has not been collected");
+    }
+    const int rc = crt_hip_render_begin(ctx, pos, dir, up, fovy, camera_changed, readback);
+    return rc != CRT_HIP_OK ? rc : render_end(ctx, stats, true);
 }
 
 const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx) { return ctx ? ctx->img.data() : nullptr; }
@@ -1124,8 +1233,11 @@ int crt_hip_assemble_tiles(crt_hip_ctx *ctx, const void *gathered, int world, in
         if (readback) {
             HIP_CHECK(hipMemcpyAsync(ctx->img.data(), ctx->d_img.ptr, ctx->img.size() * sizeof(uint32_t),
                                      hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the host image is the caller's as soon as this returns
         }
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // (without a read-back nothing waits: the assembled image stays in HBM -- crt_hip_device_framebuffer -- and the
+        // kernel is ordered on the context's stream like every later launch; a frame loop that enqueues the next frame
+        // before it collects this one keeps the GPU busy across the gather)
         return CRT_HIP_OK;
     });
 }
@@ -1139,6 +1251,9 @@ int crt_hip_trace_rays(crt_hip_ctx *ctx, uint64_t n, const float *org, const flo
     return guarded(ctx, [&]() -> int {
         if (!ctx->has_scene) {
             return fail(ctx, CRT_HIP_ESTATE, "trace_rays before set_scene");
+        }
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "trace_rays while a frame is in flight");
         }
         if (production) {
             return trace_rays_production(ctx, n, org, dir, tmin, tmax, closest != 0, out_t, out_u, out_v, out_inst, out_geom,

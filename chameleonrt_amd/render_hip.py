@@ -69,6 +69,18 @@ class RenderHIP:
                                                        int(bool(readback_framebuffer)), C.byref(st)), "render")
         return st
 
+    def render_begin(self, pos, dir, up, fovy, camera_changed, readback_framebuffer=False):
+        """Enqueue a frame without waiting for it (crt_hip_render_begin); at most two may be in flight."""
+        a = [np.ascontiguousarray(v, np.float32) for v in (pos, dir, up)]
+        core.check(self._ctx, self._lib.crt_hip_render_begin(self._ctx, core.fptr(a[0]), core.fptr(a[1]), core.fptr(a[2]), float(fovy),
+                                                             int(bool(camera_changed)), int(bool(readback_framebuffer))), "render_begin")
+
+    def render_end(self) -> core.RenderStats:
+        """Wait for the oldest frame in flight and return its statistics (crt_hip_render_end)."""
+        st = core.RenderStats()
+        core.check(self._ctx, self._lib.crt_hip_render_end(self._ctx, C.byref(st)), "render_end")
+        return st
+
     @property
     def img(self) -> np.ndarray:
         p = self._lib.crt_hip_framebuffer(self._ctx)

@@ -222,6 +222,19 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path);
 int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir[3], const float up[3],
                    float fovy_deg, int camera_changed, int readback, crt_render_stats *stats);
 
+/* The two halves of crt_hip_render for callers that must not stall the GPU between frames (the multi-GPU frame loop:
+ * gather + assemble of frame f run while frame f+1 is traced). crt_hip_render_begin enqueues every launch of the frame on
+ * the context's stream(s) and returns without waiting; crt_hip_render_end waits for the OLDEST frame in flight and fills
+ * its statistics (render_time_ms is then the GPU's time from the frame's first to its last event). At most two frames may
+ * be in flight; results are identical to crt_hip_render's (same launches, same order on the stream). While frames are in
+ * flight only render_begin / render_end / tile_buffer / assemble_tiles / device_framebuffer may be called. The tile
+ * buffer of a frame (crt_hip_tile_buffer right after its render_begin) is reused by the frame after the next one:
+ * its gather must have been ordered before that frame is enqueued. No reference counterpart (the reference's render()
+ * is synchronous, render_embree.cpp:135-216). */
+int crt_hip_render_begin(crt_hip_ctx *ctx, const float pos[3], const float dir[3], const float up[3], float fovy_deg,
+                         int camera_changed, int readback);
+int crt_hip_render_end(crt_hip_ctx *ctx, crt_render_stats *stats);
+
 /* W*H RGBA8 (8-bit sRGB, A=255), row 0 = top: RenderBackend::img. */
 const uint32_t *crt_hip_framebuffer(const crt_hip_ctx *ctx);
 

@@ -199,3 +199,45 @@ def test_meshes_without_triangles_render(all_empty, levels, oracle, hip_lib, mon
     if all_empty:
         assert int(st.rays) == w * h * sc.samples_per_pixel
     r.close()
+
+
+def test_pipelined_frames_equal_synchronous_frames(hip_lib):
+    """crt_hip_render_begin / _end (include/crt_hip.h): the frame loop of the multi-GPU bench enqueues frame f+1 before it
+    collects frame f so that the GPU never waits for the host between frames. Same launches in the same order on the same
+    stream: accumulated radiance, ray counts, RGBA8 and every frame's ray statistics are those of crt_hip_render, bit
+    for bit -- for a frame size the library cuts for pass lanes by trial (its trial frames complete inside render_begin)
+    and for one it never cuts. A third frame in flight, and re-configuring with frames in flight, are refused."""
+    from chameleonrt_amd import core
+    sc = scenes.instanced_grove(spp=4)
+    e, d, u, fovy = camera_of(sc)
+    for w, h in ((256, 192), (640, 400)):  # 0.2 M paths (never cut) / 1 M paths (tried with one lane and with two)
+        a = RenderHIP()
+        a.initialize(w, h)
+        a.set_scene(sc)
+        sync = [a.render(e, d, u, fovy, f == 0, False).rays for f in range(9)]
+        b = RenderHIP()
+        b.initialize(w, h)
+        b.set_scene(sc)
+        piped = []
+        b.render_begin(e, d, u, fovy, True, False)
+        for f in range(1, 9):
+            b.render_begin(e, d, u, fovy, False, False)  # frame f goes in while frame f-1 is still uncollected
+            if f == 3:
+                with pytest.raises(core.CoreError, match="two frames are in flight"):
+                    b.render_begin(e, d, u, fovy, False, False)
+                with pytest.raises(core.CoreError, match="in flight"):
+                    b.initialize(w, h)
+            piped.append(b.render_end().rays)
+        st = b.render_end()
+        piped.append(st.rays)
+        with pytest.raises(core.CoreError, match="without a frame in flight"):
+            b.render_end()
+        assert piped == sync
+        assert st.render_time_ms > 0 and st.passes >= 1
+        assert np.array_equal(a.accum().view(np.uint32), b.accum().view(np.uint32))
+        assert np.array_equal(a.ray_counts(), b.ray_counts())
+        # the synchronous entry point works again once nothing is in flight
+        assert b.render(e, d, u, fovy, False, True).rays == a.render(e, d, u, fovy, False, True).rays
+        assert np.array_equal(a.img, b.img)
+        a.close()
+        b.close()
