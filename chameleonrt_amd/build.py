@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrt_hip_core.so")
 SOURCES = ["kernels.hip", "crt_core.cpp", "scene_prepare.cpp", "bvh_builder.cpp", "bvh_device.hip"]
-HEADERS = ["crt_types.h", "pt_device.h", "traverse.h", "slab.h", "wavefront.h", "kernels.h", "scene_prepare.h", "host_parallel.h", "bvh_builder.h", "bvh_device.h", "lbvh.h", "leaf_slots.h",
+HEADERS = ["crt_types.h", "pt_device.h", "traverse.h", "slab.h", "wavefront.h", "kernels.h", "scene_prepare.h", "host_parallel.h", "bvh_builder.h", "bvh_device.h", "lbvh.h", "leaf_slots.h", "presplit.h",
            os.path.join("..", "..", "include", "crt_hip.h"), os.path.join("..", "..", "include", "crt_kat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function", "-x", "hip"]

@@ -31,6 +31,7 @@
 #include "kernels.h"
 #include "lbvh.h"
 #include "leaf_slots.h"
+#include "presplit.h"
 
 namespace crt {
 namespace {
@@ -440,6 +441,16 @@ struct ScenePreparer {
         }
     }
 
+    static void report_presplit(const PresplitStats &st)
+    {
+        if (std::getenv("CRT_HIP_DEBUG") || std::getenv("CRT_BVH_SPLITS_REPORT")) {
+            std::fprintf(stderr, "[crt_hip] presplit: %llu -> %llu leaf items (+%.1f %%), summed box area %.4g -> %.4g (%.1f %%)\n",
+                         (unsigned long long)st.items_in, (unsigned long long)st.items_out,
+                         100.0 * (double)(st.items_out - st.items_in) / (double)std::max<uint64_t>(1, st.items_in), st.area_in, st.area_out,
+                         100.0 * st.area_out / std::max(1e-30, st.area_in));
+        }
+    }
+
     // world-space (or, m == nullptr, object-space) box of a slot's triangles, pushed out by `pad`
     static Aabb slot_box(const crt_geometry_desc &gd, SlotTris st, const float *m, float pad)
     {
@@ -524,6 +535,10 @@ struct ScenePreparer {
                 blas_frame[m] = make_frame(Aabb{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
                 blas_bounds[m] = Aabb{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
                 continue;
+            }
+            if (presplit_fraction() > 0.0) { // opt-in (CRT_BVH_SPLITS): loosely boxed slots get several leaves (presplit.h)
+                report_presplit(presplit_items(recs, boxes, [](const LeafSlot &, const float *&mm, float &pad) { mm = nullptr; pad = 0.f; },
+                                               presplit_fraction()));
             }
             built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
@@ -786,6 +801,16 @@ struct ScenePreparer {
                         fill_instance(small[j], 1);
                     }
                 });
+            }
+            if (presplit_fraction() > 0.0) {
+                std::vector<float> pads(s->n_instances);
+                for (uint32_t i = 0; i < s->n_instances; ++i) {
+                    pads[i] = pad_of(i);
+                }
+                report_presplit(presplit_items(recs, boxes, [&](const LeafSlot &r, const float *&mm, float &pad) {
+                    mm = (r.tag & 1u) != 0u ? nullptr : s->instances[r.tag >> 1].transform;
+                    pad = pads[r.tag >> 1];
+                }, presplit_fraction()));
             }
             BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
                                       : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
