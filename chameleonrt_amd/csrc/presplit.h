@@ -110,6 +110,10 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
         st.area_in += half_area(b);
     }
     const uint64_t budget = (uint64_t)(fraction * (double)recs.size());
+    // an item is worth cutting while more than `min_waste` of its box area is empty, and a cut is kept if the two halves'
+    // boxes together are smaller than `max_kept` of the box they replace (tuning: CRT_BVH_SPLIT_WASTE / CRT_BVH_SPLIT_KEEP)
+    const float min_waste = std::getenv("CRT_BVH_SPLIT_WASTE") ? (float)std::atof(std::getenv("CRT_BVH_SPLIT_WASTE")) : 0.25f;
+    const float max_kept = std::getenv("CRT_BVH_SPLIT_KEEP") ? (float)std::atof(std::getenv("CRT_BVH_SPLIT_KEEP")) : 0.9f;
     // An item OWNS the part of its triangles inside its `cell` (all of space at first, halved by every cut: the halves are
     // closed and share the cut plane, so the parts cover the triangles exactly); its BOX is the box of that part pushed
     // out by the item's pad (a transformed instance's box has to cover where the rounded object-space test may put a
@@ -183,7 +187,7 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
         const float h = half_area(boxes[i]);
         if (std::isfinite(h) && h > 0.f && part_box(i, everywhere, boxes[i], tight, area)) {
             const float waste = h - area;
-            if (waste > 0.25f * h) { // a box that is mostly its geometry (an axis-aligned quad) gains nothing from a cut
+            if (waste > min_waste * h) { // a box that is mostly its geometry (an axis-aligned quad) gains nothing from a cut
                 heap.push(Entry{waste, i});
             }
         }
@@ -212,7 +216,7 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
             continue; // the geometry lies in one half only (the box was loose by its pad alone)
         }
         const float hl = half_area(bl), hr = half_area(br);
-        if (!(hl + hr < 0.9f * half_area(box))) {
+        if (!(hl + hr < max_kept * half_area(box))) {
             continue; // the cut does not pay for a second reference
         }
         boxes[e.item] = bl;
@@ -223,10 +227,10 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
         cells.push_back(cr);
         limits.push_back(limit);
         ++st.cuts;
-        if (hl - al > 0.25f * hl) {
+        if (hl - al > min_waste * hl) {
             heap.push(Entry{hl - al, e.item});
         }
-        if (hr - ar > 0.25f * hr) {
+        if (hr - ar > min_waste * hr) {
             heap.push(Entry{hr - ar, j});
         }
     }
