@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
     if (threadIdx.x == 0) {
         stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = 0;
     }
-    __syncthreads();
+    unorm8_init(); // (ends with the barrier that also publishes the counters)
     uint32_t parity = 0;
     const uint32_t n = pc->n_queue[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -777,6 +777,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
 // ---- KATs of the device shading functions (record layouts: include/crt_kat.h) ------------------
 __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_stride, float *out, int out_stride)
 {
+    unorm8_init();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;

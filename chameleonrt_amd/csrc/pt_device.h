@@ -155,23 +155,46 @@ CRT_DEV uint32_t rng_next(uint32_t &state)
 CRT_DEV float rng_nextf(uint32_t &state) { return (float)rng_next(state) * 2.3283064365386963e-10f; }
 
 // ---- textures: texture2d.ih:13-83, util/texture_channel_mask.h:16-23 ----------------------
+// An 8-bit texel as the reference reads it: byte / 255.f (texture2d.ih:26-35). An IEEE division is ~10 instructions and a
+// bilinear fetch of an RGB texture makes twelve of them, so the 256 possible quotients are computed ONCE per block --
+// by that very division -- into LDS (unorm8_init, then a barrier) and looked up: same bits, one ds_read per channel.
+// Every kernel that samples textures (k_shade, k_kat) calls unorm8_init() first.
+static __shared__ float crt_unorm8_lut[256];
+CRT_DEV void unorm8_init()
+{
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
+        crt_unorm8_lut[i] = (float)(int)i / 255.f;
+    }
+    __syncthreads();
+}
+#ifndef CRT_UNORM8_LUT
+#define CRT_UNORM8_LUT 1
+#endif
+CRT_DEV float unorm8(uint32_t byte)
+{
+#if CRT_UNORM8_LUT
+    return crt_unorm8_lut[byte & 0xffu];
+#else
+    return (float)(int)(byte & 0xffu) / 255.f;
+#endif
+}
 CRT_DEV float texel_channel(const SceneView &sc, const TexRec &t, int px, int py, int channel)
 {
-    return sc.texels[(size_t)t.offset16 * 16 + (size_t)tex_slot(t.width, px, py) * t.channels + channel] / 255.f;
+    return unorm8(sc.texels[(size_t)t.offset16 * 16 + (size_t)tex_slot(t.width, px, py) * t.channels + channel]);
 }
 CRT_DEV V4 texel_rgba(const SceneView &sc, const TexRec &t, int px, int py)
 {
     const uint8_t *p = sc.texels + (size_t)t.offset16 * 16 + (size_t)tex_slot(t.width, px, py) * t.channels;
     V4 c{0.f, 0.f, 0.f, 0.f};
-    c.x = p[0] / 255.f;
+    c.x = unorm8(p[0]);
     if (t.channels >= 2) {
-        c.y = p[1] / 255.f;
+        c.y = unorm8(p[1]);
     }
     if (t.channels >= 3) {
-        c.z = p[2] / 255.f;
+        c.z = unorm8(p[2]);
     }
     if (t.channels == 4) {
-        c.w = p[3] / 255.f;
+        c.w = unorm8(p[3]);
     }
     return c;
 }
@@ -242,8 +265,8 @@ CRT_DEV void fetch_taps4(const SceneView &sc, const TexRec &t, uint32_t id, V2 u
 CRT_DEV float taps_channel(const TexTaps &c, int channel)
 {
     const int sh = 8 * channel;
-    const float s00 = (float)(int)((c.t00 >> sh) & 0xffu) / 255.f, s10 = (float)(int)((c.t10 >> sh) & 0xffu) / 255.f;
-    const float s01 = (float)(int)((c.t01 >> sh) & 0xffu) / 255.f, s11 = (float)(int)((c.t11 >> sh) & 0xffu) / 255.f;
+    const float s00 = unorm8(c.t00 >> sh), s10 = unorm8(c.t10 >> sh);
+    const float s01 = unorm8(c.t01 >> sh), s11 = unorm8(c.t11 >> sh);
     return s00 * (1.f - c.tx) * (1.f - c.ty) + s10 * c.tx * (1.f - c.ty) + s01 * (1.f - c.tx) * c.ty + s11 * c.tx * c.ty;
 }
 
