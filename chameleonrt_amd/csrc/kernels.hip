@@ -534,7 +534,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 V3 v_x, v_y;
                 ortho_basis(v_x, v_y, normal);
 
+#ifdef CRT_EXP_SHADE_NO_NEE // TIMING EXPERIMENT ONLY (wrong image): what sample_direct_light's arithmetic costs
+                light_dir = normal;
+                light_dist = 1.f;
+                rng_nextf(rng);
+#else
                 nee_setup(sc, mat, normal, w_o, v_x, v_y, hit_p, rng, c_a, light_dir, light_dist, has_b, c_b, w_i_b, light_dist_b);
+#endif
                 n_rays += has_b ? 2u : 1u; // the occlusion rays (ispc:145-147, 171-173)
                 // `illum + path_throughput * nee` is evaluated even when nee == 0 (ispc:301): a
                 // non-finite throughput (the reference's glass pdfs can be negative or overflow)
@@ -596,7 +602,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         // draw are never observed: skipped.
         bool alive = false;
         V3 w_i = v3(0.f), tp = tp_in;
+#ifdef CRT_EXP_SHADE_NO_SAMPLE // TIMING EXPERIMENT ONLY (wrong image): what the continuation's BSDF sample costs
         if (is_hit && bounce + 1 < MAX_PATH_DEPTH) {
+            w_i = normal;
+            alive = (rng_next(rng) & 15u) != 0u;
+        }
+        if (false) {
+#else
+        if (is_hit && bounce + 1 < MAX_PATH_DEPTH) {
+#endif
             V3 v_x, v_y;
             ortho_basis(v_x, v_y, normal); // recomputed rather than kept live across phase 2
             float pdf;
