@@ -683,12 +683,60 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
 }
 
 // ---- K5 accumulate: render_embree.ispc:339-353 + tile_to_uint8 :358-370 ------------------------
+// A pixel's samples are summed in sample order (the reference's per-sample `illum = illum + ...`), so one thread sums one
+// pixel -- but the spp float4 records of a pixel are contiguous, and 64 lanes each reading their own 16 x spp bytes touch 64
+// different lines per load. For 2 <= spp <= ACC_TILE the block therefore streams its pixels' records through LDS: every
+// thread loads consecutive records (one 1 KB run per wave and instruction), then the threads of the first pixels of the
+// chunk sum their records from LDS in order. Same additions in the same order, coalesced reads: 0.49 -> ~0.2 ms on C4.
+constexpr int ACC_TILE = 1024;  // float4 records per LDS chunk (16 KB + padding)
+CRT_DEV uint32_t acc_pad(uint32_t e) { return e + (e >> 4); } // one spare record every 16: a pixel stride of 16 records would hit one bank group
 __global__ __launch_bounds__(SHADE_BLOCK) void k_accumulate(ViewParams vp, const uint32_t *tile_ids,
                                                             uint32_t slot0, uint32_t n_slots, const float4 *radiance,
                                                             float4 *accum, uint32_t *tile_fb, uint32_t *img_rowmajor,
                                                             uint32_t *ray_counts)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float4 s_tile[ACC_TILE + ACC_TILE / 16 + 1];
+    __shared__ float4 s_sum[SHADE_BLOCK];
+    const uint32_t k0 = blockIdx.x * blockDim.x;
+    const uint32_t k = k0 + threadIdx.x;
+    const uint32_t spp = vp.spp;
+    V3 illum = v3(0.f);
+    float rays = 0.f;
+    if (spp >= 2u && spp <= (uint32_t)ACC_TILE) {
+        const uint32_t n_here = min((uint32_t)SHADE_BLOCK, n_slots - k0); // (k0 < n_slots: the grid is ceil(n_slots / block))
+        const uint32_t per_chunk = (uint32_t)ACC_TILE / spp;              // whole pixels per chunk
+        const float4 *src = radiance + (size_t)k0 * spp;
+        for (uint32_t p0 = 0; p0 < n_here; p0 += per_chunk) {
+            const uint32_t pixels = min(per_chunk, n_here - p0), records = pixels * spp;
+            const float4 *chunk = src + (size_t)p0 * spp;
+            for (uint32_t e = threadIdx.x; e < records; e += SHADE_BLOCK) {
+                s_tile[acc_pad(e)] = chunk[e];
+            }
+            __syncthreads();
+            if (threadIdx.x < pixels) {
+                V3 sum = v3(0.f);
+                float r = 0.f;
+                for (uint32_t smp = 0; smp < spp; ++smp) {
+                    const float4 L = s_tile[acc_pad(threadIdx.x * spp + smp)];
+                    sum = sum + v3(L.x, L.y, L.z);
+                    r += L.w;
+                }
+                s_sum[p0 + threadIdx.x] = make_float4(sum.x, sum.y, sum.z, r);
+            }
+            __syncthreads();
+        }
+        if (k < n_slots) {
+            const float4 t = s_sum[threadIdx.x];
+            illum = v3(t.x, t.y, t.z);
+            rays = t.w;
+        }
+    } else if (k < n_slots) {
+        for (uint32_t smp = 0; smp < spp; ++smp) {
+            const float4 L = radiance[(size_t)k * spp + smp];
+            illum = illum + v3(L.x, L.y, L.z);
+            rays += L.w;
+        }
+    }
     if (k >= n_slots) {
         return;
     }
@@ -697,14 +745,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_accumulate(ViewParams vp, const
     if (!slot_to_pixel(vp, tile_ids, slot, x, y, ix, iy)) {
         return;
     }
-    V3 illum = v3(0.f);
-    float rays = 0.f;
-    for (uint32_t s = 0; s < vp.spp; ++s) {
-        const float4 L = radiance[(size_t)k * vp.spp + s];
-        illum = illum + v3(L.x, L.y, L.z);
-        rays += L.w;
-    }
-    illum = illum / (float)vp.spp;
+    illum = illum / (float)spp;
     const float4 a = accum[slot];
     illum = (illum + (float)vp.frame_id * v3(a.x, a.y, a.z)) / (float)(vp.frame_id + 1u);
     accum[slot] = make_float4(illum.x, illum.y, illum.z, 0.f);
