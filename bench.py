@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_GHZ, N_CUS, SIMDS = 2.4, 256, 4  # MI355X_MICROARCH.md chip-level parameters
 NODE_BYTES, SLOT_BYTES = 64, 64  # quantised BVH4 node / leaf slot of one or two triangles
 QUEUE_BYTES_CLOSEST = 24 + 32   # o,d read + the 32-byte hit record {t,u,v,tri | normal,material} written per ray
-QUEUE_BYTES_SHADOW = 28 + 8     # o,d,tmax + path,bslot read per ray
+QUEUE_BYTES_SHADOW = 28 + 16    # o,d,tmax + the 16-byte {c, path} record read per ray
 MAX_PATH_DEPTH = 5
 # CU-cycles of the vector-memory front end per divergent 64-byte line visit (tools/policy_microbench.hip, `plain`,
 # 100 % of the lanes active, profiles/r04_policy_microbench.txt): working set in L2 (1 MB) / in HBM (128 MB .. 1 GB)

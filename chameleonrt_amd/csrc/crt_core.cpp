@@ -314,10 +314,8 @@ void carve_queues(crt_hip_ctx::PassLane &l, uint64_t cap)
         l.sa.d[a] = f32();
     }
     l.sa.tmax = f32();
-    for (int a = 0; a < 3; ++a) {
-        l.sa.c[a] = f32();
-    }
-    l.sa.path = u32();
+    l.sa.cp = reinterpret_cast<float4 *>(base + k * cap); // 4 dwords per item (cap is a multiple of 64: 16-byte aligned)
+    k += 4;
     l.sa.bslot = i32();
     for (int a = 0; a < 3; ++a) {
         l.sb.o[a] = f32();
@@ -709,28 +707,23 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
         pc.n_shadow_a[bounce] = (uint32_t)n;
         HIP_CHECK(hipMemcpyAsync(d_pc.ptr, &pc, sizeof(pc), hipMemcpyHostToDevice, s));
         // one ShadowQueueA item per ray, contribution (1, 0, 0), no second ray: a visible ray leaves radiance.x = 1
-        std::vector<float> extra(5 * n);
+        std::vector<float4> extra(n);
         for (uint64_t i = 0; i < n; ++i) {
-            extra[i] = 1.f;
-            extra[n + i] = 0.f;
-            extra[2 * n + i] = 0.f;
             uint32_t path = (uint32_t)i;
-            int32_t bslot = -1;
-            std::memcpy(&extra[3 * n + i], &path, 4);
-            std::memcpy(&extra[4 * n + i], &bslot, 4);
+            float pw;
+            std::memcpy(&pw, &path, 4);
+            extra[i] = make_float4(1.f, 0.f, 0.f, pw);
         }
-        d_aux.alloc(5 * n * sizeof(float));
-        HIP_CHECK(hipMemcpyAsync(d_aux.ptr, extra.data(), 5 * n * sizeof(float), hipMemcpyHostToDevice, s));
-        float *x = d_aux.as<float>();
+        d_aux.alloc(n * sizeof(float4));
+        HIP_CHECK(hipMemcpyAsync(d_aux.ptr, extra.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
         ShadowQueueA sa{};
         for (int a = 0; a < 3; ++a) {
             sa.o[a] = base + (size_t)a * n;
             sa.d[a] = base + (size_t)(3 + a) * n;
-            sa.c[a] = x + (size_t)a * n;
         }
         sa.tmax = base + 6 * n;
-        sa.path = reinterpret_cast<uint32_t *>(x + 3 * n);
-        sa.bslot = reinterpret_cast<int32_t *>(x + 4 * n);
+        sa.cp = d_aux.as<float4>();
+        sa.bslot = nullptr; // (no item has a second ray)
         ShadowQueueB sb{};
         d_out.alloc(n * sizeof(float4));
         HIP_CHECK(hipMemsetAsync(d_out.ptr, 0, d_out.bytes, s));
@@ -1038,7 +1031,7 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
                              frame_id, b, (pc.t_end[b] - pc.t_start[b]) / 100.0, (pc.t_drained[b] - pc.t_start[b]) / 100.0,
                              100.0 * (double)(pc.t_end[b] - pc.t_drained[b]) / (double)(pc.t_end[b] - pc.t_start[b]));
             }
-            for (int k = 0; k < 2 && (ctx->flags & CRT_HIP_FLAG_COUNTERS); ++k) {
+            for (int k = 0; k < 2 && ((ctx->flags & CRT_HIP_FLAG_COUNTERS) || pc.prof_cycles[k][1] != 0); ++k) { // (a CRT_PHASE_PROFILE build fills them in every frame)
                 static const char *names[4] = {"refill", "inner", "leaf", "retire"};
                 double total = 0.0;
                 for (int ph = 0; ph < 4; ++ph) {

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 
 #include "../../include/crt_kat.h"
@@ -324,19 +325,20 @@ struct ShadowSource {
     CRT_DEV bool retire(uint32_t i, uint32_t &stage, const RayHit &h, V3 &o, V3 &d, float &tfar, uint32_t &carry) const
     {
         const bool visible = h.tri < 0; // `shadow_ray.tfar > 0.f`, ispc:148,174
-        const int32_t b = sa.bslot[i];
         if (stage == 0) {
-            if (b < 0) {
+            const float4 cp = sa.cp[i]; // {c, path | has_b}: one request for everything the common case needs
+            const uint32_t pw = __float_as_uint(cp.w);
+            if ((pw & SHADOW_HAS_B) == 0u) {
                 if (visible) { // nee = cA
-                    const uint32_t p = sa.path[i];
-                    float4 L = radiance[p];
-                    L.x = L.x + sa.c[0][i];
-                    L.y = L.y + sa.c[1][i];
-                    L.z = L.z + sa.c[2][i];
-                    radiance[p] = L;
+                    float4 L = radiance[pw];
+                    L.x = L.x + cp.x;
+                    L.y = L.y + cp.y;
+                    L.z = L.z + cp.z;
+                    radiance[pw] = L;
                 }
                 return false;
             }
+            const int32_t b = sa.bslot[i];
             carry = visible ? 1u : 0u;
             o = v3(sb.o[0][b], sb.o[1][b], sb.o[2][b]); // same origin, BSDF-sampled direction
             d = v3(sb.d[0][b], sb.d[1][b], sb.d[2][b]);
@@ -345,6 +347,7 @@ struct ShadowSource {
             return true;
         }
         // sample_direct_light's return value: illum = 0; [illum = cA;] [illum = illum + cB]
+        const int32_t b = sa.bslot[i];
         V3 nee = v3(0.f);
         if (carry) {
             nee = v3(sb.ca[0][b], sb.ca[1][b], sb.ca[2][b]);
@@ -453,12 +456,12 @@ CRT_DEV void nee_setup(const SceneView &sc, const Surface &mat, V3 normal, V3 w_
 constexpr int STAGE_CAP = SHADE_BLOCK;
 struct ShadeStage {
     uint32_t next[11][STAGE_CAP]; // PathQueue fields in declaration order
-    uint32_t a[12][STAGE_CAP];    // ShadowQueueA fields in declaration order
+    uint32_t a[12][STAGE_CAP];    // ShadowQueueA: o, d, tmax (its seven SoA fields in declaration order), c.xyz, path | has_b, slot in ShadowQueueB
     uint32_t cnt_a[2], cnt_next[2]; // entries staged in this step; the counters alternate with the step's parity
     uint32_t base, base_next;       // where the step's entries go in the global queues
 };
-static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 12 * sizeof(void *),
-              "queue structs are arrays of field pointers");
+static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 9 * sizeof(void *) && offsetof(ShadowQueueA, cp) == 7 * sizeof(void *),
+              "PathQueue is an array of field pointers, ShadowQueueA starts with seven");
 
 __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             stage.a[7][la] = __float_as_uint(c.x);
             stage.a[8][la] = __float_as_uint(c.y);
             stage.a[9][la] = __float_as_uint(c.z);
-            stage.a[10][la] = path;
-            stage.a[11][la] = has_b ? slot_b : 0xffffffffu;
+            stage.a[10][la] = path | (has_b ? SHADOW_HAS_B : 0u);
+            stage.a[11][la] = slot_b;
         }
 
         // Phase 3 (per lane): continue the path, ispc:313-335. On the last iteration
@@ -666,8 +669,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             uint32_t *const *fn = reinterpret_cast<uint32_t *const *>(&qout);
             if (t < na) {
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
+                for (int k = 0; k < 7; ++k) {
                     fa[k][ba + t] = stage.a[k][t];
+                }
+                sa.cp[ba + t] = make_float4(__uint_as_float(stage.a[7][t]), __uint_as_float(stage.a[8][t]), __uint_as_float(stage.a[9][t]),
+                                            __uint_as_float(stage.a[10][t]));
+                if ((stage.a[10][t] & SHADOW_HAS_B) != 0u) { // (one hit in 10^5)
+                    sa.bslot[ba + t] = (int32_t)stage.a[11][t];
                 }
             }
             if (t < nn) {

@@ -246,16 +246,30 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
                              unsigned long long *prof = nullptr /* PassCounters::prof_cycles[kind], iters, lanes 8 and 16 on */)
 {
-    unsigned long long pf_cyc[4] = {0, 0, 0, 0};
-    uint32_t pf_it[4] = {0, 0, 0, 0}, pf_ln[4] = {0, 0, 0, 0};
-    unsigned long long pf_t = COUNTERS ? (unsigned long long)clock64() : 0ull;
+    // Phase clocks (refill / inner / leaf / retire): wave-uniform, scalar. Normally part of the instrumented (COUNTERS)
+    // instantiations -- whose visit counters cost VGPRs the closest-hit kernels do not have (they spill: 116 B of scratch), which
+    // distorts exactly what the clocks are to measure. -DCRT_PHASE_PROFILE=1 (a tools/variants.py build) puts the clocks
+    // alone into the PRODUCTION instantiations, whose register allocation they leave alone.
+#ifndef CRT_PHASE_PROFILE
+#define CRT_PHASE_PROFILE 0
+#endif
+    constexpr bool PROF = COUNTERS || CRT_PHASE_PROFILE != 0;
+    // (32-bit cycle sums -- a launch is far shorter than 2^32 cycles per phase -- and only the counts that differ: nine SGPRs)
+    uint32_t pf_cyc[4] = {0, 0, 0, 0};
+    uint32_t pf_inner_steps = 0, pf_outer = 0, pf_inner_lanes = 0, pf_leaf_lanes_sum = 0;
+    uint32_t pf_t = PROF ? (uint32_t)clock64() : 0u;
     auto pf_mark = [&](int phase, uint32_t lanes) {
-        if (COUNTERS) {
-            const unsigned long long now = (unsigned long long)clock64();
+        if (PROF) {
+            const uint32_t now = (uint32_t)clock64();
             pf_cyc[phase] += now - pf_t;
             pf_t = now;
-            pf_it[phase] += 1u;
-            pf_ln[phase] += lanes;
+            if (phase == 1) {
+                pf_inner_steps += 1u;
+                pf_inner_lanes += lanes;
+            } else if (phase == 2) {
+                pf_outer += 1u;
+                pf_leaf_lanes_sum += lanes;
+            }
         }
     };
     if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
@@ -590,7 +604,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
         }
 
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
-        const uint32_t pf_leaf_lanes = COUNTERS ? (uint32_t)__popcll(__ballot(ray >= 0 && cur < 0 && cur != CUR_DONE)) : 0u;
+        const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(__ballot(ray >= 0 && cur < 0 && cur != CUR_DONE)) : 0u;
         if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
             bool entered = false;
             if (TWO_LEVEL && cur == CUR_EXIT) {
@@ -720,7 +734,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
             }
         }
 
-        if (COUNTERS) {
+        if (PROF) {
             pf_mark(2, pf_leaf_lanes);
         }
         // ---- retire finished rays -------------------------------------------------------------
@@ -772,15 +786,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 ray = -1;
             }
         }
-        if (COUNTERS) {
+        if (PROF) {
             pf_mark(3, 0u);
         }
     }
-    if (COUNTERS && prof != nullptr && tv_lane_id() == 0) {
+    if (PROF && prof != nullptr && tv_lane_id() == 0) {
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&prof[k], pf_cyc[k]);
-            atomicAdd(&prof[8 + k], (unsigned long long)pf_it[k]);
-            atomicAdd(&prof[16 + k], (unsigned long long)pf_ln[k]);
+            atomicAdd(&prof[k], (unsigned long long)pf_cyc[k]);
+            atomicAdd(&prof[8 + k], (unsigned long long)(k == 1 ? pf_inner_steps : pf_outer));
+            atomicAdd(&prof[16 + k], (unsigned long long)(k == 1 ? pf_inner_lanes : k == 2 ? pf_leaf_lanes_sum : 0u));
         }
     }
 }

@@ -7,7 +7,7 @@
 //   PathQueue (x2, ping-pong)  closest-hit rays of one bounce: origin, direction, path id,
 //                              RNG state, throughput                       11 dwords / ray
 //   HitBuf                     t, u, v, triangle index | shading normal, material: ONE 32-byte record / ray
-//   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray
+//   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray (7 SoA + one 16-byte record + 1)
 //   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare) 18 dwords / ray
 //   radiance                   float4 per path: rgb = radiance so far, w = rays traced
 //
@@ -46,10 +46,14 @@ struct ShadowQueueA {
     float *o[3];
     float *d[3];
     float *tmax;
-    float *c[3];
-    uint32_t *path;
-    int32_t *bslot; // index into ShadowQueueB or -1
+    // What retiring the ray needs, as ONE 16-byte record {c.x, c.y, c.z, bits(path | has_b << 31)}: a lane retires
+    // whatever item it happens to hold, so five SoA dwords (c, path, bslot) were five divergent line visits per
+    // occlusion ray in a kernel bound by exactly those; the ray itself (o, d, tmax) stays SoA --
+    // a refill takes consecutive items, which coalesce.
+    float4 *cp;
+    int32_t *bslot; // index into ShadowQueueB; written and read only for items whose has_b bit is set
 };
+constexpr uint32_t SHADOW_HAS_B = 0x80000000u; // in ShadowQueueA::cp[i].w, above the path index (PATH_ID_BITS = 27)
 
 // Second NEE shadow ray (render_embree.ispc:156-179): keeps both contributions and the
 // throughput unmultiplied so that illum += tp * (cA*visA + cB*visB) is evaluated in the
