@@ -301,6 +301,12 @@ RenderStats RenderHIP::render_impl(const glm::vec3 &pos, const glm::vec3 &dir, c
     }
     nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
     check(ctxs[0], crt_hip_assemble_tiles(ctxs[0], multi->gathered, int(n), readback ? 1 : 0), "crt_hip_assemble_tiles");
+    if (!readback) {
+        // (assemble_tiles waits only for a read-back; whoever takes the image from HBM next -- RenderHIPGL's copy into the GL
+        // texture -- must find it complete, and render() reports the time of the whole frame)
+        hip_ok(hipSetDevice(0), "hipSetDevice");
+        hip_ok(hipStreamSynchronize(multi->streams[0]), "hipStreamSynchronize");
+    }
     copy_image(readback);
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
     stats.render_time = ms;
