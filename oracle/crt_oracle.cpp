@@ -997,50 +997,56 @@ struct Bvh {
     }
 };
 
-// 4x4 inverse (cofactor expansion; stands in for glm::inverse at embree_utils.cpp:97).
-// Index-agnostic w.r.t. row/column major.
-inline bool invert4x4(const float m[16], float out[16])
+// glm::inverse (embree_utils.cpp:97: world_to_object = inverse(instance.transform)), column-major 4x4.
+inline bool invert4x4(const float m_[16], float out[16])
 {
-    float inv[16];
-    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] +
-             m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] -
-             m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] +
-             m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] -
-              m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] -
-             m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] +
-             m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] -
-             m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] +
-              m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] +
-             m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] -
-             m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] +
-              m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] -
-              m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] -
-             m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] +
-             m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] -
-              m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] +
-              m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-    if (det == 0.f) {
+    // GLM 0.9.9.8 (the version the reference's cmake/glm.cmake pins), glm/detail/func_matrix.inl, compute_inverse<4, 4, T, Q,
+    // Aligned>, scalar path -- third party, absent from the reference tree and from this image, restated from its published
+    // source: eighteen 2x2 sub-determinants, the adjugate's columns as vec4 expressions evaluated left to right
+    // ((a * b - c * d) + e * f), the sign pattern, the determinant as dot(column 0 of m, row 0 of the adjugate) summed
+    // (x + y) + (z + w) like GLM's compute_dot<vec4>, and one reciprocal multiplied through. m[c][r] = m_[4 * c + r].
+    // GLM does not look at the determinant; a zero one is reported here (the reference would go on with infinities).
+    #define M(c, r) m_[4 * (c) + (r)]
+    const float Coef00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+    const float Coef02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+    const float Coef03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+    const float Coef04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    const float Coef06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+    const float Coef07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    const float Coef08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+    const float Coef10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+    const float Coef11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+    const float Coef12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    const float Coef14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+    const float Coef15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    const float Coef16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+    const float Coef18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+    const float Coef19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+    const float Coef20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    const float Coef22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+    const float Coef23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    const float Fac0[4] = {Coef00, Coef00, Coef02, Coef03}, Fac1[4] = {Coef04, Coef04, Coef06, Coef07};
+    const float Fac2[4] = {Coef08, Coef08, Coef10, Coef11}, Fac3[4] = {Coef12, Coef12, Coef14, Coef15};
+    const float Fac4[4] = {Coef16, Coef16, Coef18, Coef19}, Fac5[4] = {Coef20, Coef20, Coef22, Coef23};
+    const float Vec0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)}, Vec1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)};
+    const float Vec2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)}, Vec3[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+    #undef M
+    const float SignA[4] = {+1.f, -1.f, +1.f, -1.f}, SignB[4] = {-1.f, +1.f, -1.f, +1.f};
+    float inv[16]; // the adjugate, column c at inv[4 * c ..]
+    for (int i = 0; i < 4; ++i) {
+        inv[0 + i] = (Vec1[i] * Fac0[i] - Vec2[i] * Fac1[i] + Vec3[i] * Fac2[i]) * SignA[i];
+        inv[4 + i] = (Vec0[i] * Fac0[i] - Vec2[i] * Fac3[i] + Vec3[i] * Fac4[i]) * SignB[i];
+        inv[8 + i] = (Vec0[i] * Fac1[i] - Vec1[i] * Fac3[i] + Vec3[i] * Fac5[i]) * SignA[i];
+        inv[12 + i] = (Vec0[i] * Fac2[i] - Vec1[i] * Fac4[i] + Vec2[i] * Fac5[i]) * SignB[i];
+    }
+    const float Dot0[4] = {m_[0] * inv[0], m_[1] * inv[4], m_[2] * inv[8], m_[3] * inv[12]};
+    const float Dot1 = (Dot0[0] + Dot0[1]) + (Dot0[2] + Dot0[3]);
+    if (Dot1 == 0.f) {
         return false;
     }
-    const float r = 1.f / det;
+    const float OneOverDeterminant = 1.f / Dot1;
     for (int i = 0; i < 16; ++i) {
-        out[i] = inv[i] * r;
+        out[i] = inv[i] * OneOverDeterminant;
     }
     return true;
 }

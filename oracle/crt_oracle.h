@@ -21,7 +21,8 @@
  *    .github/workflows/cmake.yml:12; call sites backends/embree/render_embree.ispc:144,170,245),
  *    which is not in /root/reference and not installable here; the pinning run above plugs the
  *    oracle's own intersector in where the kernel calls rtcIntersect1 / rtcOccluded1, and
- *    GLM's matrix inverse (third-party too) is the oracle's. The ISPC build's `--opt=fast-math`
+ *    GLM's matrix inverse (third-party too: GLM 0.9.9.8 per cmake/glm.cmake, absent here) is restated from its published
+ *    source (glm/detail/func_matrix.inl, compute_inverse<4, 4>), operation for operation. The ISPC build's `--opt=fast-math`
  *    and approximate transcendentals are not reproduced by any C++ build either.
  */
 #ifndef CRT_ORACLE_H
@@ -76,7 +77,7 @@ int orc_trace_rays(const orc_scene *s, uint64_t n, const float *org, const float
                    float *out_t, float *out_u, float *out_v, int32_t *out_inst,
                    int32_t *out_geom, int32_t *out_prim, orc_stats *stats);
 
-/* glm::inverse stand-in used for Instance::world_to_object (embree_utils.cpp:97). 1 = invertible. */
+/* glm::inverse (GLM 0.9.9.8's compute_inverse<4,4>, restated) used for Instance::world_to_object (embree_utils.cpp:97). 1 = invertible. */
 int orc_invert4x4(const float m[16], float out[16]);
 
 /* The same stand-in for one ray, on the calling thread: 1 = hit / occluded, 0 = not. */

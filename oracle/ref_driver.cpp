@@ -123,7 +123,7 @@ int ref_render(const crt_scene_desc *desc, int fb_w, int fb_h, const float pos[3
         const crt_parameterized_mesh_desc &pm = desc->parameterized_meshes[desc->instances[i].parameterized_mesh_id];
         insts[i].geometries = geoms.data() + desc->meshes[pm.mesh_id].first_geometry;
         std::memcpy(insts[i].object_to_world, desc->instances[i].transform, sizeof(float) * 16);
-        // glm::inverse (third-party) -> the oracle's stand-in, so both sides shade with the same matrices
+        // glm::inverse (third-party, absent here) -> the oracle's restatement of GLM 0.9.9.8's compute_inverse<4,4>, so both sides shade with the same matrices
         if (!orc_invert4x4(desc->instances[i].transform, insts[i].world_to_object)) {
             orc_scene_destroy(st.orc);
             return -3;
