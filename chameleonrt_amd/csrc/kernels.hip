@@ -1039,14 +1039,16 @@ void launch_trace_shadow(const LaunchCfg &cfg, const SceneView &sc, ShadowQueueA
 // 32, 18.0 at 128; C3 3.40 -> 3.15 ms; fewer than 8 is slower (20.4 at 4). A block should still have a few iterations to
 // amortise its start and its final partial flush (C2, 1.8 M paths per pass: 8 per CU is best), hence: one block per
 // CRT_SHADE_MIN_ITERS x 256 paths of the pass, between CRT_SHADE_GRID and CRT_SHADE_GRID_MAX blocks per CU (256 with 2
-// iterations: C4 shade a further -0.3 ms against 128 with 4). (Handing the steps
+// iterations: C4 shade a further -0.3 ms against 128 with 4; round 4, after the kernel lost a fifth of its arithmetic: 1024 with 1
+// iteration -- one block per 256 paths, no loop at all for a full-size pass -- 14.37 -> 13.66 ms on C4, C4F 13.96 -> 13.69, C2 / C3 /
+// C4's eighth +-1 %, profiles/r04_shade_alu_ab.txt). (Handing the steps
 // out in queue order by an atomic cursor instead: C4 shade 17.4 ms with 8 blocks per CU, but C3 +3 % and C2 +25 %: not kept. Runs of 2 .. 64
 // consecutive steps per XCD (block b runs on XCD b % 8) so that neighbours meet in one L2: no difference on any workload.)
 #ifndef CRT_SHADE_GRID_MAX
-#define CRT_SHADE_GRID_MAX 256
+#define CRT_SHADE_GRID_MAX 1024
 #endif
 #ifndef CRT_SHADE_MIN_ITERS
-#define CRT_SHADE_MIN_ITERS 2
+#define CRT_SHADE_MIN_ITERS 1
 #endif
 void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitBuf hits, PathQueue qout,
                   ShadowQueueA sa, ShadowQueueB sb, float4 *radiance, PassCounters *pc, int bounce, uint32_t n_paths_max)
