@@ -71,7 +71,7 @@ def build_fast(force=False):
 
 
 IO_LIB = os.path.join(HERE, "libcrt_scene_io.so")
-IO_SOURCES = ["obj_reader.cpp"]
+IO_SOURCES = ["obj_reader.cpp", "jpeg_reader.cpp"]
 
 
 def build_scene_io(force=False):

@@ -84,12 +84,12 @@ def _view(header: dict, blob: memoryview, view_id: int, want: Tuple[type, int]) 
 
 
 def _decode_image(data: bytes, name: str, color_space: str) -> Image:
-    from PIL import Image as PILImage
+    from .image_io import decode_rgba
     try:
-        im = PILImage.open(io.BytesIO(data)).convert("RGBA")  # stbi_load_from_memory(..., 4)
+        a = decode_rgba(bytes(data))  # stbi_load_from_memory(..., 4)
     except Exception as exc:  # the reference throws too (scene.cpp:497-500)
         raise RuntimeError(f"Failed to load {name}") from exc
-    a = np.asarray(im, dtype=np.uint8)[::-1].copy()  # stbi_set_flip_vertically_on_load(1)
+    a = a[::-1].copy()  # stbi_set_flip_vertically_on_load(1)
     return Image(a.shape[1], a.shape[0], 4, a, LINEAR if color_space == "LINEAR" else SRGB, name)
 
 

@@ -108,13 +108,14 @@ class _Model:
         return np.ascontiguousarray(rows).view(dt).reshape(count, ncomp)
 
     def image(self, i: int) -> Image:
-        from PIL import Image as PILImage
+        from .image_io import decode_rgba
         im = self.doc["images"][i]
         data = self._uri(im["uri"]) if "uri" in im else self.view_bytes(im["bufferView"])
-        pil = PILImage.open(io.BytesIO(data))
-        if pil.mode.startswith("I;16") or pil.mode == "I":
-            raise RuntimeError("Unsupported image pixel type")  # scene.cpp:335-338
-        a = np.asarray(pil.convert("RGBA"), dtype=np.uint8).copy()  # tinygltf asks stb for 4 components; no flip
+
+        def check(pil):
+            if pil.mode.startswith("I;16") or pil.mode == "I":
+                raise RuntimeError("Unsupported image pixel type")  # scene.cpp:335-338
+        a = decode_rgba(bytes(data), check)  # tinygltf asks stb for 4 components; no flip
         return Image(a.shape[1], a.shape[0], 4, a, LINEAR, im.get("name", ""))
 
 

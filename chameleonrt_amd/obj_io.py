@@ -47,9 +47,9 @@ def _parse_mtl(path: str) -> List[dict]:
 
 
 def _load_texture(path: str, name: str) -> Image:
-    from PIL import Image as PILImage
-    im = PILImage.open(path).convert("RGBA")  # forced to 4 channels
-    a = np.asarray(im, dtype=np.uint8)[::-1].copy()  # stbi_set_flip_vertically_on_load(1)
+    from .image_io import decode_rgba
+    with open(path, "rb") as f:
+        a = decode_rgba(f.read())[::-1].copy()  # forced to 4 channels; stbi_set_flip_vertically_on_load(1)
     return Image(a.shape[1], a.shape[0], 4, a, SRGB, name)
 
 

@@ -39,6 +39,16 @@ int crt_obj_shape_material_libs(const crt_obj_file *f, int shape);
 /* vertices: n_vertices * 3 floats, indices: n_triangles * 3, uvs: n_vertices * 2 floats (ignored unless has_uv == 1) */
 int crt_obj_shape_copy(const crt_obj_file *f, int shape, float *vertices, uint32_t *indices, float *uvs);
 
+/* ---- texture files ------------------------------------------------------------------------------------------------
+ * JPEG decoding with the arithmetic of the reference's decoder (its vendored stb_image, util/material.cpp:5-17 ->
+ * util/stb_image.h: inverse DCT, chroma up-sampling and YCbCr -> RGB are implementation choices on which libjpeg-based
+ * decoders differ from it by up to 2/255). bytes: the file's contents. On success (0) *rgba points to width * height * 4
+ * bytes, rows top to bottom, alpha 255 -- what stbi_load(..., 4) returns BEFORE the reference's vertical flip -- to be
+ * released with crt_image_free. Baseline and progressive, 8-bit, 1 / 3 / 4 components, restart intervals. */
+int crt_image_decode_jpeg(const uint8_t *bytes, uint64_t n_bytes, int32_t *width, int32_t *height, uint8_t **rgba);
+void crt_image_free(uint8_t *rgba);
+const char *crt_image_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,7 +82,8 @@ def write_files():
     return out
 
 
-DECODER_IMAGES = ["a420.jpg", "b444.jpg", "cgray.jpg", "dprog.jpg", "e32rle.tga", "f24.tga", "g24top.tga", "hgray.tga"]
+DECODER_IMAGES = ["a420.jpg", "b444.jpg", "cgray.jpg", "dprog.jpg", "e32rle.tga", "f24.tga", "g24top.tga", "hgray.tga",
+                  "i422.jpg", "j420prog.jpg", "k420rst.jpg", "l1x1.jpg", "m444q100.jpg", "ncmyk.jpg", "ograyprog.jpg", "p422rst.jpg"]
 
 
 def write_decoder_files():
@@ -107,6 +108,16 @@ def write_decoder_files():
     Image.fromarray(pic(31, 18, 3)).save(os.path.join(d, "f24.tga"))
     Image.fromarray(pic(31, 18, 3)).save(os.path.join(d, "g24top.tga"), orientation=1)
     Image.fromarray(pic(21, 11, 1)[..., 0]).save(os.path.join(d, "hgray.tga"))
+    # more JPEG shapes: 4:2:2, progressive 4:2:0 with optimised tables, restart intervals, one pixel, quality 100 (all-ones
+    # quantisation: the largest coefficients), Adobe CMYK, progressive grey, 4:2:2 with a restart every row of MCUs
+    Image.fromarray(pic(33, 17, 3)).save(os.path.join(d, "i422.jpg"), quality=70, subsampling=1)
+    Image.fromarray(pic(50, 47, 3)).save(os.path.join(d, "j420prog.jpg"), quality=60, subsampling=2, progressive=True, optimize=True)
+    Image.fromarray(pic(64, 48, 3)).save(os.path.join(d, "k420rst.jpg"), quality=80, subsampling=2, restart_marker_blocks=3)
+    Image.fromarray(pic(1, 1, 3)).save(os.path.join(d, "l1x1.jpg"), quality=90)
+    Image.fromarray(pic(24, 24, 3)).save(os.path.join(d, "m444q100.jpg"), quality=100, subsampling=0)
+    Image.fromarray(pic(16, 12, 4), "CMYK").save(os.path.join(d, "ncmyk.jpg"), quality=85)
+    Image.fromarray(pic(40, 31, 1)[..., 0]).save(os.path.join(d, "ograyprog.jpg"), quality=75, progressive=True)
+    Image.fromarray(pic(47, 40, 3)).save(os.path.join(d, "p422rst.jpg"), quality=88, subsampling=1, restart_marker_rows=1)
     with open(os.path.join(d, "t.mtl"), "w") as f:
         for i, n in enumerate(DECODER_IMAGES):
             f.write(f"newmtl m{i}\nKd 1 1 1\nmap_Kd {n}\n")

@@ -1,21 +1,24 @@
 """CPU: texture FILE decoding against the reference's decoder.
 
 The reference reads every texture file with its vendored stb_image (`Image::Image(file, ...)`, util/material.cpp:5-17:
-stbi_set_flip_vertically_on_load(1), four channels forced); chameleonrt_amd's importers read them with Pillow
-(obj_io._load_texture, gltf_io). tests/golden/scenes/decoders/ holds an OBJ whose materials name the formats real Sponza /
-San Miguel assets ship besides PNG: JPEG (4:2:0, 4:4:4, greyscale, progressive) and TGA (32-bit RLE, 24-bit bottom-up and
-top-down, 8-bit grey); tests/golden/refdecoders_obj.npz is what the reference's importer, compiled from where it lies
+stbi_set_flip_vertically_on_load(1), four channels forced). tests/golden/scenes/decoders/ holds an OBJ whose materials
+name the formats real Sponza / San Miguel assets ship besides PNG: JPEG (4:2:0, 4:4:4, 4:2:2, greyscale, progressive with
+optimised tables, restart intervals, one pixel, quality 100, Adobe CMYK) and TGA (32-bit RLE, 24-bit bottom-up and top-down,
+8-bit grey); tests/golden/refdecoders_obj.npz is what the reference's importer, compiled from where it lies
 (oracle/_ref/libref_scene.so, tests/golden/make_scene_golden.py --decoders), makes of them.
 
-The bar: PNG (tests/test_importers_pinned.py) and TGA bit for bit. JPEG is a DOCUMENTED DEVIATION:
-stb_image and libjpeg differ in the inverse DCT's rounding and in chroma up-sampling, so decoded texels may differ by
-at most 2 / 255 on a few per cent of the samples -- asserted here so that the deviation cannot grow unnoticed.
+The bar: EVERY texel bit for bit. PNG (tests/test_importers_pinned.py) and TGA go through Pillow, which matches stb_image;
+JPEG goes through chameleonrt_amd/csrc/jpeg_reader.cpp, which restates stb_image's inverse DCT, chroma up-sampling and
+YCbCr -> RGB arithmetic (a libjpeg-based decoder differs from it by up to 2/255 on a few per cent of the samples: that
+documented deviation now only applies on a host without a C++ compiler, where image_io falls back to Pillow).
 """
+import io
 import os
 
 import numpy as np
 import pytest
 
+from chameleonrt_amd import image_io
 from chameleonrt_amd.obj_io import load_obj
 from tests import ref_scene_lib as R
 from tests.golden.make_scene_golden import DECODER_IMAGES
@@ -24,25 +27,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "golden", "scenes", "decoders", "t.obj")
 
 
-def _pairs(ref):
+def _check(ref):
     mine = R.flatten(load_obj(OBJ))
     assert int(ref["counts"][4]) == len(DECODER_IMAGES) == int(mine["counts"][4])
     for i, name in enumerate(DECODER_IMAGES):
         assert np.array_equal(ref[f"tex{i}_info"], mine[f"tex{i}_info"]), name  # width, height, 4 channels, sRGB
-        yield name, np.asarray(ref[f"tex{i}_data"]).astype(int), np.asarray(mine[f"tex{i}_data"]).astype(int)
+        a, b = np.asarray(ref[f"tex{i}_data"]), np.asarray(mine[f"tex{i}_data"])
+        assert np.array_equal(a, b), f"{name}: {(a != b).mean():.4f} of the samples differ from stb_image's (max {np.abs(a.astype(int) - b.astype(int)).max()})"
 
 
-def _check(ref):
-    for name, a, b in _pairs(ref):
-        d = np.abs(a - b)
-        if name.endswith(".tga"):
-            assert d.max() == 0, f"{name}: TGA decoding differs from stb_image's"
-        else:
-            assert d.max() <= 2 and d.mean() <= 0.12 and (d > 0).mean() <= 0.10, (name, int(d.max()), float(d.mean()), float((d > 0).mean()))
-            assert (a.reshape(-1, 4)[:, 3] == 255).all() and (b.reshape(-1, 4)[:, 3] == 255).all()
-
-
-def test_tga_bit_exact_and_jpeg_within_two_lsb_of_the_reference_dump():
+def test_every_format_bit_for_bit_against_the_reference_dump():
     _check(dict(np.load(os.path.join(HERE, "golden", "refdecoders_obj.npz"))))
 
 
@@ -53,3 +47,48 @@ def test_the_dump_is_what_the_reference_decodes_now():
     for k in gold:
         assert np.array_equal(np.asarray(live[k]), np.asarray(gold[k])), k
     _check(live)
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref_scene.so is built where /root/reference exists")
+def test_random_jpegs_against_the_live_reference_decoder(tmp_path):
+    """24 seeded JPEG files -- sizes 1 .. 90, three subsamplings, baseline / progressive, optimised tables, restart
+    intervals, qualities 5 .. 100, grey and colour, smooth and noisy content -- through `Scene(fname)` of the reference
+    (stb_image) and through load_obj: identical texels."""
+    from PIL import Image
+    rng = np.random.default_rng(2024)
+    names = []
+    for k in range(24):
+        w, h = int(rng.integers(1, 91)), int(rng.integers(1, 91))
+        grey = k % 5 == 4
+        y, x = np.mgrid[0:h, 0:w]
+        chans = [np.sin(x / rng.uniform(2, 20) + c) * 80 + np.cos(y / rng.uniform(2, 20)) * 60 + 128 + rng.normal(0, rng.uniform(0, 40), (h, w))
+                 for c in range(1 if grey else 3)]
+        a = np.clip(np.stack(chans, -1), 0, 255).astype(np.uint8)
+        kw = dict(quality=int(rng.choice([5, 30, 60, 85, 95, 100])), progressive=bool(k % 3 == 1), optimize=bool(k % 4 == 2))
+        if not grey:
+            kw["subsampling"] = int(k % 3)
+        if k % 6 == 3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 6))
+        name = f"r{k}.jpg"
+        Image.fromarray(a[..., 0] if grey else a).save(str(tmp_path / name), **kw)
+        names.append(name)
+    (tmp_path / "r.mtl").write_text("".join(f"newmtl m{i}\nKd 1 1 1\nmap_Kd {n}\n" for i, n in enumerate(names)))
+    (tmp_path / "r.obj").write_text("mtllib r.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n" +
+                                    "".join(f"o s{i}\nusemtl m{i}\nf 1/1 2/2 3/3\n" for i in range(len(names))))
+    ref, mine = R.load(str(tmp_path / "r.obj")), R.flatten(load_obj(str(tmp_path / "r.obj")))
+    for i, n in enumerate(names):
+        assert np.array_equal(ref[f"tex{i}_info"], mine[f"tex{i}_info"]), n
+        assert np.array_equal(np.asarray(ref[f"tex{i}_data"]), np.asarray(mine[f"tex{i}_data"])), n
+
+
+def test_native_decoder_refuses_garbage():
+    with pytest.raises(ValueError):
+        image_io.decode_jpeg_rgba(b"\xff\xd8\xff\xdb\x00\x03")
+    with pytest.raises(ValueError):
+        image_io.decode_jpeg_rgba(b"not a jpeg at all")
+    good = open(os.path.join(HERE, "golden", "scenes", "decoders", "a420.jpg"), "rb").read()
+    for cut in (20, len(good) // 2):
+        try:
+            image_io.decode_jpeg_rgba(good[:cut])  # truncated: an error or a partial image, never a crash
+        except ValueError:
+            pass
