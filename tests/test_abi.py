@@ -34,11 +34,12 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_scene_io_library_exports_its_header():
-    """include/crt_scene_io.h (the harness's streaming OBJ reader) == what libcrt_scene_io.so exports."""
+    """include/crt_scene_io.h (the harness's streaming OBJ reader and JPEG decoder) == what libcrt_scene_io.so exports."""
     import ctypes as C
     from chameleonrt_amd import build
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "crt_scene_io.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(crt_obj_[a-z_]+)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(crt_(?:obj|image)_[a-z_]+)\s*\(", src)))
+    assert "crt_image_decode_jpeg" in names and "crt_obj_parse" in names
     assert len(names) >= 9
     L = C.CDLL(build.build_scene_io())
     for n in names:
