@@ -379,16 +379,18 @@ struct Builder {
         }
         tn[me].left = l;
         tn[me].right = r;
-        {
-            const Aabb &x = tn[me].box;
-            const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
-            int a;
-            const double as_root = (dx * dy + dy * dz + dz * dx) + best_split(me, 4, a);
-            tn[me].slot_cost[0] = as_root;
-            tn[me].slot_cost[1] = std::min(as_root, best_split(me, 2, a));
-            tn[me].slot_cost[2] = std::min(as_root, best_split(me, 3, a));
-        }
+        fill_slot_cost(me);
         return me;
+    }
+    void fill_slot_cost(int32_t me) // both children complete
+    {
+        const Aabb &x = tn[me].box;
+        const double dx = (double)x.hi[0] - x.lo[0], dy = (double)x.hi[1] - x.lo[1], dz = (double)x.hi[2] - x.lo[2];
+        int a;
+        const double as_root = (dx * dy + dy * dz + dz * dx) + best_split(me, 4, a);
+        tn[me].slot_cost[0] = as_root;
+        tn[me].slot_cost[1] = std::min(as_root, best_split(me, 2, a));
+        tn[me].slot_cost[2] = std::min(as_root, best_split(me, 3, a));
     }
     // slots(t, j): see TNode::slot_cost; a leaf costs nothing here (its triangles are tested either way)
     double slots(int32_t t, int j) const { return tn[t].left >= 0 ? tn[t].slot_cost[j - 1] : 0.0; }
@@ -407,6 +409,172 @@ struct Builder {
         return best;
     }
 };
+
+// ---- insertion-based optimisation of the binary tree (opt-in: CRT_BVH_REINSERT=<passes>) ----------------------------
+// A top-down build decides every split with the items of one range in hand and never revisits it. Bittner, Hapala,
+// Havran 2013 ("Fast insertion-based optimization of bounding volume hierarchies") repair that afterwards: take a subtree
+// out (its parent goes with it, the sibling moves up), find the place where putting it back costs the least summed
+// surface area -- the direct cost area(x U y) of the new parent plus the growth of every ancestor of y -- by a
+// branch-and-bound search from the root, and put it there, reusing the parent node. Leaves keep their item ranges, so
+// nothing below changes. Serial and deterministic (ties by node index). Role in the reference: the quality of
+// rtcCommitScene's tree (embree_utils.cpp:63-76); priced like every builder change by tools/tree_cost.py.
+struct Reinserter {
+    TNode *tn;
+    int32_t root;
+    std::vector<int32_t> parent;
+    std::vector<float> area;
+    struct Cand {
+        float induced;
+        int32_t node;
+    };
+    std::vector<Cand> heap;
+
+    static Aabb merged(const Aabb &a, const Aabb &b)
+    {
+        Aabb o = a;
+        box_grow(o, b);
+        return o;
+    }
+    void index(int32_t n_nodes)
+    {
+        parent.assign(n_nodes, -1);
+        area.assign(n_nodes, 0.f);
+        for (int32_t t = 0; t < n_nodes; ++t) {
+            area[t] = half_area(tn[t].box);
+            if (tn[t].left >= 0) {
+                parent[tn[t].left] = t;
+                parent[tn[t].right] = t;
+            }
+        }
+    }
+    void refit_up(int32_t t)
+    {
+        for (; t >= 0; t = parent[t]) {
+            const Aabb nb = merged(tn[tn[t].left].box, tn[tn[t].right].box);
+            if (std::memcmp(&nb, &tn[t].box, sizeof(Aabb)) == 0) {
+                break;
+            }
+            tn[t].box = nb;
+            area[t] = half_area(nb);
+        }
+    }
+    static bool worse(const Cand &a, const Cand &b) { return a.induced != b.induced ? a.induced > b.induced : a.node > b.node; }
+    int32_t best_place(int32_t x)
+    {
+        const Aabb &xb = tn[x].box;
+        const float ax = area[x];
+        float best_cost = std::numeric_limits<float>::infinity();
+        int32_t best = root;
+        heap.clear();
+        heap.push_back(Cand{0.f, root});
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            const Cand c = heap.back();
+            heap.pop_back();
+            if (c.induced + ax >= best_cost) {
+                break; // every remaining candidate has at least this much induced cost
+            }
+            const float direct = half_area(merged(tn[c.node].box, xb));
+            const float total = c.induced + direct;
+            if (total < best_cost || (total == best_cost && c.node < best)) {
+                best_cost = total;
+                best = c.node;
+            }
+            const float below = total - area[c.node]; // what every place under this node pays for growing it
+            if (tn[c.node].left >= 0 && below + ax < best_cost) {
+                heap.push_back(Cand{below, tn[c.node].left});
+                std::push_heap(heap.begin(), heap.end(), worse);
+                heap.push_back(Cand{below, tn[c.node].right});
+                std::push_heap(heap.begin(), heap.end(), worse);
+            }
+        }
+        return best;
+    }
+    // returns whether the subtree moved
+    bool reinsert(int32_t x)
+    {
+        const int32_t p = parent[x];
+        if (p < 0 || parent[p] < 0) {
+            return false; // the root and its children stay
+        }
+        const int32_t g = parent[p];
+        const int32_t s = tn[p].left == x ? tn[p].right : tn[p].left;
+        (tn[g].left == p ? tn[g].left : tn[g].right) = s;
+        parent[s] = g;
+        refit_up(g);
+        const int32_t y = best_place(x);
+        const int32_t py = parent[y];
+        tn[p].left = y;
+        tn[p].right = x;
+        parent[y] = p;
+        parent[x] = p;
+        parent[p] = py;
+        tn[p].box = merged(tn[y].box, tn[x].box);
+        area[p] = half_area(tn[p].box);
+        if (py < 0) {
+            root = p;
+        } else {
+            (tn[py].left == y ? tn[py].left : tn[py].right) = p;
+            refit_up(py);
+        }
+        return y != s;
+    }
+    double inner_area() const
+    {
+        double sum = 0.0;
+        for (size_t t = 0; t < parent.size(); ++t) {
+            if (tn[t].left >= 0) {
+                sum += area[t];
+            }
+        }
+        return sum;
+    }
+};
+
+// `passes` sweeps over all subtrees, largest first; then the collapse table (TNode::slot_cost) is rebuilt bottom-up.
+int32_t optimise_by_reinsertion(Builder &b, int32_t root, int32_t n_nodes, int passes, bool verbose)
+{
+    Reinserter r;
+    r.tn = b.tn.get();
+    r.root = root;
+    r.index(n_nodes);
+    std::vector<int32_t> todo(n_nodes);
+    for (int pass = 0; pass < passes; ++pass) {
+        const double before = r.inner_area();
+        for (int32_t t = 0; t < n_nodes; ++t) {
+            todo[t] = t;
+        }
+        std::sort(todo.begin(), todo.end(), [&](int32_t x, int32_t y) { return r.area[x] != r.area[y] ? r.area[x] > r.area[y] : x < y; });
+        size_t moved = 0;
+        const double top = std::getenv("CRT_BVH_REINSERT_TOP") ? std::atof(std::getenv("CRT_BVH_REINSERT_TOP")) : 1.0;
+        const size_t n_todo = (size_t)std::min((double)n_nodes, std::max(1.0, top * n_nodes));
+        for (size_t i = 0; i < n_todo; ++i) {
+            moved += r.reinsert(todo[i]) ? 1 : 0;
+        }
+        if (verbose) {
+            std::fprintf(stderr, "[crt_hip]   reinsertion pass %d: %zu of %d subtrees moved, summed inner area %.4g -> %.4g (%.1f %%)\n", pass,
+                         moved, n_nodes, before, r.inner_area(), 100.0 * (r.inner_area() / before - 1.0));
+        }
+        if (moved == 0) {
+            break;
+        }
+    }
+    std::vector<int32_t> stack{r.root}, post;
+    post.reserve(n_nodes / 2 + 1);
+    while (!stack.empty()) {
+        const int32_t t = stack.back();
+        stack.pop_back();
+        if (b.tn[t].left >= 0) {
+            post.push_back(t);
+            stack.push_back(b.tn[t].left);
+            stack.push_back(b.tn[t].right);
+        }
+    }
+    for (size_t i = post.size(); i-- > 0;) { // parents come before their children in `post`
+        b.fill_slot_cost(post[i]);
+    }
+    return r.root;
+}
 
 inline int32_t leaf_ref(uint32_t first, uint32_t count) { return (int32_t)~((first << 3) | (count - 1u)); }
 
@@ -456,8 +624,16 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     b.tn.reset(new TNode[2 * n]);
     b.spare_threads = std::max(0, n_threads - 1);
     phase("setup");
-    const int32_t root = b.build(0, (uint32_t)n, 0);
+    int32_t root = b.build(0, (uint32_t)n, 0);
     phase("recursive build");
+    if (const char *e = std::getenv("CRT_BVH_REINSERT")) {
+        const int passes = std::atoi(e);
+        const int32_t n_nodes = b.next.load();
+        if (passes > 0 && n_nodes > 7) {
+            root = optimise_by_reinsertion(b, root, n_nodes, passes, dbg && n > 100000);
+            phase("reinsertion");
+        }
+    }
 
     BuiltBvh out;
     out.bounds = b.tn[root].box;

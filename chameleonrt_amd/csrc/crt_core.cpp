@@ -593,7 +593,7 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->stack_need = ps.stack_need;
 
     SceneView &sv = ctx->sv;
-    sv.nodes = ctx->d_nodes.as<QNode>();
+    sv.nodes = ctx->d_nodes.as<PNode>();
     sv.root_frame = ps.root_frame;
     sv.slots = ctx->d_slots.as<LeafSlot>();
     sv.tri_uvs = ctx->d_tri_uvs.as<float>();
@@ -1406,7 +1406,7 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
         }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (nodes) {
-            HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(QNode), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(nodes, ctx->d_nodes.ptr, ctx->n_nodes * sizeof(PNode), hipMemcpyDeviceToHost));
         }
         if (tris) {
             HIP_CHECK(hipMemcpy(tris, ctx->d_slots.ptr, ctx->n_tris * sizeof(LeafSlot), hipMemcpyDeviceToHost));

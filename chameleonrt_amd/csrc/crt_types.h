@@ -62,6 +62,77 @@ struct alignas(16) QNode {
 };
 static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 
+// The node as the TRAVERSAL KERNELS read it: the same four boxes and references in 48 bytes of a 64-byte record, fetched
+// with THREE dwordx4 per lane instead of four. tools/node_bytes_microbench.hip (profiles/r04_node_bytes_microbench.txt):
+// an incoherent 64-byte node visit costs the CU's vector-memory front end 2.77 cycles per lane, the 48 bytes of a
+// 64-byte-aligned record 2.06 -- the cost follows the number of 16-byte requests, and the front end is what binds the
+// traversal kernels. QNode stays the builders' output (host SAH, host and device LBVH, the world-tree
+// cut); scene_prepare.cpp packs every node once, at the end (pack_node below), and the packed form is what is uploaded,
+// saved, and copied out (crt_hip_bvh_copy).
+//
+// Per axis the node has an ORIGIN on the BVH's 16-bit grid (the smallest `lo` of its used children) and a SCALE
+// 2^e or 1.5 x 2^e grid units (five bits: e << 1 | m); a child's plane is origin + byte x scale: lo rounded down, hi
+// rounded up to a multiple of the scale, the scale the smallest of that sequence with which the farthest `hi` still
+// fits a byte. Boxes only ever grow (by less than one scale step, i.e. less than 1/170 of the node's extent), so the
+// conservative-box argument of QNode carries over; nodes no wider than 255 grid units -- every node near the leaves --
+// have scale 1 and exactly the boxes they had. An unused slot has lo = 255, hi = 0 (inverted for every ray direction,
+// slab.h) and a copy of slot 0's reference, as in QNode.
+struct alignas(16) PNode {
+    uint32_t frame[2];  // [0] = origin_x | origin_y << 16; [1] = origin_z | scale_x << 16 | scale_y << 21 | scale_z << 26
+    uint32_t lo_x, hi_x; // byte c = child c
+    uint32_t lo_y, hi_y, lo_z, hi_z;
+    int32_t ref[BVH_WIDTH];
+    uint32_t unused[4]; // (zero; never fetched by the kernels)
+};
+static_assert(sizeof(PNode) == 64, "PNode must be 64 bytes");
+// (the part of a PNode the kernels read: what the LDS copy of the top levels holds per node)
+struct alignas(16) PNodeHead {
+    uint32_t w[12];
+};
+
+CRT_TYPES_HD PNode pack_node(const QNode &q)
+{
+    PNode p;
+    uint32_t origin[3], scale[3], lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};
+    for (int a = 0; a < 3; ++a) {
+        uint32_t omin = 0xffffffffu, hmax = 0u;
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            if (q.child[c].q[0][0] <= q.child[c].q[0][1]) { // (an unused slot is inverted on every axis)
+                omin = q.child[c].q[a][0] < omin ? q.child[c].q[a][0] : omin;
+                hmax = q.child[c].q[a][1] > hmax ? q.child[c].q[a][1] : hmax;
+            }
+        }
+        if (omin == 0xffffffffu) {
+            omin = hmax = 0u; // no used child (the empty scene's node)
+        }
+        // twice the scale, so that 1.5 x 2^e stays an integer: 2, 3, 4, 6, 8, 12, ... = (2 + m) << e
+        uint32_t code = 0u, scale2 = 2u;
+        while ((2u * (hmax - omin) + scale2 - 1u) / scale2 > 255u) {
+            ++code;
+            scale2 = (2u + (code & 1u)) << (code >> 1);
+        }
+        origin[a] = omin;
+        scale[a] = code;
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            uint32_t l = 255u, h = 0u;
+            if (q.child[c].q[0][0] <= q.child[c].q[0][1]) {
+                l = 2u * (q.child[c].q[a][0] - omin) / scale2;
+                h = (2u * (q.child[c].q[a][1] - omin) + scale2 - 1u) / scale2;
+            }
+            lo[a] |= l << (8 * c);
+            hi[a] |= h << (8 * c);
+        }
+    }
+    p.frame[0] = origin[0] | origin[1] << 16;
+    p.frame[1] = origin[2] | scale[0] << 16 | scale[1] << 21 | scale[2] << 26;
+    p.lo_x = lo[0], p.hi_x = hi[0], p.lo_y = lo[1], p.hi_y = hi[1], p.lo_z = lo[2], p.hi_z = hi[2];
+    for (int c = 0; c < BVH_WIDTH; ++c) {
+        p.ref[c] = q.child[c].ref;
+        p.unused[c] = 0u;
+    }
+    return p;
+}
+
 // One LEAF of a BVH = one 64-byte slot = 4 x dwordx4 in ONE cache line: a triangle, or two triangles of one geometry
 // (and one instance) that share an edge -- a quad, Embree's own leaf form for triangle meshes -- stored as the four
 // distinct vertices in full precision plus the ids. A leaf visit is a dependent step that costs a line fill whatever
@@ -140,7 +211,7 @@ struct ViewParams {
 
 // Device pointers of the whole scene, passed to kernels by value.
 struct SceneView {
-    const QNode *nodes;
+    const PNode *nodes;
     const LeafSlot *slots;        // leaves: one or two triangles each (LeafSlot above)
     const InstanceRec *instances;
     const float *tri_uvs;         // TRI_UV_STRIDE floats per TRIANGLE index 2 * slot + which (uv of its three vertices, two of padding: 2 x dwordx4)

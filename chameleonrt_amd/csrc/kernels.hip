@@ -197,21 +197,22 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
 template <bool TWO_LEVEL, bool INST_TRIS = false> struct TraceLds {
-    QNode top[(TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : MAX_TOP_NODES) + 1];
+    PNodeHead top[(TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : MAX_TOP_NODES) + 1]; // 48 of a node's 64 bytes
     int32_t stack[lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
     // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
     // world tree: the ray in the object space of the instance whose triangle the lane tested last
     float cold[lds_cold_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
 };
 
-template <typename Lds> CRT_DEV const QNode *stage_top_nodes(const SceneView &sc, Lds &lds)
+template <typename Lds> CRT_DEV const PNodeHead *stage_top_nodes(const SceneView &sc, Lds &lds)
 {
-    // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step.
-    const uint32_t n = min(sc.n_top_nodes, (uint32_t)(sizeof(lds.top) / sizeof(QNode) - 1));
+    // Cooperative copy of the BFS-ordered top levels into LDS, 16 B per lane per step: the three quarters of each
+    // 64-byte record that the traversal reads.
+    const uint32_t n = min(sc.n_top_nodes, (uint32_t)(sizeof(lds.top) / sizeof(PNodeHead) - 1));
     const float4 *src = reinterpret_cast<const float4 *>(sc.nodes + sc.root);
     float4 *dst = reinterpret_cast<float4 *>(lds.top);
-    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x) {
-        dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < n * 3; i += blockDim.x) {
+        dst[i] = src[i + i / 3];
     }
     __syncthreads();
     return lds.top; // always the LDS array (so loads through it stay ds_read); holds min(n_top_nodes, MAX_TOP_NODES) nodes
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
                                                                PassCounters *pc, int bounce)
 {
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
-    const QNode *top = stage_top_nodes(sc, lds);
+    const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
-    const QNode *top = stage_top_nodes(sc, lds);
+    const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
                                                             unsigned long long *counters)
 {
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
-    const QNode *top = stage_top_nodes(sc, lds);
+    const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;

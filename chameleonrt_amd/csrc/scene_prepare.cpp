@@ -285,6 +285,7 @@ struct ScenePreparer {
     uint32_t n_top = 0;
     int32_t root = 0;
     QFrame root_frame{};
+    std::vector<QNode> qnodes; // the tree as the builders deliver it; packed into ps->nodes at the end (pack_nodes)
     const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
     std::chrono::high_resolution_clock::time_point t_phase = std::chrono::high_resolution_clock::now();
 
@@ -323,6 +324,7 @@ struct ScenePreparer {
             append_mesh_trees();
         }
         finish_references();
+        pack_nodes();
         phase("TLAS + quantisation");
         linearise_textures();
         copy_tables();
@@ -670,7 +672,7 @@ struct ScenePreparer {
 
     void build_world_tree()
     {
-        std::vector<QNode> &nodes = ps->nodes;
+        std::vector<QNode> &nodes = qnodes;
         std::vector<LeafSlot> &slots = ps->slots;
         std::vector<float> &tri_uvs = ps->tri_uvs;
         std::vector<InstanceRec> &insts = ps->insts;
@@ -850,7 +852,7 @@ struct ScenePreparer {
     // the top-level tree of a two-level scene (embree_utils.cpp:121-129), with the static instance grafted into it
     void build_top_level_tree()
     {
-        std::vector<QNode> &nodes = ps->nodes;
+        std::vector<QNode> &nodes = qnodes;
         if (two_level) {
             // items of the top-level tree: the cut through the grafted mesh's BLAS (if any), then one box per other instance
             std::vector<Aabb> items;
@@ -1028,7 +1030,7 @@ struct ScenePreparer {
         for (int k = 0; k < BVH_WIDTH; ++k) {
             q.child[k].ref = 0; // (never followed: no ray enters an inverted box)
         }
-        ps->nodes.assign(1, q);
+        qnodes.assign(1, q);
         root = 0;
         n_top = 1;
         blas_depth = 1;
@@ -1040,7 +1042,7 @@ struct ScenePreparer {
     // the meshes' trees behind the top-level nodes: references local to a mesh become global
     void append_mesh_trees()
     {
-        std::vector<QNode> &nodes = ps->nodes;
+        std::vector<QNode> &nodes = qnodes;
         for (uint32_t m = 0; m < s->n_meshes; ++m) {
             const int32_t node_base = (int32_t)nodes.size();
             const uint32_t tri_base = (uint32_t)blas_root[m];
@@ -1075,6 +1077,18 @@ struct ScenePreparer {
             built[m] = BuiltBvh();
             built_q[m] = std::vector<QNode>();
         }
+    }
+
+    // the kernels' 48-byte form of every node (crt_types.h PNode)
+    void pack_nodes()
+    {
+        ps->nodes.resize(qnodes.size());
+        parallel_for(qnodes.size(), n_threads, 1u << 14, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                ps->nodes[i] = pack_node(qnodes[i]);
+            }
+        });
+        qnodes = std::vector<QNode>();
     }
 
     void finish_references()
@@ -1248,7 +1262,7 @@ int fail_global(int code, const std::string &msg)
 // Flat serialisation of a prepared scene: header, then the arrays back to back. Meant for a tmpfs
 // path (/dev/shm) shared by the ranks of one node; same build, same machine -- not an exchange format.
 namespace {
-constexpr uint64_t PREP_MAGIC = 0x3530505250545243ull; // "CRTPRP05" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids; 05: 64-byte leaf slots)
+constexpr uint64_t PREP_MAGIC = 0x3630505250545243ull; // "CRTPRP06" (02: tiled texels; 03: grafted world instance; 04: textured flag on material ids; 05: 64-byte leaf slots; 06: packed nodes)
 struct PrepHeader {
     uint64_t magic, abi;
     uint64_t n_nodes, n_tris, n_insts, n_matids, n_materials, n_lights_f, n_tex, n_texels;
@@ -1340,7 +1354,7 @@ int crt_hip_prepared_scene_copy(const crt_hip_prepared_scene *ps, void *nodes, v
         return fail_global(CRT_HIP_EINVAL, "prepared scene is null");
     }
     if (nodes) {
-        std::memcpy(nodes, ps->nodes.data(), ps->nodes.size() * sizeof(QNode));
+        std::memcpy(nodes, ps->nodes.data(), ps->nodes.size() * sizeof(PNode));
     }
     if (tris) {
         std::memcpy(tris, ps->slots.data(), ps->slots.size() * sizeof(LeafSlot));
@@ -1426,7 +1440,7 @@ crt_hip_prepared_scene *crt_hip_load_prepared_scene(const char *path)
                 return refuse("counts");
             }
         }
-        const uint64_t expect = sizeof(h) + h.n_nodes * sizeof(QNode) + h.n_tris * sizeof(LeafSlot) + h.n_tris * 2 * TRI_UV_STRIDE * sizeof(float) +
+        const uint64_t expect = sizeof(h) + h.n_nodes * sizeof(PNode) + h.n_tris * sizeof(LeafSlot) + h.n_tris * 2 * TRI_UV_STRIDE * sizeof(float) +
                                 h.n_insts * sizeof(InstanceRec) + h.n_matids * 4 + h.n_materials * 4 + h.n_lights_f * 4 +
                                 h.n_tex * sizeof(TexRec) + h.n_texels;
         if (expect != file_size) {

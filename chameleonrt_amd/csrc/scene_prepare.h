@@ -9,7 +9,7 @@
 
 // What crt_hip_prepare_scene hands out (include/crt_hip.h): the arrays the kernels read, ready for upload.
 struct crt_hip_prepared_scene {
-    std::vector<crt::QNode> nodes;
+    std::vector<crt::PNode> nodes;    // packed 4-wide nodes (crt_types.h PNode)
     std::vector<crt::LeafSlot> slots; // the leaves: one or two triangles each (crt_types.h)
     std::vector<float> tri_uvs;      // TRI_UV_STRIDE per triangle index 2 * slot + which
     std::vector<crt::InstanceRec> insts;

@@ -1,15 +1,12 @@
-// slab.h — the ray / quantised-box test of the traversal kernels, written so that the SAME source
-// compiles for the device (hipcc) and for the host (g++: tests/native/slab_check.cpp checks it
+// slab.h — the ray / box test of the traversal kernels against a packed 4-wide node (crt_types.h PNode), written so
+// that the SAME source compiles for the device (hipcc) and for the host (g++: tests/native/slab_check.cpp checks it
 // against the plain min/max formulation; the oracle's BVH walker mirrors the visit rule).
 //
-// A child's box is three dwords, one per axis: lo | hi << 16 in quanta of the BVH's QFrame. A plane
-// at coordinate q has ray parameter t(q) = fma(q, qa, qb) with qa = step/d, qb = (base - o)/d
-// (|d| clamped to >= 1e-18, sign kept). t(q) is monotone in q with the sign of qa, so the entry
-// plane of an axis is `lo` if d > 0 and `hi` if d < 0: instead of computing both parameters and
-// taking min / max (6 + 6 instructions per child), the dword is ROTATED by 0 or 16 bits (per ray
-// and axis, from the sign of d) so that the entry plane sits in the low half, and near / far are
-// read from fixed halves: 3 rotates per child, and the values are bit-identical to the min / max
-// form. A box stored inverted (lo > hi) has near > far for every direction, so unused child slots
+// The ray in the fixed-point frame of a BVH (QFrame: coordinate = base + q * step) is t(q) = fma(q, qa, qb) with
+// qa = step/d, qb = (base - o)/d (|d| clamped to >= 1e-18, sign kept). t is monotone in q with the sign of qa, so the
+// entry plane of an axis is `lo` if d > 0 and `hi` if d < 0: instead of computing both parameters and taking min / max,
+// the near and far plane words of an axis are SELECTED once per node from the sign of qa (the values are bit-identical
+// to the min / max form). A box stored inverted (lo > hi) has near > far for every direction, so unused child slots
 // need no separate test.
 #pragma once
 #include <stdint.h>
@@ -24,38 +21,65 @@ namespace crt {
 
 struct SlabRay {
     float qa[3], qb[3];  // t(q) = fma(q, qa, qb) per axis
-    // (the rotate count of an axis -- 0 if qa >= 0: entry plane = lo; 16 if qa < 0: entry plane = hi -- is derived from
-    // qa's sign where it is used: three registers less to keep alive across the leaf steps of the traversal kernels)
 };
-
-CRT_SLAB_FN uint32_t slab_rotr(uint32_t w, uint32_t sh) { return (w >> sh) | (w << ((32u - sh) & 31u)); }
 
 // bit pattern of a float / sign test without <cmath> or device headers
 CRT_SLAB_FN uint32_t slab_bits(float x) { return __builtin_bit_cast(uint32_t, x); }
 
-// rot for an axis whose plane parameter scales with qa
-CRT_SLAB_FN uint32_t slab_rot_of(float qa) { return (slab_bits(qa) >> 31) << 4; }
+// ---- the packed node (crt_types.h PNode): byte planes on a per-node origin and shift ----------------------------------
+// A plane byte b of an axis stands for grid coordinate origin + b * scale (scale = 2^e or 1.5 * 2^e, a float with one
+// mantissa bit), whose ray parameter fma(origin + b*scale, qa, qb) is evaluated in steps that cost one conversion and one
+// fma per plane: a = fma(origin, qa, qb) and s = qa * scale once per node and axis, then t(b) = fma(b, s, a). Against the
+// one-step form this rounds three times; the extra roundings are at most half an ulp of a, with |a| <= |t| + 255 |s|,
+// and 255 half ulps of s: together below 2^-14 of a grid unit's parameter span on top of the half ulp of t every box
+// test has -- the builders' one-unit outward rounding (crt_types.h QNode) covers it.
+// The near planes of an axis are the `lo` bytes if qa >= 0 and the `hi` bytes otherwise (one select per node and axis
+// instead of a rotate per child); an unused slot (lo = 255, hi = 0) is inverted for both signs.
+struct SlabAxis {
+    float a, s;
+    uint32_t near, far; // byte c = child c
+};
 
-// Entry distance of the ray into the child box {wx, wy, wz} clamped to tmin, and whether the ray
-// enters it within [tmin, tmax] (exit widened by 2 ulp, like every box test of this path tracer).
-CRT_SLAB_FN bool slab_enter(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay &r, float tmin, float tmax, float &tn)
+// scale: the five-bit code e << 1 | m of crt_types.h PNode
+CRT_SLAB_FN SlabAxis slab_axis(uint32_t origin, uint32_t scale, uint32_t lo, uint32_t hi, float qa, float qb)
 {
-    const uint32_t rx = slab_rotr(wx, slab_rot_of(r.qa[0])), ry = slab_rotr(wy, slab_rot_of(r.qa[1])), rz = slab_rotr(wz, slab_rot_of(r.qa[2]));
-    const float nx = __builtin_fmaf((float)(rx & 0xffffu), r.qa[0], r.qb[0]), fx = __builtin_fmaf((float)(rx >> 16), r.qa[0], r.qb[0]);
-    const float ny = __builtin_fmaf((float)(ry & 0xffffu), r.qa[1], r.qb[1]), fy = __builtin_fmaf((float)(ry >> 16), r.qa[1], r.qb[1]);
-    const float nz = __builtin_fmaf((float)(rz & 0xffffu), r.qa[2], r.qb[2]), fz = __builtin_fmaf((float)(rz >> 16), r.qa[2], r.qb[2]);
-    tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin));
-    const float tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax));
-    return tn <= tf * 1.0000004f;
+    SlabAxis x;
+    x.a = __builtin_fmaf((float)origin, qa, qb);
+    x.s = qa * __builtin_bit_cast(float, (127u << 23) + (scale << 22));
+    const bool neg = (slab_bits(qa) >> 31) != 0u;
+    x.near = neg ? hi : lo;
+    x.far = neg ? lo : hi;
+    return x;
 }
 
-// Sort key of a child (inner-node phase of trace_wavefront): entry distance bits with the slot in
-// the two lowest, or all-ones if the ray does not enter the box.
-CRT_SLAB_FN uint32_t slab_child_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t slot, const SlabRay &r, float tmin,
-                                    float tmax)
+struct SlabNode {
+    SlabAxis x, y, z;
+};
+
+// w[0..7]: the first eight dwords of a PNode
+CRT_SLAB_FN SlabNode slab_node(uint32_t f0, uint32_t f1, uint32_t lo_x, uint32_t hi_x, uint32_t lo_y, uint32_t hi_y, uint32_t lo_z,
+                               uint32_t hi_z, const SlabRay &r)
 {
-    float tn;
-    return slab_enter(wx, wy, wz, r, tmin, tmax, tn) ? ((slab_bits(tn) & 0x7ffffffcu) | slot) : 0xffffffffu;
+    SlabNode n;
+    n.x = slab_axis(f0 & 0xffffu, (f1 >> 16) & 31u, lo_x, hi_x, r.qa[0], r.qb[0]);
+    n.y = slab_axis(f0 >> 16, (f1 >> 21) & 31u, lo_y, hi_y, r.qa[1], r.qb[1]);
+    n.z = slab_axis(f1 & 0xffffu, f1 >> 26, lo_z, hi_z, r.qa[2], r.qb[2]);
+    return n;
+}
+
+template <int C> CRT_SLAB_FN float slab_byte(uint32_t w) { return (float)((w >> (8 * C)) & 0xffu); }
+
+// Sort key of child C (inner-node phase of trace_wavefront): the entry distance into its box clamped to tmin (exit widened
+// by 2 ulp, like every box test of this path tracer), as bits, with the slot in the two lowest; all-ones if the ray does
+// not enter the box within [tmin, tmax].
+template <int C> CRT_SLAB_FN uint32_t slab_packed_key(const SlabNode &n, float tmin, float tmax)
+{
+    const float nx = __builtin_fmaf(slab_byte<C>(n.x.near), n.x.s, n.x.a), fx = __builtin_fmaf(slab_byte<C>(n.x.far), n.x.s, n.x.a);
+    const float ny = __builtin_fmaf(slab_byte<C>(n.y.near), n.y.s, n.y.a), fy = __builtin_fmaf(slab_byte<C>(n.y.far), n.y.s, n.y.a);
+    const float nz = __builtin_fmaf(slab_byte<C>(n.z.near), n.z.s, n.z.a), fz = __builtin_fmaf(slab_byte<C>(n.z.far), n.z.s, n.z.a);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin));
+    const float tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax));
+    return tn <= tf * 1.0000004f ? ((slab_bits(tn) & 0x7ffffffcu) | (uint32_t)C) : 0xffffffffu;
 }
 
 } // namespace crt

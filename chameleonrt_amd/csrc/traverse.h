@@ -20,19 +20,20 @@ namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
 // vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 19 for the single-level kernels (26 KB per block; 16 -> 19: C4F -2.2 %, C3 -2 % frame time),
+// budget of 6 blocks per CU allows: 21 for the single-level kernels (26 KB per block; 16 -> 19: C4F -2.2 %, C3 -2 % frame time;
+// 19 -> 21 came with the 48-byte LDS copies of the top nodes),
 // 16 for the two-level ones,
 // which also keep 9 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 19
+#define CRT_LDS_STACK 21
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
 #define CRT_LDS_STACK_TWO_LEVEL 16
 #endif
 // the kernels of a world tree (INST_TRIS below) keep the world-space ray in LDS next to the stack, like the two-level
-// ones: six dwords per lane, paid for with two stack entries (26 KB per block)
+// ones: six dwords per lane, paid for with five stack entries (26 KB per block)
 #ifndef CRT_LDS_STACK_WORLD_TREE
-#define CRT_LDS_STACK_WORLD_TREE 14
+#define CRT_LDS_STACK_WORLD_TREE 16
 #endif
 // levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
 constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
@@ -100,10 +101,6 @@ CRT_DEV float box_dir(float x) { return fabsf(x) < 1e-18f ? copysignf(1e-18f, x)
 
 // The ray / quantised-box test lives in slab.h (shared with the host-side check).
 typedef uint32_t tv_u4 __attribute__((ext_vector_type(4))); // plain vector: loadable from any address space
-CRT_DEV uint32_t child_key(const tv_u4 k, uint32_t slot, const SlabRay &sr, float tmin, float tmax)
-{
-    return slab_child_key(k.x, k.y, k.z, slot, sr, tmin, tmax);
-}
 
 // (a, b, c): the triangle's vertices in its index order. e1 = v0 - v1, e2 = v2 - v0 are formed here from
 // the leaf slot's vertices -- the IEEE subtractions the host made for the 48-byte records of rounds 1-2, so every bit of
@@ -240,7 +237,7 @@ CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 // the ray transformed into that instance's object space (same expressions as the two-level entry, so the same bits),
 // which the lane keeps until a triangle of another instance comes along.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source, bool INST_TRIS = false>
-CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> &st, uint32_t n,
+CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris, uint32_t &n_slots,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
@@ -510,20 +507,18 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
             } else if (inner) {
-                // one 16-byte quarter per child: {x: lo|hi, y: lo|hi, z: lo|hi, ref}
-                tv_u4 k0, k1, k2, k3;
+                // three of the record's four 16-byte quarters (crt_types.h PNode): frame + x planes, y and z planes, references
+                tv_u4 k0, k1, k2;
                 if ((TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : CRT_MAX_TOP_NODES) > 0 && cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
                     const TV_LDS tv_u4 *p = (const TV_LDS tv_u4 *)(top + (cur - top_lo));
                     k0 = p[0];
                     k1 = p[1];
                     k2 = p[2];
-                    k3 = p[3];
                 } else {
                     const TV_HBM tv_u4 *p = (const TV_HBM tv_u4 *)(sc.nodes + cur);
                     k0 = p[0];
                     k1 = p[1];
                     k2 = p[2];
-                    k3 = p[3];
                 }
                 if (COUNTERS) {
                     ++n_nodes;
@@ -534,17 +529,18 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                 // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
                 // the slot makes keys distinct and breaks ties towards the lower slot); children
                 // that are missed, or unused slots, get the all-ones key.
-                const uint32_t s0 = child_key(k0, 0u, sr, tnear, hit.t);
-                const uint32_t s1 = child_key(k1, 1u, sr, tnear, hit.t);
-                const uint32_t s2 = child_key(k2, 2u, sr, tnear, hit.t);
-                const uint32_t s3 = child_key(k3, 3u, sr, tnear, hit.t);
+                const SlabNode sn = slab_node(k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, sr);
+                const uint32_t s0 = slab_packed_key<0>(sn, tnear, hit.t);
+                const uint32_t s1 = slab_packed_key<1>(sn, tnear, hit.t);
+                const uint32_t s2 = slab_packed_key<2>(sn, tnear, hit.t);
+                const uint32_t s3 = slab_packed_key<3>(sn, tnear, hit.t);
                 // 5-comparator sorting network
                 const uint32_t a0 = min(s0, s1), a1 = max(s0, s1), a2 = min(s2, s3), a3 = max(s2, s3);
                 const uint32_t b0 = min(a0, a2), b2 = max(a0, a2), b1 = min(a1, a3), b3 = max(a1, a3);
                 const uint32_t c1 = min(b1, b2), c2 = max(b1, b2);
                 auto ref_of = [&](uint32_t key) -> int32_t {
                     const uint32_t slot = key & 3u;
-                    return (int32_t)(slot == 0u ? k0.w : slot == 1u ? k1.w : slot == 2u ? k2.w : k3.w);
+                    return (int32_t)(slot == 0u ? k2.x : slot == 1u ? k2.y : slot == 2u ? k2.z : k2.w);
                 };
                 if (ANY_HIT && !CRT_ANYHIT_SORT) {
                     // occlusion rays: any order finds the same answer; lowest used slot first
@@ -554,15 +550,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                     } else {
                         const int first = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
                         if (h3 && first < 3) {
-                            st.push((int32_t)k3.w);
-                        }
-                        if (h2 && first < 2) {
                             st.push((int32_t)k2.w);
                         }
-                        if (h1 && first < 1) {
-                            st.push((int32_t)k1.w);
+                        if (h2 && first < 2) {
+                            st.push((int32_t)k2.z);
                         }
-                        cur = (int32_t)(first == 0 ? k0.w : first == 1 ? k1.w : first == 2 ? k2.w : k3.w);
+                        if (h1 && first < 1) {
+                            st.push((int32_t)k2.y);
+                        }
+                        cur = (int32_t)(first == 0 ? k2.x : first == 1 ? k2.y : first == 2 ? k2.z : k2.w);
                     }
                 } else if (CRT_CHILD_ORDER == 1) {
                     // nearest child first, the other entered children stacked in slot order: no sort
@@ -572,16 +568,16 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const QNode *top, TraversalSta
                         pop_next();
                     } else {
                         if (s3 != 0xffffffffu && s3 != nearest) {
-                            st.push((int32_t)k3.w);
-                        }
-                        if (s2 != 0xffffffffu && s2 != nearest) {
                             st.push((int32_t)k2.w);
                         }
+                        if (s2 != 0xffffffffu && s2 != nearest) {
+                            st.push((int32_t)k2.z);
+                        }
                         if (s1 != 0xffffffffu && s1 != nearest) {
-                            st.push((int32_t)k1.w);
+                            st.push((int32_t)k2.y);
                         }
                         if (s0 != 0xffffffffu && s0 != nearest) {
-                            st.push((int32_t)k0.w);
+                            st.push((int32_t)k2.x);
                         }
                         cur = ref_of(nearest);
                     }

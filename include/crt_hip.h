@@ -297,7 +297,8 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
                 float *out, int out_stride);
 
 /* BVH introspection for tests: copy out the traversal arrays the kernels use. Nodes are
- * 64-byte quantised 4-wide records, leaves 64-byte slots of one or two triangles -- n_tris counts SLOTS
+ * 64-byte packed 4-wide records (48 bytes used: per-axis origin and scale on the BVH's 16-bit grid, one byte per
+ * child plane, four references), leaves 64-byte slots of one or two triangles -- n_tris counts SLOTS
  * (DESIGN.md "Data layout in HBM");
  * root_frame receives the 6 floats {base.xyz, step.xyz} of the root BVH's fixed-point frame. */
 int crt_hip_bvh_info(crt_hip_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tris,

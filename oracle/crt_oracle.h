@@ -85,7 +85,7 @@ int orc_intersect1(const orc_scene *s, const float org[3], const float dir[3], f
                    float *t, float *u, float *v, int32_t *inst, int32_t *geom, int32_t *prim);
 int orc_occluded1(const orc_scene *s, const float org[3], const float dir[3], float tnear, float tfar);
 
-/* Walk a FOREIGN BVH (the product's 64-byte quantised 4-wide nodes + frames / 64-byte leaf slots of 1-2 triangles /
+/* Walk a FOREIGN BVH (the product's 64-byte packed 4-wide nodes + frames / 64-byte leaf slots of 1-2 triangles /
  * 128-byte instance records) with the product's documented visit rule (child_order =
  * the product's CRT_CHILD_ORDER build setting): counts nodes fetched / triangles tested, to
  * cross-check the HIP kernels' CRT_HIP_FLAG_COUNTERS numbers (the roofline input), reports the

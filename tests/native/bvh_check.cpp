@@ -159,6 +159,45 @@ int main(int argc, char **argv)
             }
         }
     }
+    // the kernels' packed form of the same nodes (crt_types.h pack_node): planes at origin + byte * scale, in doubled grid
+    // units here so that the 1.5 * 2^e scales stay integers
+    size_t pack_errors = 0, exact_nodes = 0;
+    for (const BvhNode &nd : b.nodes) {
+        const QNode q = quantise(nd, f);
+        const PNode p = pack_node(q);
+        const uint32_t origin[3] = {p.frame[0] & 0xffffu, p.frame[0] >> 16, p.frame[1] & 0xffffu};
+        const uint32_t code[3] = {(p.frame[1] >> 16) & 31u, (p.frame[1] >> 21) & 31u, p.frame[1] >> 26};
+        const uint32_t lo_w[3] = {p.lo_x, p.lo_y, p.lo_z}, hi_w[3] = {p.hi_x, p.hi_y, p.hi_z};
+        bool exact = true;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t scale2 = (2u + (code[k] & 1u)) << (code[k] >> 1);
+            uint32_t far2 = 0u;
+            for (int c = 0; c < BVH_WIDTH; ++c) {
+                const uint32_t l = (lo_w[k] >> (8 * c)) & 255u, h = (hi_w[k] >> (8 * c)) & 255u;
+                if (nd.c[c] == EMPTY_CHILD) {
+                    pack_errors += !(l == 255u && h == 0u);
+                    continue;
+                }
+                const uint32_t ql2 = 2u * q.child[c].q[k][0], qh2 = 2u * q.child[c].q[k][1];
+                const uint32_t dl2 = 2u * origin[k] + l * scale2, dh2 = 2u * origin[k] + h * scale2;
+                pack_errors += !(dl2 <= ql2 && ql2 - dl2 < scale2); // rounded down, by less than one step
+                pack_errors += !(dh2 >= qh2 && dh2 - qh2 < scale2); // rounded up, by less than one step
+                exact = exact && dl2 == ql2 && dh2 == qh2;
+                far2 = qh2 - 2u * origin[k] > far2 ? qh2 - 2u * origin[k] : far2;
+                pack_errors += origin[k] > q.child[c].q[k][0];
+            }
+            if (code[k] > 0u) { // the smallest scale that fits: the next smaller one would need a byte above 255
+                const uint32_t smaller = (2u + ((code[k] - 1u) & 1u)) << ((code[k] - 1u) >> 1);
+                pack_errors += !((far2 + smaller - 1u) / smaller > 255u);
+            }
+        }
+        for (int c = 0; c < BVH_WIDTH; ++c) {
+            pack_errors += p.ref[c] != q.child[c].ref;
+            pack_errors += p.unused[c] != 0u;
+        }
+        exact_nodes += exact;
+    }
+    errors += pack_errors;
     // expected node visits of a random ray that hits the root box: sum of the nodes' surface areas over the root's
     double sah_nodes = 0.0, root_area = 0.0;
     for (size_t i = 0; i < b.nodes.size(); ++i) {
@@ -177,6 +216,7 @@ int main(int argc, char **argv)
         sah_nodes += area;
     }
     std::printf("sah_nodes %.3f (builder: %.3f) ", root_area > 0 ? sah_nodes / root_area : 0.0, b.collapse_cost);
+    std::printf("packed_exact %zu ", exact_nodes);
     std::printf("items %zu nodes %zu fill %.2f depth %u top %u errors %d mean_slack_quanta %.3f over_3_quanta %zu\n", n,
                 b.nodes.size(), b.nodes.empty() ? 0.0 : (double)slots / (BVH_WIDTH * b.nodes.size()), b.max_depth, b.n_top,
                 errors, planes ? slack / planes / f.step[0] : 0.0, inflated);

@@ -18,6 +18,35 @@ def slot_triangles(bvh):
     return 1 + (bvh["tris"][:, 14].view(np.uint32) != 0xffffffff).astype(np.int64)
 
 
+def node_refs(nodes):
+    """(n, 4) child references of the packed 4-wide nodes (crt_types.h PNode: dwords 8..11 of the 64-byte record)."""
+    return nodes[:, 8:12].astype(np.uint32).view(np.int32)
+
+
+def node_boxes(nodes):
+    """(n, 4, 3, 2) child boxes in units of the BVH's 16-bit grid: PNode dwords 0..1 hold the per-axis origin and scale
+    (code e << 1 | m: 2^e or 1.5 * 2^e), dwords 2..7 the lo / hi plane bytes (byte c = child c); an unused slot is
+    inverted (lo = 255 > hi = 0)."""
+    n = nodes.shape[0]
+    f0, f1 = nodes[:, 0].astype(np.int64), nodes[:, 1].astype(np.int64)
+    origin = np.stack([f0 & 0xffff, f0 >> 16, f1 & 0xffff], axis=1).astype(np.float64)
+    code = np.stack([(f1 >> 16) & 31, (f1 >> 21) & 31, f1 >> 26], axis=1)
+    scale = np.where(code & 1, 1.5, 1.0) * 2.0 ** (code >> 1)
+    out = np.zeros((n, 4, 3, 2), np.float64)
+    for a in range(3):
+        for side in range(2):
+            w = nodes[:, 2 + 2 * a + side].astype(np.int64)
+            for c in range(4):
+                out[:, c, a, side] = origin[:, a] + ((w >> (8 * c)) & 255) * scale[:, a]
+    return out
+
+
+def node_used(nodes):
+    """(n, 4) which child slots are in use"""
+    lo, hi = nodes[:, 2].astype(np.int64), nodes[:, 3].astype(np.int64)
+    return np.stack([((lo >> (8 * c)) & 255) <= ((hi >> (8 * c)) & 255) for c in range(4)], axis=1)
+
+
 def probe_rays(scene, n, seed=0, spread=0.3):
     """Half camera-cone rays, half uniformly random directions from points around the scene."""
     rng = np.random.default_rng(seed)

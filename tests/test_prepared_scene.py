@@ -16,7 +16,7 @@ import pytest
 from chameleonrt_amd import core, scenes
 from chameleonrt_amd.render_hip import PreparedScene
 from chameleonrt_amd.scene import PackedScene
-from tests.parity import awkward_instances, probe_rays, slot_triangles
+from tests.parity import awkward_instances, node_refs, node_used, probe_rays, slot_triangles
 
 SCENES = {
     "cornell": lambda: scenes.cornell(),
@@ -117,7 +117,7 @@ def test_world_tree_of_an_instanced_scene(name, oracle, monkeypatch):
     ident = np.array([np.array_equal(np.asarray(it.transform, np.float32).reshape(4, 4), np.eye(4, dtype=np.float32))
                       for it in sc.instances])
     assert np.array_equal((tag & 1).astype(bool), ident[tag >> 1])
-    refs = bvh["nodes"].reshape(-1, 4, 4)[:, :, 3].astype(np.uint32).view(np.int32)
+    refs = node_refs(bvh["nodes"])
     leaves = refs[refs < 0]
     assert ((~leaves & 7) <= 3).all(), "leaves of at most CRT_BVH_MAX_LEAF slots"
     o = oracle.OracleScene(sc)
@@ -251,9 +251,8 @@ def test_static_instance_is_grafted_into_the_top_level_tree(name, oracle, monkey
     # (the top-level tree over read-back boxes, which are a quantum wider, may decide a split differently)
     assert via_q["world_inst"] == 0 and abs(via_q["nodes"].shape[0] - bvh["nodes"].shape[0]) <= 0.01 * bvh["nodes"].shape[0]
     assert plain["world_inst"] == -1 and bvh["world_inst"] == 0 and bvh["two_level"]
-    nodes = bvh["nodes"].reshape(-1, 4, 4)
-    refs = nodes[:, :, 3].astype(np.uint32).view(np.int32)
-    used = (nodes[:, :, 0] & 0xFFFF) <= (nodes[:, :, 0] >> 16)
+    refs = node_refs(bvh["nodes"])
+    used = node_used(bvh["nodes"])
     # walk the top level: everything reachable from the root without passing an instance leaf
     seen_inst, stack, top_tri_leaves, visited = set(), [bvh["root"]], 0, set()
     while stack:

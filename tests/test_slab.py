@@ -1,9 +1,10 @@
-"""CPU: the ray / quantised-box test of the traversal kernels (chameleonrt_amd/csrc/slab.h) is one
+"""CPU: the ray / packed-node box test of the traversal kernels (chameleonrt_amd/csrc/slab.h) is one
 source compiled for the device and for the host. The host build is checked here, bit for bit, against
 the plain formulation the oracle's BVH walker uses: both plane parameters per axis and min / max,
-unused child slots skipped explicitly (tests/native/slab_check.cpp) -- millions of random boxes and
-rays including exactly-zero direction components of both signs, origins far outside the frame, flat
-boxes, clipped intervals, and the inverted boxes that mark unused slots."""
+unused child slots skipped explicitly (tests/native/slab_check.cpp) -- on nodes packed by the product's
+own packer from random 16-bit boxes of every scale, with rays including exactly-zero direction components
+of both signs, origins far outside the frame, flat boxes, clipped intervals, and the inverted boxes that
+mark unused slots; and packing never narrows a box (a ray that enters the builders' box enters the packed one)."""
 import os
 import subprocess
 
@@ -15,6 +16,8 @@ def test_slab_header_matches_the_min_max_formulation(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I",
                            os.path.join(ROOT, "chameleonrt_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "slab_check.cpp"), "-o", exe])
-    p = subprocess.run([exe, "1500000"], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe, "600000"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "errors 0" in p.stdout and "inverted boxes entered 0" in p.stdout
+    # (an unused slot spans 255 steps of its node's scale; a ray whose origin is ~10^6 node sizes away cannot tell its two planes apart
+    # and "enters" it -- counted, checked to be exactly that case, and harmless: the slot holds a copy of slot 0's reference)
+    assert "errors 0" in p.stdout and "narrowed 0" in p.stdout
