@@ -16,8 +16,13 @@ LIB = os.path.join(HERE, "libcrt_hip_core.so")
 SOURCES = ["kernels.hip", "crt_core.cpp", "scene_prepare.cpp", "bvh_builder.cpp", "bvh_device.hip"]
 HEADERS = ["crt_types.h", "pt_device.h", "traverse.h", "slab.h", "wavefront.h", "kernels.h", "scene_prepare.h", "host_parallel.h", "bvh_builder.h", "bvh_device.h", "lbvh.h", "leaf_slots.h", "presplit.h",
            os.path.join("..", "..", "include", "crt_hip.h"), os.path.join("..", "..", "include", "crt_kat.h")]
+# -fno-slp-vectorize: the SLP vectoriser pairs fp32 operations into gfx950's packed instructions (v_pk_fma_f32, v_pk_mul_f32,
+# v_pk_add_f32: ~3 800 of them in these kernels). They compute the same bits, but they need aligned register pairs -- the
+# traversal kernels took 80 VGPRs with them and take 65-72 without, which is the difference between 6 and 7 waves per SIMD --
+# and they are no faster here: C4 60.6 -> 58.1 ms with the flag alone, 56.9 ms with the seventh wave
+# (profiles/r04_issue_bound_ab.txt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function", "-x", "hip"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-pthread", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
 def _stale():
@@ -34,7 +39,8 @@ def build(force=False, verbose=False, defines=(), out=None):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = out or LIB
-    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    extra = [d if d.startswith("-") else "-D" + d for d in defines]  # (a variant may also name a raw compiler flag)
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

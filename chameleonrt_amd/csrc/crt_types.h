@@ -77,6 +77,12 @@ static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 // conservative-box argument of QNode carries over; nodes no wider than 255 grid units -- every node near the leaves --
 // have scale 1 and exactly the boxes they had. An unused slot has lo = 255, hi = 0 (inverted for every ray direction,
 // slab.h) and a copy of slot 0's reference, as in QNode.
+// (The format has room for half steps -- scales 1.5 x 2^e, the m bit of the code -- which make the boxes of C2 / C3 / C4
+// 0.5 / 0.7 / 0.3 % tighter in node visits; the kernels then need a multiply by a constructed float per axis instead of one
+// ldexp, and that costs more than the visits save: C4 56.7 against 55.8 ms, profiles/r04_issue_bound_ab.txt. Off.)
+#ifndef CRT_PNODE_HALF_STEPS
+#define CRT_PNODE_HALF_STEPS 0
+#endif
 struct alignas(16) PNode {
     uint32_t frame[2];  // [0] = origin_x | origin_y << 16; [1] = origin_z | scale_x << 16 | scale_y << 21 | scale_z << 26
     uint32_t lo_x, hi_x; // byte c = child c
@@ -106,9 +112,10 @@ CRT_TYPES_HD PNode pack_node(const QNode &q)
             omin = hmax = 0u; // no used child (the empty scene's node)
         }
         // twice the scale, so that 1.5 x 2^e stays an integer: 2, 3, 4, 6, 8, 12, ... = (2 + m) << e
+        // (CRT_PNODE_HALF_STEPS = 0: powers of two only -- the kernels then scale with one ldexp)
         uint32_t code = 0u, scale2 = 2u;
         while ((2u * (hmax - omin) + scale2 - 1u) / scale2 > 255u) {
-            ++code;
+            code += CRT_PNODE_HALF_STEPS ? 1u : 2u;
             scale2 = (2u + (code & 1u)) << (code >> 1);
         }
         origin[a] = omin;

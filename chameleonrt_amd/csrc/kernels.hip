@@ -34,17 +34,18 @@ namespace crt {
 #define CRT_TRACE_BLOCK 256
 #endif
 #ifndef CRT_TRACE_BLOCKS_PER_CU
-#define CRT_TRACE_BLOCKS_PER_CU 6
+#define CRT_TRACE_BLOCKS_PER_CU 7
 #endif
 // waves per SIMD the register allocator must leave room for in the traversal kernels (= blocks per CU
-// for 256-thread blocks). 6: every variant fits 80 VGPRs without scratch (the two-level closest-hit
-// kernel would otherwise take 82 and run 5 waves). Forcing 7 makes the allocator spill, and a
-// scratch-backed kernel loses far more than the seventh wave buys (measured: C4 +19 % frame time).
+// for 256-thread blocks). 7 = 72 VGPRs: every production instantiation fits without scratch once the compiler no longer
+// forms packed-fp32 instructions (build.py -fno-slp-vectorize: 65-72 VGPRs; with them the kernels needed 80 and
+// spilled at 7 waves, which cost far more than the seventh wave buys). 22.6 KB of LDS per block (traverse.h).
+// The instrumented (COUNTERS) instantiations spill ~110-140 B at this bound: diagnostics, not the frame.
 #ifndef CRT_TRACE_MIN_WAVES
-#define CRT_TRACE_MIN_WAVES 6
+#define CRT_TRACE_MIN_WAVES 7
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
-constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (64 B each; 85 = 4 full levels)
+constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (48 B each; 85 = 4 full levels)
 #ifndef CRT_SHADE_BLOCK
 #define CRT_SHADE_BLOCK 256 // threads per block of k_raygen / k_shade / k_accumulate (128 and 512 measured: profiles/r03_shade_grid_ab.txt)
 #endif
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));
@@ -826,6 +829,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
     st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
     st.stride = TRACE_BLOCK;
+    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
     st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
     st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
                                   (threadIdx.x & 63));

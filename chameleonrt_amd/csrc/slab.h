@@ -11,6 +11,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "crt_types.h" // PNode and its CRT_PNODE_HALF_STEPS
+
 #if defined(__HIPCC__)
 #define CRT_SLAB_FN __host__ __device__ inline
 #else
@@ -45,11 +47,25 @@ CRT_SLAB_FN SlabAxis slab_axis(uint32_t origin, uint32_t scale, uint32_t lo, uin
 {
     SlabAxis x;
     x.a = __builtin_fmaf((float)origin, qa, qb);
-    x.s = qa * __builtin_bit_cast(float, (127u << 23) + (scale << 22));
+#if !CRT_PNODE_HALF_STEPS
+    x.s = __builtin_ldexpf(qa, (int)(scale >> 1)); // (the packer made even codes only)
+#else
+    x.s = qa * __builtin_bit_cast(float, (scale << 22) + (127u << 23));
+#endif
     const bool neg = (slab_bits(qa) >> 31) != 0u;
     x.near = neg ? hi : lo;
     x.far = neg ? lo : hi;
     return x;
+}
+
+// bits [at, at + n) of w (the device's one-instruction bit-field extract: the step is bound by its instruction count)
+CRT_SLAB_FN uint32_t slab_field(uint32_t w, uint32_t at, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(w, at, n);
+#else
+    return (w >> at) & ((1u << n) - 1u);
+#endif
 }
 
 struct SlabNode {
@@ -61,25 +77,47 @@ CRT_SLAB_FN SlabNode slab_node(uint32_t f0, uint32_t f1, uint32_t lo_x, uint32_t
                                uint32_t hi_z, const SlabRay &r)
 {
     SlabNode n;
-    n.x = slab_axis(f0 & 0xffffu, (f1 >> 16) & 31u, lo_x, hi_x, r.qa[0], r.qb[0]);
-    n.y = slab_axis(f0 >> 16, (f1 >> 21) & 31u, lo_y, hi_y, r.qa[1], r.qb[1]);
+    n.x = slab_axis(f0 & 0xffffu, slab_field(f1, 16, 5), lo_x, hi_x, r.qa[0], r.qb[0]);
+    n.y = slab_axis(f0 >> 16, slab_field(f1, 21, 5), lo_y, hi_y, r.qa[1], r.qb[1]);
     n.z = slab_axis(f1 & 0xffffu, f1 >> 26, lo_z, hi_z, r.qa[2], r.qb[2]);
     return n;
 }
 
 template <int C> CRT_SLAB_FN float slab_byte(uint32_t w) { return (float)((w >> (8 * C)) & 0xffu); }
 
-// Sort key of child C (inner-node phase of trace_wavefront): the entry distance into its box clamped to tmin (exit widened
-// by 2 ulp, like every box test of this path tracer), as bits, with the slot in the two lowest; all-ones if the ray does
-// not enter the box within [tmin, tmax].
-template <int C> CRT_SLAB_FN uint32_t slab_packed_key(const SlabNode &n, float tmin, float tmax)
+// Entry distance of child C clamped to tmin (tn) and exit distance clamped to tmax (tf). (Plain fmas: gfx950's packed
+// v_pk_fma_f32 -- one instruction for the near and the far plane of an axis -- was built and measured slower, 61.8 against
+// 60.3 ms on C4, profiles/r04_issue_bound_ab.txt.)
+template <int C> CRT_SLAB_FN void slab_packed_span(const SlabNode &n, float tmin, float tmax, float &tn, float &tf)
 {
     const float nx = __builtin_fmaf(slab_byte<C>(n.x.near), n.x.s, n.x.a), fx = __builtin_fmaf(slab_byte<C>(n.x.far), n.x.s, n.x.a);
     const float ny = __builtin_fmaf(slab_byte<C>(n.y.near), n.y.s, n.y.a), fy = __builtin_fmaf(slab_byte<C>(n.y.far), n.y.s, n.y.a);
     const float nz = __builtin_fmaf(slab_byte<C>(n.z.near), n.z.s, n.z.a), fz = __builtin_fmaf(slab_byte<C>(n.z.far), n.z.s, n.z.a);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin));
-    const float tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax));
-    return tn <= tf * 1.0000004f ? ((slab_bits(tn) & 0x7ffffffcu) | (uint32_t)C) : 0xffffffffu;
+    tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin));
+    tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax));
+}
+
+// Sort keys of the four children (inner-node phase of trace_wavefront): the entry distance (exit widened by 2 ulp, like
+// every box test of this path tracer) as bits, with the slot in the two lowest; all-ones if the ray does not enter the
+// box within [tmin, tmax].
+CRT_SLAB_FN void slab_packed_keys(const SlabNode &n, float tmin, float tmax, uint32_t key[4])
+{
+    float tn[4], tf[4];
+    slab_packed_span<0>(n, tmin, tmax, tn[0], tf[0]);
+    slab_packed_span<1>(n, tmin, tmax, tn[1], tf[1]);
+    slab_packed_span<2>(n, tmin, tmax, tn[2], tf[2]);
+    slab_packed_span<3>(n, tmin, tmax, tn[3], tf[3]);
+    const float wide[4] = {tf[0] * 1.0000004f, tf[1] * 1.0000004f, tf[2] * 1.0000004f, tf[3] * 1.0000004f};
+    for (int c = 0; c < 4; ++c) {
+        key[c] = tn[c] <= wide[c] ? ((slab_bits(tn[c]) & 0x7ffffffcu) | (uint32_t)c) : 0xffffffffu;
+    }
+}
+
+template <int C> CRT_SLAB_FN uint32_t slab_packed_key(const SlabNode &n, float tmin, float tmax)
+{
+    uint32_t key[4];
+    slab_packed_keys(n, tmin, tmax, key);
+    return key[C];
 }
 
 } // namespace crt

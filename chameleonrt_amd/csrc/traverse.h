@@ -18,22 +18,22 @@
 
 namespace crt {
 
-// Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM through the same
-// vector-memory front end that bounds the kernel, so the LDS part is as deep as the LDS
-// budget of 6 blocks per CU allows: 21 for the single-level kernels (26 KB per block; 16 -> 19: C4F -2.2 %, C3 -2 % frame time;
-// 19 -> 21 came with the 48-byte LDS copies of the top nodes),
-// 16 for the two-level ones,
-// which also keep 9 dwords of cold ray state per lane there (26 KB). 8 -> 12 entries: C4F -3.7 % frame time.
+// Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM, so the LDS part is as
+// deep as the LDS budget of 7 blocks per CU allows (160 KB / 7 = 22.8 KB per block, of which 4 KB hold the top levels'
+// nodes): 17 entries for the single-level kernels, 13 for the two-level ones, which also keep 9 dwords of cold ray
+// state per lane there, 12 for a world tree's (6 cold dwords). History: 8 -> 12 entries: C4F -3.7 % frame time;
+// 16 -> 19: C4F -2.2 %, C3 -2 %; at 6 blocks per CU the budget allowed 21 / 16 / 16 -- the seventh wave is worth more
+// than the entries it costs (C4 58.1 -> 56.9 ms, profiles/r04_issue_bound_ab.txt).
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 21
+#define CRT_LDS_STACK 17
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
-#define CRT_LDS_STACK_TWO_LEVEL 16
+#define CRT_LDS_STACK_TWO_LEVEL 13
 #endif
 // the kernels of a world tree (INST_TRIS below) keep the world-space ray in LDS next to the stack, like the two-level
-// ones: six dwords per lane, paid for with five stack entries (26 KB per block)
+// ones: six dwords per lane, paid for with five stack entries
 #ifndef CRT_LDS_STACK_WORLD_TREE
-#define CRT_LDS_STACK_WORLD_TREE 16
+#define CRT_LDS_STACK_WORLD_TREE 12
 #endif
 // levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
 constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
@@ -58,30 +58,44 @@ struct RayHit {
 #define TV_LDS __attribute__((address_space(3)))
 #define TV_HBM __attribute__((address_space(1)))
 
+// The stack pointer is kept as the LDS ADDRESS of the next free entry (`top`), not as a count: a push is a store at
+// `top` and one add, a pop one subtract and a load -- no index -> address arithmetic in the step, which is bound by the
+// vector instructions it issues. Entries of one lane are stride * 4 = 1024 bytes apart and a lane's column starts less
+// than that into the array, so "the entry lies in the LDS part" is one compare of `top` against `limit`, the same
+// constant for every lane (the address LDS_STACK rows into the block's stack array).
 template <int LDS_STACK> struct TraversalStack {
     TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
-    int sp;
+    uint32_t limit;        // LDS address of row LDS_STACK of the block's stack array
+    uint32_t top;
+    CRT_DEV uint32_t base() const { return (uint32_t)(uintptr_t)lds; }
+    CRT_DEV uint32_t step() const { return (uint32_t)stride * 4u; }
+    CRT_DEV void clear() { top = base(); }
+    CRT_DEV bool empty() const { return top == base(); }
+    CRT_DEV int depth() const { return (int)((top - base()) / step()); }
+    CRT_DEV TV_HBM int32_t *spilled(uint32_t at) const { return spill + (size_t)((at - base()) / step() - (uint32_t)LDS_STACK) * 64u; }
     CRT_DEV void push(int32_t x)
     {
-        if (sp < LDS_STACK) {
-            lds[sp * stride] = x;
+        if (top < limit) {
+            *(TV_LDS int32_t *)(uintptr_t)top = x;
         } else {
-            spill[(sp - LDS_STACK) * 64] = x;
+            *spilled(top) = x;
         }
-        ++sp;
+        top += step();
     }
     CRT_DEV int32_t pop()
     {
-        --sp;
-        return sp < LDS_STACK ? lds[sp * stride] : spill[(sp - LDS_STACK) * 64];
+        top -= step();
+        return top < limit ? *(TV_LDS int32_t *)(uintptr_t)top : *spilled(top);
     }
-    CRT_DEV int32_t peek() const // the top entry (sp > 0), left on the stack
+    CRT_DEV int32_t peek() const // the top entry (not empty), left on the stack
     {
-        return sp - 1 < LDS_STACK ? lds[(sp - 1) * stride] : spill[(sp - 1 - LDS_STACK) * 64];
+        const uint32_t at = top - step();
+        return at < limit ? *(TV_LDS int32_t *)(uintptr_t)at : *spilled(at);
     }
+    CRT_DEV void drop() { top -= step(); } // consume the entry peek() returned
 };
 
 // m: InstanceRec::w2o, the 3x4 affine part of the column-major matrix (column c, row r at m[c*3 + r]);
@@ -338,7 +352,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
     // the ray in the space of the triangle it tested last: xf_space = 1 for world space (every identity instance), else
     // the tag (instance << 1) of a transformed instance. (Both rays in registers cost the kernels scratch spills.)
     uint32_t xf_space = 1u;
-    st.sp = 0;
+    st.clear();
     // multi-ray items (Source::retire): which ray of the item the lane is on (bit 0) and what it carries over (bit 1) --
     // read and written only when a ray retires, so one dword, and for the sources that use it (Source::MULTI_RAY)
     // a cold LDS slot of the lane where the kernel has LDS to spare (one instance, two-level), not a register
@@ -394,7 +408,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         hit.u = hit.v = 0.f;
         hit.tri = -1;
         hit.inst = -1;
-        st.sp = 0;
+        st.clear();
         cur = sc.root;
     };
 
@@ -403,7 +417,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
     // is done by the leaf phase, like entering an instance, so that the inner-node loop -- which most iterations
     // run -- carries no code for the few lanes that change level.
     auto pop_next = [&]() {
-        if (st.sp == 0) {
+        if (st.empty()) {
             cur = CUR_DONE;
             return;
         }
@@ -529,11 +543,23 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
                 // the slot makes keys distinct and breaks ties towards the lower slot); children
                 // that are missed, or unused slots, get the all-ones key.
+#if defined(CRT_EXP_INNER_PAD) // timing experiment: N extra VALU instructions per inner step (is the step issue-bound?)
+#pragma unroll
+                for (int pad_i = 0; pad_i < CRT_EXP_INNER_PAD; ++pad_i) {
+                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(k0.x));
+                }
+                k0.x -= (uint32_t)CRT_EXP_INNER_PAD;
+#endif
                 const SlabNode sn = slab_node(k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, sr);
-                const uint32_t s0 = slab_packed_key<0>(sn, tnear, hit.t);
-                const uint32_t s1 = slab_packed_key<1>(sn, tnear, hit.t);
-                const uint32_t s2 = slab_packed_key<2>(sn, tnear, hit.t);
-                const uint32_t s3 = slab_packed_key<3>(sn, tnear, hit.t);
+                // Visit order: children whose box the ray enters, nearest entry first. The key is the entry distance with
+                // its two lowest mantissa bits replaced by the child slot (distances are >= tnear >= 0, so their bit
+                // patterns order like the values; the slot makes keys distinct and breaks ties towards the lower slot);
+                // all-ones for a child that is missed or unused. (Finding the nearest child by comparing the distances
+                // themselves saves the four slot inserts and was measured slower: 56.7 against 55.9 ms on C4,
+                // profiles/r04_issue_bound_ab.txt.)
+                uint32_t child_keys[4];
+                slab_packed_keys(sn, tnear, hit.t, child_keys);
+                const uint32_t s0 = child_keys[0], s1 = child_keys[1], s2 = child_keys[2], s3 = child_keys[3];
                 // 5-comparator sorting network
                 const uint32_t a0 = min(s0, s1), a1 = max(s0, s1), a2 = min(s2, s3), a3 = max(s2, s3);
                 const uint32_t b0 = min(a0, a2), b2 = max(a0, a2), b1 = min(a1, a3), b3 = max(a1, a3);
@@ -561,8 +587,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                         cur = (int32_t)(first == 0 ? k2.x : first == 1 ? k2.y : first == 2 ? k2.z : k2.w);
                     }
                 } else if (CRT_CHILD_ORDER == 1) {
-                    // nearest child first, the other entered children stacked in slot order: no sort
-                    // network and no slot -> reference selects for the pushes
+                    // nearest child first, the other entered children stacked in slot order: no sort network
                     const uint32_t nearest = min(min(s0, s1), min(s2, s3));
                     if (nearest == 0xffffffffu) {
                         pop_next();
@@ -579,7 +604,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                         if (s0 != 0xffffffffu && s0 != nearest) {
                             st.push((int32_t)k2.x);
                         }
-                        cur = ref_of(nearest);
+                        cur = (int32_t)(s3 == nearest ? k2.w : s2 == nearest ? k2.z : s1 == nearest ? k2.y : k2.x); // (keys are distinct)
                     }
                 } else if (b0 == 0xffffffffu) {
                     pop_next();
@@ -640,7 +665,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 // instance than the last one tested).
                 const float4 *p = reinterpret_cast<const float4 *>(sc.slots + first);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const bool have_next = st.sp > 0;
+                const bool have_next = !st.empty();
                 const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
                 // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
                 const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
@@ -724,7 +749,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 } else if (!have_next) {
                     cur = CUR_DONE;
                 } else {
-                    --st.sp; // consume the entry read above
+                    st.drop(); // consume the entry read above
                     cur = TWO_LEVEL && next_ref == STACK_SENTINEL ? CUR_EXIT : next_ref;
                 }
             }

@@ -186,8 +186,10 @@ int main(int argc, char **argv)
                 far2 = qh2 - 2u * origin[k] > far2 ? qh2 - 2u * origin[k] : far2;
                 pack_errors += origin[k] > q.child[c].q[k][0];
             }
+            pack_errors += !CRT_PNODE_HALF_STEPS && (code[k] & 1u) != 0u;
             if (code[k] > 0u) { // the smallest scale that fits: the next smaller one would need a byte above 255
-                const uint32_t smaller = (2u + ((code[k] - 1u) & 1u)) << ((code[k] - 1u) >> 1);
+                const uint32_t prev = code[k] - (CRT_PNODE_HALF_STEPS ? 1u : 2u);
+                const uint32_t smaller = (2u + (prev & 1u)) << (prev >> 1);
                 pack_errors += !((far2 + smaller - 1u) / smaller > 255u);
             }
         }

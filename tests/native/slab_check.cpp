@@ -158,5 +158,5 @@ int main(int argc, char **argv)
     }
     std::printf("nodes %ld children entered %ld zero-direction rays %ld scales seen %d inverted boxes entered %ld narrowed %ld errors %ld\n", n,
                 entered, zero_dirs, n_scales, inverted_entered, narrowed, errors);
-    return errors == 0 && narrowed == 0 && entered > n / 100 && n_scales >= 16 ? 0 : 1;
+    return errors == 0 && narrowed == 0 && entered > n / 100 && n_scales >= (CRT_PNODE_HALF_STEPS ? 16 : 9) ? 0 : 1;
 }

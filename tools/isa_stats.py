@@ -14,7 +14,7 @@ from chameleonrt_amd import build as b
 def stats(defines=(), source="kernels.hip", keep=None):
     out = keep or tempfile.mktemp(suffix=".s")
     flags = [f for f in b.FLAGS if f not in ("-shared", "-fPIC")]
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-S", "--cuda-device-only"] + ["-D" + d for d in defines] + \
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-S", "--cuda-device-only"] + [d if d.startswith("-") else "-D" + d for d in defines] + \
           [os.path.join(b.CSRC, source), "-o", out]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     text = open(out).read()
@@ -36,7 +36,7 @@ def demangle(name):
 
 
 if __name__ == "__main__":
-    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    defs = [a[2:] if a.startswith("-D") else a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-f") or a.startswith("-m")]
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     for r in stats(defs, keep=keep):
         total = r["vgpr"] + r["agpr"]
