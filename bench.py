@@ -31,13 +31,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_GHZ, N_CUS, SIMDS = 2.4, 256, 4  # MI355X_MICROARCH.md chip-level parameters
-NODE_BYTES, SLOT_BYTES = 64, 64  # quantised BVH4 node / leaf slot of one or two triangles
+NODE_BYTES, SLOT_BYTES = 48, 64  # bytes a visit fetches: 48 of a packed BVH4 node's 64-byte record / a leaf slot of one or two triangles
 QUEUE_BYTES_CLOSEST = 24 + 32   # o,d read + the 32-byte hit record {t,u,v,tri | normal,material} written per ray
 QUEUE_BYTES_SHADOW = 28 + 16    # o,d,tmax + the 16-byte {c, path} record read per ray
 MAX_PATH_DEPTH = 5
-# CU-cycles of the vector-memory front end per divergent 64-byte line visit (tools/policy_microbench.hip, `plain`,
-# 100 % of the lanes active, profiles/r04_policy_microbench.txt): working set in L2 (1 MB) / in HBM (128 MB .. 1 GB)
-LINE_VISIT_CYCLES_L2, LINE_VISIT_CYCLES_HBM = 2.93, 10.6
+# CU-cycles of the vector-memory front end per divergent visit (tools/node_bytes_microbench.hip, 100 % of the lanes active,
+# profiles/r04_node_bytes_microbench.txt): the 48 bytes of a 64-byte node record (three dwordx4 per lane) / a 64-byte leaf
+# slot (four), working set in L2 (1 MB) / in HBM (1 GB)
+NODE_VISIT_CYCLES_L2, NODE_VISIT_CYCLES_HBM = 2.06, 10.25
+SLOT_VISIT_CYCLES_L2, SLOT_VISIT_CYCLES_HBM = 2.77, 10.64
 
 
 def parse():
@@ -577,6 +579,7 @@ def main():
         rs = roof("k_trace_shadow", bytes_shadow, acc["shadow_rays"], acc["shadow_ms"])
         rc["line_visits_per_ray"] = (cn + csl) / max(1, cr)
         rs["line_visits_per_ray"] = (sn + ssl) / max(1, sr)
+        rc["node_share"], rs["node_share"] = cn / max(1, cn + csl), sn / max(1, sn + ssl)
         if args.schedule == "serial":
             dom, other_k = (rc, rs) if acc["closest_ms"] >= acc["shadow_ms"] else (rs, rc)
         else:  # the occlusion spans include queueing: the closest-hit kernel, whose spans are clean, is the one reported first
@@ -607,11 +610,16 @@ def main():
                 b["line_visits_per_ray"] = round(v, 2)
                 b["cycles_per_line_visit"] = round(cyc, 2)
                 if hit is not None:
-                    ceil = hit * LINE_VISIT_CYCLES_L2 + (1.0 - hit) * LINE_VISIT_CYCLES_HBM
+                    ns = k.get("node_share", 1.0)
+                    ceil = (ns * (hit * NODE_VISIT_CYCLES_L2 + (1.0 - hit) * NODE_VISIT_CYCLES_HBM) +
+                            (1.0 - ns) * (hit * SLOT_VISIT_CYCLES_L2 + (1.0 - hit) * SLOT_VISIT_CYCLES_HBM))
+                    b["node_share_of_visits"] = round(ns, 3)
                     b["ceiling_cycles"] = round(ceil, 2)
                     b["frac_of_front_end_ceiling"] = round(ceil / cyc, 3)
-                    b["ceiling_note"] = (f"{LINE_VISIT_CYCLES_L2} CU-cycles per divergent 64-byte line visit that hits L2, {LINE_VISIT_CYCLES_HBM} "
-                                         "from HBM (tools/policy_microbench.hip, profiles/r04_policy_microbench.txt), blended by l2_hit_rate")
+                    b["ceiling_note"] = (f"front end alone: {NODE_VISIT_CYCLES_L2} / {SLOT_VISIT_CYCLES_L2} CU-cycles per divergent node / leaf-slot "
+                                         f"visit that hits L2, {NODE_VISIT_CYCLES_HBM} / {SLOT_VISIT_CYCLES_HBM} from HBM (tools/node_bytes_microbench.hip, "
+                                         "profiles/r04_node_bytes_microbench.txt), blended by node share and l2_hit_rate; the kernels also "
+                                         "answer to the instructions they issue per step (profiles/r04_issue_bound_ab.txt)")
             return base
 
         out["roofline"] = contract(dom)
