@@ -7,10 +7,12 @@
 
 namespace crt {
 
-// BFS-ordered top BVH levels the traversal kernels stage in LDS (64 B each; 85 = 4 full levels of
-// the 4-wide tree). The builder is asked for this many nodes in BFS order.
+// BFS-ordered top BVH levels the traversal kernels stage in LDS (48 B each). 5 = the root and its children: at 7 blocks
+// per CU (22.8 KB of LDS each) the 4 KB that four full levels (85 nodes) took are worth more as four more entries of
+// every lane's stack -- C4 55.4 -> 54.6 ms; 0 nodes measures the same (profiles/r04_issue_bound_ab.txt). The builder is
+// asked for this many nodes in BFS order.
 #ifndef CRT_MAX_TOP_NODES
-#define CRT_MAX_TOP_NODES 85
+#define CRT_MAX_TOP_NODES 5
 #endif
 // two-level scenes: top levels of the TLAS staged in LDS: none. The LDS of the two-level kernels also holds the cold
 // ray state and a traversal stack that runs much deeper than in a single tree (26 entries on the instanced C4), and

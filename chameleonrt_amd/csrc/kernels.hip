@@ -45,7 +45,7 @@ namespace crt {
 #define CRT_TRACE_MIN_WAVES 7
 #endif
 constexpr int TRACE_BLOCK = CRT_TRACE_BLOCK;     // threads per traversal block
-constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (48 B each; 85 = 4 full levels)
+constexpr int MAX_TOP_NODES = CRT_MAX_TOP_NODES; // BFS-ordered top BVH levels staged in LDS (48 B each)
 #ifndef CRT_SHADE_BLOCK
 #define CRT_SHADE_BLOCK 256 // threads per block of k_raygen / k_shade / k_accumulate (128 and 512 measured: profiles/r03_shade_grid_ab.txt)
 #endif

@@ -19,13 +19,13 @@
 namespace crt {
 
 // Per-lane stack entries kept in LDS. Every entry beyond them is a 4-byte lane request to HBM, so the LDS part is as
-// deep as the LDS budget of 7 blocks per CU allows (160 KB / 7 = 22.8 KB per block, of which 4 KB hold the top levels'
-// nodes): 17 entries for the single-level kernels, 13 for the two-level ones, which also keep 9 dwords of cold ray
-// state per lane there, 12 for a world tree's (6 cold dwords). History: 8 -> 12 entries: C4F -3.7 % frame time;
-// 16 -> 19: C4F -2.2 %, C3 -2 %; at 6 blocks per CU the budget allowed 21 / 16 / 16 -- the seventh wave is worth more
-// than the entries it costs (C4 58.1 -> 56.9 ms, profiles/r04_issue_bound_ab.txt).
+// deep as the LDS budget of 7 blocks per CU allows (160 KB / 7 = 22.8 KB per block): 21 entries for the single-level
+// kernels, 13 for the two-level ones, which also keep 9 dwords of cold ray state per lane there, 16 for a world tree's
+// (6 cold dwords). History: 8 -> 12 entries: C4F -3.7 % frame time; 16 -> 19: C4F -2.2 %, C3 -2 %; the seventh wave per
+// SIMD is worth more than the entries it costs (C4 58.1 -> 56.9 ms), and entries are worth more than LDS copies of the
+// tree's top levels (kernels.h CRT_MAX_TOP_NODES; profiles/r04_issue_bound_ab.txt).
 #ifndef CRT_LDS_STACK
-#define CRT_LDS_STACK 17
+#define CRT_LDS_STACK 21
 #endif
 #ifndef CRT_LDS_STACK_TWO_LEVEL
 #define CRT_LDS_STACK_TWO_LEVEL 13
@@ -33,7 +33,7 @@ namespace crt {
 // the kernels of a world tree (INST_TRIS below) keep the world-space ray in LDS next to the stack, like the two-level
 // ones: six dwords per lane, paid for with five stack entries
 #ifndef CRT_LDS_STACK_WORLD_TREE
-#define CRT_LDS_STACK_WORLD_TREE 12
+#define CRT_LDS_STACK_WORLD_TREE 16
 #endif
 // levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
 constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
