@@ -288,7 +288,7 @@ def main():
     import hashlib
     lib_stat = os.stat(core.LIB_PATH)
     key = hashlib.sha1(repr((args.workload, sorted(kw.items()), args.levels, build_on_device, os.environ.get("CRT_SCENE_DIR"),
-                             [os.environ.get(k) for k in ("CRT_PAIR_MAX_RATIO", "CRT_BVH_MAX_LEAF", "CRT_BVH_BUILDER", "CRT_HIP_NO_GRAFT", "CRT_BVH_SPLITS")],
+                             [os.environ.get(k) for k in ("CRT_PAIR_MAX_RATIO", "CRT_BVH_MAX_LEAF", "CRT_BVH_BUILDER", "CRT_HIP_NO_GRAFT", "CRT_BVH_SPLITS", "CRT_BVH_REINSERT")],
                              lib_stat.st_size, int(lib_stat.st_mtime))).encode()).hexdigest()[:12]
     prepared_path, meta_path = f"{shm}/crt_prepared_{args.workload}_{key}.bin", f"{shm}/crt_prepared_{args.workload}_{key}.json"
     scene = None

@@ -418,23 +418,10 @@ struct Builder {
 // branch-and-bound search from the root, and put it there, reusing the parent node. Leaves keep their item ranges, so
 // nothing below changes. Serial and deterministic (ties by node index). Role in the reference: the quality of
 // rtcCommitScene's tree (embree_utils.cpp:63-76); priced like every builder change by tools/tree_cost.py.
-struct Reinserter {
+struct ReinsertTree { // shared by the workers of a pass, which own disjoint sets of nodes
     TNode *tn;
-    int32_t root;
     std::vector<int32_t> parent;
     std::vector<float> area;
-    struct Cand {
-        float induced;
-        int32_t node;
-    };
-    std::vector<Cand> heap;
-
-    static Aabb merged(const Aabb &a, const Aabb &b)
-    {
-        Aabb o = a;
-        box_grow(o, b);
-        return o;
-    }
     void index(int32_t n_nodes)
     {
         parent.assign(n_nodes, -1);
@@ -447,22 +434,43 @@ struct Reinserter {
             }
         }
     }
+};
+
+// works on the subtree under `root` (whose parent link is -1 while it does): searches start there, refits end there
+struct Reinserter {
+    ReinsertTree &T;
+    int32_t root;
+    struct Cand {
+        float induced;
+        int32_t node;
+    };
+    std::vector<Cand> heap;
+    Reinserter(ReinsertTree &tree, int32_t r) : T(tree), root(r) {}
+
+    static Aabb merged(const Aabb &a, const Aabb &b)
+    {
+        Aabb o = a;
+        box_grow(o, b);
+        return o;
+    }
     void refit_up(int32_t t)
     {
-        for (; t >= 0; t = parent[t]) {
+        TNode *tn = T.tn;
+        for (; t >= 0; t = T.parent[t]) {
             const Aabb nb = merged(tn[tn[t].left].box, tn[tn[t].right].box);
             if (std::memcmp(&nb, &tn[t].box, sizeof(Aabb)) == 0) {
                 break;
             }
             tn[t].box = nb;
-            area[t] = half_area(nb);
+            T.area[t] = half_area(nb);
         }
     }
     static bool worse(const Cand &a, const Cand &b) { return a.induced != b.induced ? a.induced > b.induced : a.node > b.node; }
     int32_t best_place(int32_t x)
     {
+        const TNode *tn = T.tn;
         const Aabb &xb = tn[x].box;
-        const float ax = area[x];
+        const float ax = T.area[x];
         float best_cost = std::numeric_limits<float>::infinity();
         int32_t best = root;
         heap.clear();
@@ -480,7 +488,7 @@ struct Reinserter {
                 best_cost = total;
                 best = c.node;
             }
-            const float below = total - area[c.node]; // what every place under this node pays for growing it
+            const float below = total - T.area[c.node]; // what every place under this node pays for growing it
             if (tn[c.node].left >= 0 && below + ax < best_cost) {
                 heap.push_back(Cand{below, tn[c.node].left});
                 std::push_heap(heap.begin(), heap.end(), worse);
@@ -493,6 +501,8 @@ struct Reinserter {
     // returns whether the subtree moved
     bool reinsert(int32_t x)
     {
+        TNode *tn = T.tn;
+        std::vector<int32_t> &parent = T.parent;
         const int32_t p = parent[x];
         if (p < 0 || parent[p] < 0) {
             return false; // the root and its children stay
@@ -510,7 +520,7 @@ struct Reinserter {
         parent[x] = p;
         parent[p] = py;
         tn[p].box = merged(tn[y].box, tn[x].box);
-        area[p] = half_area(tn[p].box);
+        T.area[p] = half_area(tn[p].box);
         if (py < 0) {
             root = p;
         } else {
@@ -519,47 +529,126 @@ struct Reinserter {
         }
         return y != s;
     }
-    double inner_area() const
-    {
-        double sum = 0.0;
-        for (size_t t = 0; t < parent.size(); ++t) {
-            if (tn[t].left >= 0) {
-                sum += area[t];
-            }
-        }
-        return sum;
-    }
 };
 
 // `passes` sweeps over all subtrees, largest first; then the collapse table (TNode::slot_cost) is rebuilt bottom-up.
+// A pass is cut into independent pieces: the tree is split at the highest nodes that have at most REINSERT_PIECE
+// nodes below them (a property of the tree, not of the thread count, so the result does not depend on it), every piece
+// (2^17) is swept by one worker with searches confined to the piece, and the few nodes above the cut -- and the pieces' own
+// roots -- are then swept serially with searches over the whole tree. 10 M nodes: 60 s per pass serially, ~10 s on 8 cores.
 int32_t optimise_by_reinsertion(Builder &b, int32_t root, int32_t n_nodes, int passes, bool verbose)
 {
-    Reinserter r;
-    r.tn = b.tn.get();
-    r.root = root;
-    r.index(n_nodes);
-    std::vector<int32_t> todo(n_nodes);
-    for (int pass = 0; pass < passes; ++pass) {
-        const double before = r.inner_area();
+    // (CRT_BVH_REINSERT_PIECE: the tests cut small trees into many pieces with it)
+    const int32_t REINSERT_PIECE = std::getenv("CRT_BVH_REINSERT_PIECE") ? std::max(2, std::atoi(std::getenv("CRT_BVH_REINSERT_PIECE"))) : 1 << 17;
+    ReinsertTree T;
+    T.tn = b.tn.get();
+    T.index(n_nodes);
+    TNode *tn = T.tn;
+    auto inner_area = [&]() {
+        double sum = 0.0;
         for (int32_t t = 0; t < n_nodes; ++t) {
-            todo[t] = t;
+            sum += tn[t].left >= 0 ? (double)T.area[t] : 0.0;
         }
-        std::sort(todo.begin(), todo.end(), [&](int32_t x, int32_t y) { return r.area[x] != r.area[y] ? r.area[x] > r.area[y] : x < y; });
+        return sum;
+    };
+    auto by_area = [&](int32_t x, int32_t y) { return T.area[x] != T.area[y] ? T.area[x] > T.area[y] : x < y; };
+    std::vector<int32_t> size(n_nodes), order;
+    for (int pass = 0; pass < passes; ++pass) {
+        const double before = verbose ? inner_area() : 0.0;
+        // nodes under every node (children after their parents in `order`, so backwards is bottom-up)
+        order.clear();
+        order.push_back(root);
+        for (size_t i = 0; i < order.size(); ++i) {
+            const int32_t t = order[i];
+            if (tn[t].left >= 0) {
+                order.push_back(tn[t].left);
+                order.push_back(tn[t].right);
+            }
+        }
+        for (size_t i = order.size(); i-- > 0;) {
+            const int32_t t = order[i];
+            size[t] = tn[t].left >= 0 ? 1 + size[tn[t].left] + size[tn[t].right] : 1;
+        }
+        std::vector<int32_t> pieces, above;
+        for (int32_t t : order) {
+            const int32_t p = T.parent[t];
+            if (size[t] > REINSERT_PIECE) {
+                above.push_back(t);
+            } else if (p < 0 || size[p] > REINSERT_PIECE) {
+                pieces.push_back(t);
+            }
+        }
+        std::vector<int32_t> piece_parent(pieces.size()), piece_root(pieces.size());
+        std::vector<size_t> piece_moved(pieces.size(), 0);
+        for (size_t k = 0; k < pieces.size(); ++k) {
+            piece_parent[k] = T.parent[pieces[k]];
+            T.parent[pieces[k]] = -1;
+        }
+        std::atomic<size_t> next_piece{0};
+        auto worker = [&]() {
+            std::vector<int32_t> mine;
+            for (size_t k = next_piece.fetch_add(1); k < pieces.size(); k = next_piece.fetch_add(1)) {
+                Reinserter r(T, pieces[k]);
+                mine.clear();
+                mine.push_back(pieces[k]);
+                for (size_t i = 0; i < mine.size(); ++i) {
+                    const int32_t t = mine[i];
+                    if (tn[t].left >= 0) {
+                        mine.push_back(tn[t].left);
+                        mine.push_back(tn[t].right);
+                    }
+                }
+                std::sort(mine.begin(), mine.end(), by_area);
+                for (int32_t x : mine) {
+                    piece_moved[k] += r.reinsert(x) ? 1 : 0;
+                }
+                piece_root[k] = r.root;
+            }
+        };
+        {
+            std::vector<std::future<void>> jobs;
+            for (int t = 1; t < std::min<int>(b.n_threads, (int)pieces.size()); ++t) {
+                jobs.push_back(std::async(std::launch::async, worker));
+            }
+            worker();
+            for (auto &j : jobs) {
+                j.get();
+            }
+        }
         size_t moved = 0;
-        const double top = std::getenv("CRT_BVH_REINSERT_TOP") ? std::atof(std::getenv("CRT_BVH_REINSERT_TOP")) : 1.0;
-        const size_t n_todo = (size_t)std::min((double)n_nodes, std::max(1.0, top * n_nodes));
-        for (size_t i = 0; i < n_todo; ++i) {
-            moved += r.reinsert(todo[i]) ? 1 : 0;
+        Reinserter top(T, root);
+        for (size_t k = 0; k < pieces.size(); ++k) { // hang the pieces back in (their roots may have changed)
+            moved += piece_moved[k];
+            const int32_t p = piece_parent[k];
+            T.parent[piece_root[k]] = p;
+            if (p < 0) {
+                top.root = piece_root[k];
+            } else {
+                (tn[p].left == pieces[k] ? tn[p].left : tn[p].right) = piece_root[k];
+            }
         }
+        for (size_t k = 0; k < pieces.size(); ++k) {
+            if (piece_parent[k] >= 0) {
+                top.refit_up(piece_parent[k]);
+            }
+        }
+        // the nodes above the cut and the pieces' roots, over the whole tree
+        above.insert(above.end(), piece_root.begin(), piece_root.end());
+        std::sort(above.begin(), above.end(), by_area);
+        for (int32_t x : above) {
+            moved += top.reinsert(x) ? 1 : 0;
+        }
+        root = top.root;
         if (verbose) {
-            std::fprintf(stderr, "[crt_hip]   reinsertion pass %d: %zu of %d subtrees moved, summed inner area %.4g -> %.4g (%.1f %%)\n", pass,
-                         moved, n_nodes, before, r.inner_area(), 100.0 * (r.inner_area() / before - 1.0));
+            const double after = inner_area();
+            std::fprintf(stderr, "[crt_hip]   reinsertion pass %d: %zu of %d subtrees moved (%zu pieces), summed inner area %.4g -> %.4g (%.1f %%)\n",
+                         pass, moved, n_nodes, pieces.size(), before, after, 100.0 * (after / before - 1.0));
         }
         if (moved == 0) {
             break;
         }
     }
-    std::vector<int32_t> stack{r.root}, post;
+    std::vector<int32_t> stack{root}, post;
     post.reserve(n_nodes / 2 + 1);
     while (!stack.empty()) {
         const int32_t t = stack.back();
@@ -573,7 +662,7 @@ int32_t optimise_by_reinsertion(Builder &b, int32_t root, int32_t n_nodes, int p
     for (size_t i = post.size(); i-- > 0;) { // parents come before their children in `post`
         b.fill_slot_cost(post[i]);
     }
-    return r.root;
+    return root;
 }
 
 inline int32_t leaf_ref(uint32_t first, uint32_t count) { return (int32_t)~((first << 3) | (count - 1u)); }

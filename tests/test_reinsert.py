@@ -22,8 +22,12 @@ from tests.test_presplit import _beams_and_confetti
 F = np.float32
 
 
-def _prepared(sc, monkeypatch, passes, levels=None, threads=None):
+def _prepared(sc, monkeypatch, passes, levels=None, threads=None, piece=None):
     monkeypatch.setenv("CRT_BVH_REINSERT", passes)
+    if piece:
+        monkeypatch.setenv("CRT_BVH_REINSERT_PIECE", piece)
+    else:
+        monkeypatch.delenv("CRT_BVH_REINSERT_PIECE", raising=False)
     monkeypatch.delenv("CRT_BVH_SPLITS", raising=False)
     if levels:
         monkeypatch.setenv("CRT_HIP_LEVELS", levels)
@@ -69,9 +73,30 @@ def test_reinserted_tree_finds_what_brute_force_finds(structure, oracle, monkeyp
 
 def test_thread_count_does_not_change_the_reinserted_tree(monkeypatch):
     sc = _beams_and_confetti()
-    a = _prepared(sc, monkeypatch, "2", threads="1")
-    b = _prepared(sc, monkeypatch, "2", threads="5")
-    assert np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["tris"], b["tris"])
+    for piece in (None, "512"):  # one piece (the whole tree); ~50 pieces swept by several workers + the nodes above the cut
+        a = _prepared(sc, monkeypatch, "2", threads="1", piece=piece)
+        b = _prepared(sc, monkeypatch, "2", threads="5", piece=piece)
+        assert np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["tris"], b["tris"])
+
+
+def test_tree_swept_in_pieces_finds_what_brute_force_finds(oracle, monkeypatch):
+    """A pass over a large tree is cut into independent pieces (searches confined to a piece, the nodes above the cut swept
+    afterwards over the whole tree): forced here on a small tree."""
+    sc = _beams_and_confetti(instanced=True)
+    b0 = _prepared(sc, monkeypatch, "0", "world")
+    b1 = _prepared(sc, monkeypatch, "3", "world", threads="4", piece="256")
+    assert b1["tris"].shape[0] == b0["tris"].shape[0] and not np.array_equal(b1["nodes"], b0["nodes"])
+    org, dirs = probe_rays(sc, 20000, seed=17, spread=0.6)
+    c = oracle.OracleScene(sc).trace(org, dirs, 0.0, 1e20, closest=True, brute_force=True)
+    w0 = oracle.walk_product_bvh(b0, org, dirs, 0.0, 1e20, closest=True)
+    w1 = oracle.walk_product_bvh(b1, org, dirs, 0.0, 1e20, closest=True)
+    for k in ("inst", "geom", "prim"):
+        assert np.array_equal(w1[k], c[k]), k
+    hit = c["inst"] >= 0
+    assert np.array_equal(w1["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32)) and w1["max_stack"] <= b1["stack_need"]
+    lines0, lines1 = (w0["nodes"] + w0["slots"]) / len(org), (w1["nodes"] + w1["slots"]) / len(org)
+    print(f"\nworld tree swept in pieces of <= 256 nodes: lines per closest-hit ray {lines0:.2f} -> {lines1:.2f}")
+    assert lines1 <= 1.02 * lines0
 
 
 def test_builder_check_with_reinsertion(tmp_path):
