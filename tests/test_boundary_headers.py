@@ -58,3 +58,19 @@ def test_reference_loader_opens_the_plugin_and_reaches_the_backend():
     p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "crt_bench"), "-benchmark-frames", "1"], capture_output=True, text=True)
     assert p.returncode == 1
     assert "RenderHIP: no HIP device (this backend has no CPU fallback)" in p.stderr, p.stderr
+
+
+def test_cmake_recipe_compiles_the_core_with_the_flags_of_build_py():
+    """backends/hip/CMakeLists.txt (what a maintainer of the reference adds) builds libcrt_hip_core.so with the
+    same compiler flags and sources as chameleonrt_amd/build.py -- in particular -ffp-contract=off / -fno-fast-math (parity) and
+    -fno-slp-vectorize (without it the traversal kernels spill at their 7-wave launch bounds)."""
+    import re
+
+    from chameleonrt_amd import build
+    text = open(os.path.join(ROOT, "backends", "hip", "CMakeLists.txt")).read()
+    cmd = re.search(r"COMMAND \$\{HIPCC\}(.*?)-o \$\{CRT_HIP_CORE\}", text, re.S).group(1)
+    flags = [f for f in build.FLAGS if f not in ("-Wall", "-Wno-unused-function")]
+    for f in flags:
+        assert f in cmd.split(), f
+    for src in build.SOURCES:
+        assert f"/chameleonrt_amd/csrc/{src}" in cmd, src
