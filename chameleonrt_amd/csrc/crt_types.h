@@ -17,7 +17,8 @@ namespace crt {
 // The BVH is 4-wide: one fetch decides four children, which about halves the chain of dependent
 // node fetches of a ray and the per-node bookkeeping (DESIGN.md "Traversal"; what bounds the kernel
 // is analysed there with PMC counters, not assumed here). BvhNode is what the host builder produces (full-precision
-// boxes of all children); the traversal kernels read the 64-byte quantised form below.
+// boxes of all children), QNode its 16-bit fixed-point form (what every builder delivers), PNode the packed form the
+// traversal kernels read (48 bytes of a 64-byte record).
 constexpr int BVH_WIDTH = 4;
 constexpr int32_t EMPTY_CHILD = (int32_t)0x80000002;
 #if defined(__HIPCC__)
@@ -43,11 +44,10 @@ struct QFrame {
     float step[3];
 };
 
-// One BVH4 node as the kernels see it: 64 B = 4 x dwordx4 per lane, one 16-byte quarter per child:
+// One BVH4 node as the BUILDERS deliver it (rounds 1-3: also what the kernels read): 64 B, one 16-byte quarter per child:
 // its AABB as 16-bit fixed point in the BVH's QFrame (one lo|hi dword per axis), rounded OUTWARD by at least one quantum
 // (conservative: a box may only grow, so no hit can be missed; which triangle wins never depends
-// on the boxes), and its reference. 64 B per 4 children is 2/3 of the bytes the same tree took as
-// 32-byte binary nodes.
+// on the boxes), and its reference. scene_prepare.cpp packs it into a PNode (below) at the end.
 struct alignas(16) QChild {
     uint16_t q[3][2]; // per axis: {lo, hi} -> one dword per axis, lo in the low half
     int32_t ref;

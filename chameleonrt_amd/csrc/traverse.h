@@ -538,11 +538,6 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                     ++n_nodes;
                     ++ray_nodes;
                 }
-                // Visit order: children whose box the ray enters, nearest entry first. The sort key
-                // is the entry distance with its two lowest mantissa bits replaced by the child
-                // slot (distances are >= tnear >= 0, so their bit patterns order like the values;
-                // the slot makes keys distinct and breaks ties towards the lower slot); children
-                // that are missed, or unused slots, get the all-ones key.
 #if defined(CRT_EXP_INNER_PAD) // timing experiment: N extra VALU instructions per inner step (is the step issue-bound?)
 #pragma unroll
                 for (int pad_i = 0; pad_i < CRT_EXP_INNER_PAD; ++pad_i) {

@@ -92,7 +92,7 @@ class OracleScene:
 
 
 def walk_product_bvh(bvh, org, dirs, tmin, tmax, closest=True):
-    """Walk the PRODUCT's BVH arrays (RenderHIP.bvh(): quantised 4-wide nodes, triangle and instance
+    """Walk the PRODUCT's BVH arrays (RenderHIP.bvh(): packed 4-wide nodes, triangle and instance
     records) on the CPU with the product's documented visit rule. Returns node / triangle visit counts
     (what the instrumented kernels must report), the deepest stack any ray needed, and the hits."""
     org = np.ascontiguousarray(org, np.float32)
