@@ -5,7 +5,7 @@
 #
 # Everything a step writes goes to gpurun_out/TAG/ (merged back into the working tree by gpurun); the summaries worth
 # keeping are copied into profiles/ by hand. Steps:
-#   tests[:EXPR]        pytest -m gpu (optionally -k EXPR)                       -> pytest.log
+#   tests[:EXPR[:ENV=V,...]]  pytest -m gpu (optionally -k EXPR, with environment settings) -> pytest_<n>.log
 #   bench:W[:ARGS]      python bench.py --workload W ARGS (',' separates ARGS)   -> bench_W.json / .err
 #   ab:W:V1,V2[:N]      frames of workload W with library variants (tools/variants.py; `prod` = the product) -> ab_W.log
 #   phase:W             wave-phase profile of the instrumented kernels (CRT_HIP_DEBUG) -> phase_W.log
@@ -24,7 +24,7 @@ for step in "$@"; do
   case $kind in
     tests)
       if [ -n "$a" ]; then K=(-k "$a"); else K=(); fi
-      timeout -k 5 1500 python -m pytest tests -m gpu -x -q -s "${K[@]}" > "$OUT/pytest_$n.log" 2>&1
+      ( [ -n "$b" ] && export ${b//,/ }; timeout -k 5 1500 python -m pytest tests -m gpu -x -q -s "${K[@]}" ) > "$OUT/pytest_$n.log" 2>&1
       grep -E "passed|failed|error|diverged|deepest" "$OUT/pytest_$n.log" | tail -12 ;;
     bench)
       ARGS=${b//,/ }
