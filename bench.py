@@ -386,7 +386,9 @@ def main():
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)" +
                                       (" + RCCL gather to rank 0 every step, overlapped with the next frame" if dist else ""),
                        "scene_gen_s": meta["scene_gen_s"], "set_scene_host_s": meta["set_scene_host_s"],
-                       "bvh_builder": "device linear BVH (CRT_HIP_BUILD=device)" if build_on_device else "host binned SAH",
+                       "bvh_builder": "device linear BVH (CRT_HIP_BUILD=device)" if build_on_device else
+                                      "host binned SAH" + (lambda p: f" + {p} passes of insertion-based re-optimisation (Bittner 2013)" if p > 0 else "")(
+                                          int(os.environ.get("CRT_BVH_REINSERT", "2") or 0)),
                        "prepared_scene_cache": "hit: the prepared arrays of an earlier run on this box (scene_gen_s / set_scene_host_s are that run's)"
                                                if cache_hit else "miss",
                        "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},

@@ -85,7 +85,7 @@ def build_scene_io(force=False):
     deps = [os.path.join(CSRC, f) for f in IO_SOURCES] + [os.path.join(HERE, "..", "include", "crt_scene_io.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(IO_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(IO_LIB) for d in deps):
         return IO_LIB
-    subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] +
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off"] +
                           [os.path.join(CSRC, f) for f in IO_SOURCES] + ["-o", IO_LIB])
     return IO_LIB
 

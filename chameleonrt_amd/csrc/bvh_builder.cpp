@@ -410,7 +410,7 @@ struct Builder {
     }
 };
 
-// ---- insertion-based optimisation of the binary tree (opt-in: CRT_BVH_REINSERT=<passes>) ----------------------------
+// ---- insertion-based optimisation of the binary tree (CRT_BVH_REINSERT=<passes>, default 2) ----------------------------
 // A top-down build decides every split with the items of one range in hand and never revisits it. Bittner, Hapala,
 // Havran 2013 ("Fast insertion-based optimization of bounding volume hierarchies") repair that afterwards: take a subtree
 // out (its parent goes with it, the sibling moves up), find the place where putting it back costs the least summed
@@ -715,8 +715,10 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     phase("setup");
     int32_t root = b.build(0, (uint32_t)n, 0);
     phase("recursive build");
-    if (const char *e = std::getenv("CRT_BVH_REINSERT")) {
-        const int passes = std::atoi(e);
+    {
+        // two passes by default (round 5; C4 -8 % line visits per ray, 54.6 -> 53.0 ms); CRT_BVH_REINSERT=0 switches it off
+        const char *e = std::getenv("CRT_BVH_REINSERT");
+        const int passes = e != nullptr ? std::atoi(e) : 2;
         const int32_t n_nodes = b.next.load();
         if (passes > 0 && n_nodes > 7) {
             root = optimise_by_reinsertion(b, root, n_nodes, passes, dbg && n > 100000);

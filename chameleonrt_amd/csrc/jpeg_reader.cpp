@@ -320,6 +320,13 @@ private:
             h_max = std::max(h_max, comp[i].h);
             v_max = std::max(v_max, comp[i].v);
         }
+        // every component's sampling factor must divide the largest one (as current stb_image demands): to_rgba up-samples by
+        // the integer ratio h_max / h, and with H = 3, 2, 1 that ratio would read past a plane only mcu_x * h * 8 wide
+        for (int i = 0; i < n_comp; ++i) {
+            if (h_max % comp[i].h != 0 || v_max % comp[i].v != 0) {
+                throw Fail("bad H / V: sampling factors that do not divide the largest");
+            }
+        }
         mcu_x = (img_x + h_max * 8 - 1) / (h_max * 8);
         mcu_y = (img_y + v_max * 8 - 1) / (v_max * 8);
         for (int i = 0; i < n_comp; ++i) {
@@ -404,7 +411,7 @@ private:
     void decode_block(int16_t data[64], Component &c)
     {
         const int t = huff_decode(dc_tab[c.hd]);
-        if (t < 0) {
+        if (t < 0 || t > 15) { // (a DC category is a bit count: more than 15 would shift by >= 32 in receive_extend)
             throw Fail("bad huffman code");
         }
         std::memset(data, 0, 64 * sizeof(int16_t));
@@ -441,13 +448,13 @@ private:
         if (succ_high == 0) {
             std::memset(data, 0, 64 * sizeof(int16_t));
             const int t = huff_decode(dc_tab[c.hd]);
-            if (t < 0) {
+            if (t < 0 || t > 15) {
                 throw Fail("bad huffman code");
             }
             const int diff = t ? receive_extend(t) : 0;
             const int dc = c.dc_pred + diff;
             c.dc_pred = dc;
-            data[0] = (int16_t)(dc << succ_low);
+            data[0] = (int16_t)(dc * (1 << succ_low)); // (a product, not a shift: dc may be negative)
         } else if (get_bit()) {
             data[0] = (int16_t)(data[0] + (int16_t)(1 << succ_low));
         }
@@ -490,7 +497,7 @@ private:
                     k += r;
                     const unsigned zig = DEZIGZAG[std::min(k, 78)];
                     ++k;
-                    data[zig] = (int16_t)(receive_extend(s) << succ_low);
+                    data[zig] = (int16_t)(receive_extend(s) * (1 << succ_low));
                 }
             } while (k <= spec_end);
             return;

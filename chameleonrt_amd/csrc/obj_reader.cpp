@@ -2,7 +2,8 @@
 // include/crt_scene_io.h (libcrt_scene_io.so, plain g++: no HIP in here).
 //
 // What the reference's importer makes of an OBJ file (util/scene.cpp:94-228, on tinyobjloader): every `o` / `g` group
-// that has faces becomes one Geometry; polygons are triangulated as fans; the vertices of a group are re-indexed on
+// that has faces becomes one Geometry; polygons are cut into triangles by tinyobjloader's ear clipping (`triangulate`
+// below: concave polygons come out as the reference's triangles, not as a fan); the vertices of a group are re-indexed on
 // unique (position, normal, uv) index triples in order of first use; a group's material is the material of its FIRST
 // face. This file does the text half of that -- the part that is hopeless line by line in Python on the 10 M-triangle
 // assets BASELINE.json names (Rungholt, San Miguel): one pass over the memory-mapped file with std::from_chars
@@ -16,6 +17,9 @@
 #include <unistd.h>
 
 #include <charconv>
+#include <cmath>
+#include <cstddef>
+#include <limits>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -102,6 +106,16 @@ struct Parser {
         if (*b == '+') {
             ++b; // from_chars does not accept a leading plus; Python's float() does
         }
+        // The reference's number grammar (tinyobjloader's tryParseDouble, util/tiny_obj_loader.h:567-680): an optional sign,
+        // then at least one DIGIT. ".5", "-.5", "inf", "nan" do not parse there and silently read as 0.0; here such a
+        // file is refused rather than loaded as something else than the reference would make of it. (What follows the first
+        // digit -- fraction, exponent, the whole token consumed -- is from_chars' general format = the rest of that grammar.)
+        {
+            const char *d0 = (*b == '-') ? b + 1 : b;
+            if (d0 >= q || *d0 < '0' || *d0 > '9') {
+                return false;
+            }
+        }
         double d = 0.0;
         const auto r = std::from_chars(b, q, d);
         if (r.ec != std::errc() || r.ptr != q) {
@@ -147,10 +161,107 @@ struct Parser {
         return true;
     }
 
+    // ---- polygons -> triangles, as the reference's importer gets them from tinyobjloader (util/tiny_obj_loader.h:1107-1310,
+    // called with triangulate = true by util/scene.cpp:117). Not a fan: the polygon is projected on the two axes chosen from
+    // its first non-degenerate corner, its signed area gives the winding, and ears are clipped -- starting at corner
+    // `guess`, three consecutive remaining corners (a, b, c) are an ear if the turn at b has the polygon's winding and no
+    // other remaining corner lies inside (a, b, c) by the crossing-number test; an ear is emitted as (a, b, c) and b is
+    // taken out; otherwise the search moves on by one corner. The search gives up after as many fruitless steps as there
+    // are corners left (what has been emitted stays); the last three corners are emitted as they are. All arithmetic in
+    // float, in the reference's order -- which ears exist depends on it. Consequence worth knowing: the first emitted corner
+    // of a face need not be its first corner, so the re-indexed vertex ORDER of a group depends on this, too.
+    // (tinyobjloader's "invalid index" skips cannot occur here: parse_face has refused such faces already.)
+    static bool inside_tri(const float *vx, const float *vy, float tx, float ty)
+    {
+        bool c = false;
+        for (int i = 0, j = 2; i < 3; j = i++) {
+            if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) {
+                c = !c;
+            }
+        }
+        return c;
+    }
+    std::vector<Corner> ring; // the corners still to be cut (scratch of triangulate)
+    template <class Emit> void triangulate(const std::vector<Corner> &face, Emit &&emit)
+    {
+        const size_t n = face.size();
+        if (n < 3) {
+            return;
+        }
+        if (n == 3) {
+            emit(face[0], face[1], face[2]);
+            return;
+        }
+        const float *v = pos.data();
+        int ax0 = 1, ax1 = 2;
+        for (size_t k = 0; k < n; ++k) {
+            const float *a = v + 3 * (size_t)face[k].v, *b = v + 3 * (size_t)face[(k + 1) % n].v, *c = v + 3 * (size_t)face[(k + 2) % n].v;
+            const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+            const float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+            const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+            const float eps = std::numeric_limits<float>::epsilon();
+            if (cx > eps || cy > eps || cz > eps) { // the first corner that is one
+                if (!(cx > cy && cx > cz)) {
+                    ax0 = 0;
+                    if (cz > cx && cz > cy) {
+                        ax1 = 1;
+                    }
+                }
+                break;
+            }
+        }
+        float area = 0.f;
+        for (size_t k = 0; k < n; ++k) {
+            const float *a = v + 3 * (size_t)face[k].v, *b = v + 3 * (size_t)face[(k + 1) % n].v;
+            area += (a[ax0] * b[ax1] - a[ax1] * b[ax0]) * 0.5f;
+        }
+        ring = face;
+        size_t guess = 0, budget = n, last_size = n;
+        while (ring.size() > 3 && budget > 0) {
+            const size_t m = ring.size();
+            if (guess >= m) {
+                guess -= m;
+            }
+            if (last_size != m) { // the previous step cut a corner off: a fresh budget
+                last_size = m;
+                budget = m;
+            } else {
+                --budget;
+            }
+            Corner tri[3];
+            float vx[3], vy[3];
+            for (int k = 0; k < 3; ++k) {
+                tri[k] = ring[(guess + (size_t)k) % m];
+                vx[k] = v[3 * (size_t)tri[k].v + ax0];
+                vy[k] = v[3 * (size_t)tri[k].v + ax1];
+            }
+            const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+            const float cross = e0x * e1y - e0y * e1x;
+            if (cross * area < 0.f) { // a reflex corner
+                ++guess;
+                continue;
+            }
+            bool blocked = false;
+            for (size_t o = 3; o < m && !blocked; ++o) {
+                const Corner &q = ring[(guess + o) % m];
+                blocked = inside_tri(vx, vy, v[3 * (size_t)q.v + ax0], v[3 * (size_t)q.v + ax1]);
+            }
+            if (blocked) {
+                ++guess;
+                continue;
+            }
+            emit(tri[0], tri[1], tri[2]);
+            ring.erase(ring.begin() + (std::ptrdiff_t)((guess + 1) % m));
+        }
+        if (ring.size() == 3) {
+            emit(ring[0], ring[1], ring[2]);
+        }
+    }
+
+    std::vector<Corner> face; // the corners of the face being read (scratch of parse_face)
     bool parse_face()
     {
-        Corner first{0, 0, 0}, prev{0, 0, 0};
-        int count = 0;
+        face.clear();
         while (!at_eol()) {
             const char *q = token_end();
             const char *s1 = (const char *)memchr(p, '/', (size_t)(q - p));
@@ -191,26 +302,23 @@ struct Parser {
                 }
             }
             p = q;
-            if (count == 0) {
-                first = c;
-            } else if (count >= 2) { // fan: (first, prev, this)
-                if (cur < 0) {
-                    shapes.emplace_back();
-                    cur = (int)shapes.size() - 1;
-                }
-                Shape &s = shapes[(size_t)cur];
-                if (s.pending.empty()) {
-                    s.material = cur_mat;
-                    s.has_material = have_mat;
-                    s.material_libs = cur_mat_libs;
-                }
-                s.pending.push_back(first);
-                s.pending.push_back(prev);
-                s.pending.push_back(c);
-            }
-            prev = c;
-            ++count;
+            face.push_back(c);
         }
+        triangulate(face, [this](const Corner &a, const Corner &b, const Corner &c) {
+            if (cur < 0) {
+                shapes.emplace_back();
+                cur = (int)shapes.size() - 1;
+            }
+            Shape &s = shapes[(size_t)cur];
+            if (s.pending.empty()) {
+                s.material = cur_mat;
+                s.has_material = have_mat;
+                s.material_libs = cur_mat_libs;
+            }
+            s.pending.push_back(a);
+            s.pending.push_back(b);
+            s.pending.push_back(c);
+        });
         return true;
     }
 

@@ -119,6 +119,19 @@ class _Model:
         return Image(a.shape[1], a.shape[0], 4, a, LINEAR, im.get("name", ""))
 
 
+def _mat4_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """a * b as GLM computes it (glm/detail/type_mat4x4.inl, operator*(mat4, mat4), GLM 0.9.9.8 per the reference's
+    cmake/glm.cmake): every result column is ((A0 * b0 + A1 * b1) + A2 * b2) + A3 * b3 with A_k the columns of a and b_k the
+    entries of b's column, in float32, left to right -- not a BLAS product, whose summation order is its own business. With
+    this the flattened node matrices of util/flatten_gltf.cpp:21,26,50 come out bit for bit. Matrices are [row, column]."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    r = np.empty((4, 4), np.float32)
+    for c in range(4):
+        r[:, c] = ((a[:, 0] * b[0, c] + a[:, 1] * b[1, c]) + a[:, 2] * b[2, c]) + a[:, 3] * b[3, c]
+    return r
+
+
 def node_transform(n: dict) -> np.ndarray:
     """read_node_transform (flatten_gltf.cpp:9-30): 4x4 float32, indexed [row, column]."""
     if n.get("matrix"):
@@ -133,11 +146,11 @@ def node_transform(n: dict) -> np.ndarray:
         rot[0, 0], rot[1, 0], rot[2, 0] = one - two * (y * y + z * z), two * (x * y + w * z), two * (x * z - w * y)
         rot[0, 1], rot[1, 1], rot[2, 1] = two * (x * y - w * z), one - two * (x * x + z * z), two * (y * z + w * x)
         rot[0, 2], rot[1, 2], rot[2, 2] = two * (x * z + w * y), two * (y * z - w * x), one - two * (x * x + y * y)
-        m = (rot @ m).astype(np.float32)
+        m = _mat4_mul(rot, m)
     if n.get("translation"):
         t = np.eye(4, dtype=np.float32)
         t[:3, 3] = np.float32(n["translation"])
-        m = (t @ m).astype(np.float32)
+        m = _mat4_mul(t, m)
     return m
 
 
@@ -151,7 +164,7 @@ def _root_nodes(doc: dict) -> List[dict]:
     flat: List[dict] = []
 
     def visit(node: dict, parent: np.ndarray):
-        transform = (parent @ node_transform(node)).astype(np.float32)
+        transform = _mat4_mul(parent, node_transform(node))
         if "mesh" in node or "camera" in node or "skin" in node:
             out = {k: v for k, v in node.items() if k not in ("children", "scale", "rotation", "translation", "matrix")}
             out["matrix"] = [float(x) for x in transform.T.reshape(16)]

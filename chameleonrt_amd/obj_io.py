@@ -15,6 +15,7 @@ a real ChameleonRT build for cross-checking.
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from typing import Dict, List
@@ -131,6 +132,90 @@ def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int =
     return _assemble_obj_scene(path, base_dir, geoms, material_ids, obj_materials, material_mode, samples_per_pixel)
 
 
+_NUMBER = re.compile(r"[+-]?[0-9]+(\.[0-9]*)?([eE][+-]?[0-9]+)?\Z")
+
+
+def _num(tok: str) -> float:
+    """A coordinate. The grammar is the reference's (tinyobjloader's tryParseDouble, util/tiny_obj_loader.h:567-680): optional
+    sign, at least one digit, optional fraction, optional exponent. What does not parse there (".5", "inf", "1_0") reads as
+    0.0 in the reference; here the file is refused instead of being loaded as something else."""
+    if not _NUMBER.match(tok):
+        raise ValueError(f"not a number in the reference's OBJ grammar: {tok!r}")
+    return float(tok)
+
+
+def _triangulate(corners, positions):
+    """A face's corners -> triangles the way the reference's importer gets them from tinyobjloader
+    (util/tiny_obj_loader.h:1107-1310, triangulate = true at util/scene.cpp:117): ear clipping, not a fan. The polygon is
+    projected on two axes chosen from its first non-degenerate corner; its signed area gives the winding; from corner
+    `guess` on, three consecutive remaining corners (a, b, c) are an ear when the turn at b has the polygon's winding and no
+    other remaining corner lies inside (a, b, c) (crossing-number test); the ear is emitted as (a, b, c), b leaves the ring;
+    a search that has made as many fruitless steps as corners are left gives up (what was emitted stays). float32
+    arithmetic in the reference's order. The native reader (csrc/obj_reader.cpp `triangulate`) is the twin of this."""
+    n = len(corners)
+    if n < 3:
+        return []
+    if n == 3:
+        return [tuple(corners)]
+    f32 = np.float32
+    P = [[f32(x) for x in positions[c[0]]] for c in corners]
+    eps = f32(np.finfo(np.float32).eps)
+    ax0, ax1 = 1, 2
+    for k in range(n):
+        a, b, c = P[k], P[(k + 1) % n], P[(k + 2) % n]
+        e0 = [b[i] - a[i] for i in range(3)]
+        e1 = [c[i] - b[i] for i in range(3)]
+        cx = abs(e0[1] * e1[2] - e0[2] * e1[1])
+        cy = abs(e0[2] * e1[0] - e0[0] * e1[2])
+        cz = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        if cx > eps or cy > eps or cz > eps:
+            if not (cx > cy and cx > cz):
+                ax0 = 0
+                if cz > cx and cz > cy:
+                    ax1 = 1
+            break
+    area = f32(0.0)
+    for k in range(n):
+        a, b = P[k], P[(k + 1) % n]
+        area = area + (a[ax0] * b[ax1] - a[ax1] * b[ax0]) * f32(0.5)
+
+    def inside(vx, vy, tx, ty):
+        c = False
+        j = 2
+        for i in range(3):
+            if (vy[i] > ty) != (vy[j] > ty) and tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]:
+                c = not c
+            j = i
+        return c
+
+    ring = list(range(n))  # indices into corners / P
+    out = []
+    guess, budget, last_size = 0, n, n
+    while len(ring) > 3 and budget > 0:
+        m = len(ring)
+        if guess >= m:
+            guess -= m
+        if last_size != m:
+            last_size, budget = m, m
+        else:
+            budget -= 1
+        tri = [ring[(guess + k) % m] for k in range(3)]
+        vx = [P[t][ax0] for t in tri]
+        vy = [P[t][ax1] for t in tri]
+        cross = (vx[1] - vx[0]) * (vy[2] - vy[1]) - (vy[1] - vy[0]) * (vx[2] - vx[1])
+        if cross * area < f32(0.0):
+            guess += 1
+            continue
+        if any(inside(vx, vy, P[ring[(guess + o) % m]][ax0], P[ring[(guess + o) % m]][ax1]) for o in range(3, m)):
+            guess += 1
+            continue
+        out.append(tuple(corners[t] for t in tri))
+        del ring[(guess + 1) % m]
+    if len(ring) == 3:
+        out.append(tuple(corners[t] for t in ring))
+    return out
+
+
 def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixel: int = 1) -> Scene:
     base_dir = os.path.dirname(os.path.abspath(path))
     positions: List[List[float]] = []
@@ -163,11 +248,11 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
                 continue
             k = tok[0]
             if k == "v":
-                positions.append([float(x) for x in tok[1:4]])
+                positions.append([_num(x) for x in tok[1:4]])
             elif k == "vn":
-                normals.append([float(x) for x in tok[1:4]])
+                normals.append(None)  # counted only: the hot path reads no normals (quirk Q7); the native reader does the same
             elif k == "vt":
-                texcoords.append([float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0])
+                texcoords.append([_num(tok[1]), _num(tok[2]) if len(tok) > 2 else 0.0])
             elif k in ("o", "g"):
                 if cur is not None and not cur["faces"]:
                     continue  # tinyobj does not emit empty shapes
@@ -186,9 +271,9 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
                     ti = resolve(int(parts[1]), len(texcoords)) if len(parts) > 1 and parts[1] else -1
                     ni = resolve(int(parts[2]), len(normals), True) if len(parts) > 2 and parts[2] else -1
                     corners.append((vi, ni, ti))
-                s = shape()
-                for j in range(1, len(corners) - 1):  # triangulate as a fan
-                    s["faces"].append((corners[0], corners[j], corners[j + 1]))
+                for tri in _triangulate(corners, positions):
+                    s = shape()
+                    s["faces"].append(tri)
                     s["mats"].append(cur_mat)
     shapes = [s for s in shapes if s["faces"]]
     if not shapes:

@@ -1,7 +1,7 @@
 /* crt_scene_io.h — C API of the harness's scene-file readers (libcrt_scene_io.so; plain C++, no HIP).
  *
  * the step before set_scene. The reference reads OBJ through tinyobjloader inside
- * Scene::load_obj (util/scene.cpp:94-228); this is the text half of that -- groups, fan triangulation, re-indexing on
+ * Scene::load_obj (util/scene.cpp:94-228); this is the text half of that -- groups, tinyobjloader's ear-clipping triangulation, re-indexing on
  * unique (position, normal, uv) index triples in order of first use, the material name in force at a group's first
  * face -- as a streaming reader that takes a 10 M-triangle file in seconds. Materials, textures, the generated light
  * and the Scene assembly stay in chameleonrt_amd/obj_io.py (scene.cpp:191-227), which binds these entry points with

@@ -45,6 +45,10 @@ def write_files():
                 "o triples\nusemtl over\nf 1/1/1 2/2/1 3/3/2\nf 1/1/2 3/3/2 4/2/2\n"
                 "g tail\nf 1 3 5\n")
     out["obj_quirks"] = p
+    p = os.path.join(SCENES, "polygons.obj")
+    with open(p, "w") as f:  # what tinyobjloader's ear clipping (tiny_obj_loader.h:1107-1310) makes of non-trivial polygons
+        f.write(polygons_obj())
+    out["obj_polygons"] = p
     p = os.path.join(SCENES, "bare.obj")
     with open(p, "w") as f:
         f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
@@ -80,6 +84,63 @@ def write_files():
     save_crts(scenes.instanced_grove(n_instances=12, leaves_per_tree=40, tex_size=8), p)
     out["crts_grove"] = p
     return out
+
+
+def polygons_obj():
+    """Polygons a fan gets wrong or that steer the ear search: a concave quad with the reflex corner at each of the four
+    positions and in both windings, in each of the three projection planes; a concave pentagon, an L, a plus sign, a
+    five-pointed star (10 corners), a spiral; a non-planar quad; collinear runs; a corner used twice; a polygon with all
+    corners on one line (no axes found, no area: nothing is an ear); a bow tie (self-intersecting: the search gives up);
+    a 12-gon with texture coordinates; tiny and huge coordinates. Every face is its own `o` group so that the vertex
+    order the clipping implies shows in each Geometry."""
+    L = ["mtllib quirks.mtl", "vn 0 0 1"]
+    nv = [0]
+
+    def face(name, pts, uv=False, order=None):
+        L.append(f"o {name}")
+        for q in pts:
+            L.append("v %.9g %.9g %.9g" % tuple(q))
+        n = len(pts)
+        if uv:
+            for q in pts:
+                L.append("vt %.9g %.9g" % (q[0] * 0.25, q[1] * 0.25 + q[2]))
+        idx = list(order) if order is not None else list(range(n))
+        base = nv[0] + 1
+        L.append("f " + " ".join(f"{base + i}/{base_uv[0] + i}" if uv else f"{base + i}" for i in idx))
+        nv[0] += n
+        if uv:
+            base_uv[0] += n
+
+    base_uv = [1]
+    dart = [(0, 0), (2, 0.5), (4, 0), (2, 3)]  # concave at corner 1
+    for plane, lift in (("xy", lambda a, b: (a, b, 0.0)), ("yz", lambda a, b: (0.5, a, b)), ("zx", lambda a, b: (b, -1.0, a))):
+        for rot in range(4):
+            for wind in (1, -1):
+                pts = [lift(*dart[(rot + wind * k) % 4]) for k in range(4)]
+                face(f"dart_{plane}_r{rot}_{'ccw' if wind > 0 else 'cw'}", pts)
+    face("pentagon_concave", [(0, 0, 0), (2, 0, 0), (2, 2, 0), (1, 0.5, 0), (0, 2, 0)])
+    face("ell", [(0, 0, 1), (3, 0, 1), (3, 1, 1), (1, 1, 1), (1, 3, 1), (0, 3, 1)], uv=True)
+    face("plus", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (3, 1, 0), (3, 2, 0), (2, 2, 0), (2, 3, 0), (1, 3, 0), (1, 2, 0), (0, 2, 0), (0, 1, 0), (1, 1, 0)])
+    star = [((1.0 if k % 2 == 0 else 0.38) * np.cos(np.pi * k / 5 + 0.3), (1.0 if k % 2 == 0 else 0.38) * np.sin(np.pi * k / 5 + 0.3), 0.1 * k) for k in range(10)]
+    face("star_tilted", star)
+    face("star_cw", star[::-1], uv=True)
+    spiral = [(0, 0), (5, 0), (5, 5), (1, 5), (1, 2), (3, 2), (3, 3), (2, 3), (2, 4), (4, 4), (4, 1), (0, 1)]
+    face("spiral", [(a, 0.25 * a, b) for a, b in spiral])
+    face("nonplanar_quad", [(0, 0, 0), (1, 0, 0.7), (1, 1, -0.4), (0, 1, 0.9)])
+    face("nonplanar_concave", [(0, 0, 0), (0.4, 0.4, 2.0), (1, 0, 0.3), (0, 1, -0.5)])
+    face("collinear_run", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (3, 2, 0), (0, 2, 0)])
+    face("collinear_start", [(0, 0, 0), (1, 1, 1), (2, 2, 2), (3, 3, 3), (3, 0, 3), (0, -1, 0)])
+    face("all_on_a_line", [(0, 0, 0), (1, 1, 0), (2, 2, 0), (3, 3, 0), (4, 4, 0)])
+    face("corner_twice", [(0, 0, 0), (2, 0, 0), (2, 2, 0), (1, 1, 0), (0, 2, 0)], order=[0, 1, 2, 3, 4, 3])
+    face("same_corner_thrice", [(0, 0, 0), (1, 0, 0), (0, 1, 0)], order=[0, 1, 1, 2, 0])
+    face("bow_tie", [(0, 0, 0), (2, 2, 0), (2, 0, 0), (0, 2, 0)])
+    face("bow_tie_hex", [(0, 0, 0), (3, 2, 0), (3, 0, 0), (0, 2, 0), (1.5, 3, 0), (1.5, -1, 0)])
+    face("gon12_uv", [(np.cos(k * np.pi / 6) * (2 + (k % 3 == 0)), np.sin(k * np.pi / 6) * (2 + (k % 3 == 0)), 0.05 * k * k) for k in range(12)], uv=True)
+    face("tiny", [(1e-6 * a, 1e-6 * b, 0) for a, b in dart])
+    face("sub_epsilon", [(1e-4 * a, 1e-4 * b, 0) for a, b in dart])  # every corner's cross product below FLT_EPSILON: default axes (y, z)
+    face("huge", [(1e5 * a + 3e6, 1e5 * b, 7e5) for a, b in dart])
+    face("sliver", [(0, 0, 0), (1000, 1e-3, 0), (2000, 0, 0), (1000, 2e-3, 0)])
+    return "\n".join(L) + "\n"
 
 
 DECODER_IMAGES = ["a420.jpg", "b444.jpg", "cgray.jpg", "dprog.jpg", "e32rle.tga", "f24.tga", "g24top.tga", "hgray.tga",
@@ -137,7 +198,10 @@ def main():
         np.savez_compressed(os.path.join(HERE, "refdecoders_obj.npz"), **{k: v for k, v in d.items() if k.startswith("tex") or k == "counts"})
         print("decoders", dict(zip("mesh pmesh inst mat tex light cam".split(), d["counts"])))
         return
+    only = [a[len("--only="):] for a in sys.argv if a.startswith("--only=")]  # (npz bytes carry time stamps: add a file without touching the others)
     for name, path in write_files().items():
+        if only and name not in only:
+            continue
         for wd in (False, True):
             d = R.load(path, white_diffuse=wd)
             np.savez_compressed(os.path.join(HERE, f"refscene_{name}{'_wd' if wd else ''}.npz"), **d)

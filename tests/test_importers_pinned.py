@@ -8,8 +8,8 @@ under tests/golden/scenes/. Where oracle/_ref/libref_scene.so exists (the develo
 the live library is compared too. The bar: every array bit for bit -- vertices after the
 (position, normal, uv) re-indexing, index buffers, material ids, the 16-float materials with the
 texture handles in their bits, 8-bit texels after the flip / 4-channel rules, the generated or
-loaded lights, cameras -- except instance transforms that went through a matrix product
-(glTF TRS nodes), which may differ in the last bits (float32 product order): <= 2e-6 relative.
+loaded lights, cameras, and the instance transforms, including those that went through matrix
+products (glTF TRS nodes, flattened node trees: gltf_io._mat4_mul multiplies in GLM's order).
 """
 import glob
 import os
@@ -24,7 +24,7 @@ from tests import ref_scene_lib as R
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCENES = os.path.join(HERE, "golden", "scenes")
-FILES = {"obj_cornell": "cornell.obj", "obj_atrium": "atrium.obj", "obj_quirks": "quirks.obj", "obj_bare": "bare.obj",
+FILES = {"obj_cornell": "cornell.obj", "obj_atrium": "atrium.obj", "obj_quirks": "quirks.obj", "obj_bare": "bare.obj", "obj_polygons": "polygons.obj",
          "gltf_scene": "scene.gltf", "glb_scene": "scene.glb", "gltf_tree": "tree.gltf", "crts_handmade": "handmade.crts",
          "crts_nolight": "nolight.crts", "crts_grove": "grove.crts"}
 
@@ -46,9 +46,6 @@ def _compare(ref, mine, what):
         assert a.shape == b.shape, f"{what}: {k} shape {a.shape} vs {b.shape}"
         if a.dtype == np.float32:
             same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
-            if not same and k == "instance_transforms":
-                assert np.allclose(a, b, rtol=2e-6, atol=1e-7), f"{what}: {k}"
-                continue
             assert same, f"{what}: {k} differs (max abs {np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))})"
         else:
             assert np.array_equal(a, b), f"{what}: {k}"
