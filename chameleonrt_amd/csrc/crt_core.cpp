@@ -805,6 +805,11 @@ int crt_hip_render_begin(crt_hip_ctx *ctx, const float pos[3], const float dir_[
         if (fs.pending) {
             return fail(ctx, CRT_HIP_ESTATE, "render_begin: two frames are in flight already; collect one with crt_hip_render_end");
         }
+        if (readback && frames_in_flight(ctx)) {
+            // there is ONE host image (RenderBackend::img): a second frame's copy would overwrite the first one's before its
+            // render_end hands it out. Pipelined callers read tiles / the device framebuffer; a host image wants one frame at a time
+            return fail(ctx, CRT_HIP_ESTATE, "render_begin: readback = 1 while another frame is in flight (one host image): collect it first");
+        }
         if (ctx->capacity == 0) {
             // the queues are (re)carved: nothing of an earlier frame may still be using them
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1330,6 +1335,9 @@ int crt_hip_debug_copy_queue(crt_hip_ctx *ctx, int which, uint64_t first, uint64
         if (!out || ctx->capacity == 0 || which < 0 || which > 2 || first + n > ctx->capacity) {
             return fail(ctx, CRT_HIP_EINVAL, "debug_copy_queue: bad arguments (or no frame rendered yet)");
         }
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "debug_copy_queue while a frame is in flight");
+        }
         const crt_hip_ctx::PassLane &l = ctx->lanes[0];
         const int n_fields = which == 2 ? 7 : 6;
         const float *src[7];
@@ -1354,6 +1362,9 @@ int crt_hip_kat(crt_hip_ctx *ctx, int fn, uint64_t n, const float *in, int in_st
     return guarded(ctx, [&]() -> int {
         if (!in || !out || n == 0 || n > 0x7fffffffull || in_stride <= 0 || out_stride <= 0) {
             return fail(ctx, CRT_HIP_EINVAL, "kat: bad arguments");
+        }
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "kat while a frame is in flight");
         }
         DeviceBuffer d_in, d_out;
         d_in.alloc(n * in_stride * 4);
@@ -1403,6 +1414,9 @@ int crt_hip_bvh_copy(crt_hip_ctx *ctx, void *nodes, void *tris)
     return guarded(ctx, [&]() -> int {
         if (!ctx->has_scene) {
             return fail(ctx, CRT_HIP_ESTATE, "bvh_copy before set_scene");
+        }
+        if (frames_in_flight(ctx)) {
+            return fail(ctx, CRT_HIP_ESTATE, "bvh_copy while a frame is in flight");
         }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (nodes) {

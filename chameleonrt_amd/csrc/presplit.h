@@ -35,10 +35,17 @@ struct P3 {
     float x[3];
 };
 
-// polygon (<= 9 vertices) clipped to the slab lo <= x[a] <= hi
+// polygon clipped to the slab lo <= x[a] <= hi. A triangle cut by three slabs has at most 9 vertices when the arithmetic is
+// exact; clip points are ROUNDED, though, and vertices within rounding of a later plane can make the in / out pattern
+// alternate, each sign change adding a vertex (at most n / 2 more per half-plane). Inputs of more than CLIP_IN vertices are
+// refused (-1: the caller leaves the item uncut), which bounds both stages inside arrays of CLIP_CAP (12 -> 18 -> 27).
+constexpr int CLIP_IN = 12, CLIP_CAP = 32;
 inline int clip_axis(const P3 *in, int n, int a, float lo, float hi, P3 *out)
 {
-    P3 tmp[12];
+    if (n > CLIP_IN) {
+        return -1;
+    }
+    P3 tmp[CLIP_CAP];
     int m = 0;
     for (int i = 0; i < n; ++i) { // keep x[a] >= lo
         const P3 &p = in[i], &q = in[(i + 1) % n];
@@ -138,7 +145,7 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
         area = 0.f;
         const uint32_t sel = s.geom_sel >> SLOT_GEOM_BITS;
         for (int which = 0; which < (s.prim1 == SLOT_NO_SECOND ? 1 : 2); ++which) {
-            P3 a0[12], a1[12];
+            P3 a0[CLIP_CAP], a1[CLIP_CAP];
             if (which == 0) {
                 a0[0] = v[0], a0[1] = v[1], a0[2] = v[2];
             } else {
@@ -148,6 +155,9 @@ inline PresplitStats presplit_items(std::vector<LeafSlot> &recs, std::vector<Aab
             for (int a = 0; a < 3 && n >= 3; ++a) {
                 if (cell.lo[a] > -INFINITY || cell.hi[a] < INFINITY) {
                     n = clip_axis(a0, n, a, cell.lo[a], cell.hi[a], a1);
+                    if (n < 0) {
+                        return false; // a pathological polygon (see clip_axis): no cut for this item
+                    }
                     std::copy(a1, a1 + n, a0);
                 }
             }

@@ -145,6 +145,37 @@ CRT_DEV bool tri_test(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnea
     v = V / abs_den;
     return true;
 }
+// The same test with the barycentrics left undivided: (U, V, |den|). Only t's quotient is needed while walking (it is what
+// hits are compared by); u = U / |den| and v = V / |den| of the BEST hit are formed once, when the ray retires -- the same
+// IEEE divisions on the same operands, so the same bits, but one division per accepted hit instead of three (a division
+// is ~10 instructions; CRT_DEFER_UV).
+CRT_DEV bool tri_test_raw(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnear, float tfar, float &t, float &U_out, float &V_out, float &den_out)
+{
+    const V3 v0 = a, e1 = a - b, e2 = c - a;
+    const V3 Ng = cross3(e2, e1);
+    const V3 C = v0 - O;
+    const V3 R = cross3(C, D);
+    const float den = dot3(Ng, D);
+    const float abs_den = fabsf(den);
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float U = __uint_as_float(__float_as_uint(dot3(R, e2)) ^ sgn);
+    const float V = __uint_as_float(__float_as_uint(dot3(R, e1)) ^ sgn);
+    const float T = __uint_as_float(__float_as_uint(dot3(Ng, C)) ^ sgn);
+    if (den == 0.f) {
+        return false;
+    }
+    if (!(U >= 0.f && V >= 0.f && U + V <= abs_den)) {
+        return false;
+    }
+    if (!(T > abs_den * tnear && T <= abs_den * tfar)) {
+        return false;
+    }
+    t = T / abs_den;
+    U_out = U;
+    V_out = V;
+    den_out = abs_den;
+    return true;
+}
 
 // The four quarters of a leaf slot (crt_types.h LeafSlot) -> its vertices, and triangle B's vertex k (two selector bits).
 struct SlotVerts {
@@ -218,6 +249,11 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_POOL_CHUNK_MIN
 #define CRT_POOL_CHUNK_MIN 16
 #endif
+// closest-hit kernels of single trees and world trees: divide the best hit's barycentrics at retire (tri_test_raw): C4
+// closest-hit 24.37 -> 23.90 ms, C2 / C3 +-0 (sessions r5s3, r5s4); 0 = three divisions per accepted hit, as in rounds 1-4
+#ifndef CRT_DEFER_UV
+#define CRT_DEFER_UV 1
+#endif
 // two-level scenes: 0 = instances are entered in the leaf phase; 1 = in the inner-node phase (see there) -- measured
 // 16 % SLOWER on the instanced C4 (123.2 vs 105.9 ms): the entry's transform and frame change then sit in the hot
 // loop that most iterations run, for the few lanes that need them
@@ -266,7 +302,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
 #endif
     constexpr bool PROF = COUNTERS || CRT_PHASE_PROFILE != 0;
     // (32-bit cycle sums -- a launch is far shorter than 2^32 cycles per phase -- and only the counts that differ: nine SGPRs)
-    uint32_t pf_cyc[4] = {0, 0, 0, 0};
+    uint32_t pf_cyc[4] = {0, 0, 0, 0}; // (32-bit sums per wave: they wrap after 2^32 shader clocks, ~1.8 s of one wave's life -- far beyond a launch)
     uint32_t pf_inner_steps = 0, pf_outer = 0, pf_inner_lanes = 0, pf_leaf_lanes_sum = 0;
     uint32_t pf_t = PROF ? (uint32_t)clock64() : 0u;
     auto pf_mark = [&](int phase, uint32_t lanes) {
@@ -370,6 +406,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
     // wave-uniform pool of ray indices
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
+    constexpr bool DEFER_UV = CRT_DEFER_UV != 0 && !ANY_HIT && !TWO_LEVEL;
+    float hit_den = 1.f; // DEFER_UV: |den| of the best hit, whose hit.u / hit.v then hold U and V undivided
     const int32_t top_lo = sc.root, top_hi = sc.root + (int32_t)sc.n_top_nodes; // host: n_top_nodes <= CRT_MAX_TOP_NODES
 
     // Box tests use 1/d with |d| clamped to >= 1e-18 (sign kept): with an exactly zero component
@@ -440,7 +478,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
             uint32_t base = 0;
             uint32_t chunk = (uint32_t)CRT_POOL_CHUNK;
             if (CRT_POOL_GUIDED) {
-                const uint32_t shift = 32u - (uint32_t)__builtin_clz(2u * gridDim.x * (blockDim.x >> 6) - 1u);
+                // (blocks of the traversal kernels hold whole waves, TRACE_BLOCK = 256; the clamp keeps the shift defined for any block)
+                const uint32_t shift = min(31u, 32u - (uint32_t)__builtin_clz((max(1u, 2u * gridDim.x * (blockDim.x >> 6)) - 1u) | 1u));
                 chunk = min((uint32_t)CRT_POOL_CHUNK, max((uint32_t)CRT_POOL_CHUNK_MIN, (((n - pool_end) >> shift) + 15u) & ~15u));
             }
             if (tv_lane_id() == 0) {
@@ -688,7 +727,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                         }
                     }
                     const SlotVerts sv = slot_verts(q0, q1, q2);
-                    auto accept = [&](float t, float u, float v, uint32_t prim, uint32_t which) {
+                    auto accept = [&](float t, float u, float v, uint32_t prim, uint32_t which, float den = 1.f) {
                         bool take = t < hit.t;
                         if (t == hit.t && hit.tri >= 0) { // exact tie with the best hit so far: (inst, geom, prim) decides
                             take = tie_break(cur_inst, geom, prim);
@@ -702,29 +741,34 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                                 hit.inst = cur_inst;
                             }
                             store_hit_cold(u, v);
+                            if (DEFER_UV) {
+                                hit_den = den;
+                            }
                         }
                     };
                     float t, u, v;
                     if (COUNTERS) {
                         ++n_tris;
                     }
-                    if (tri_test(sv.p0, sv.p1, sv.p2, o, d, tnear, tfar, t, u, v)) {
+                    float den_abs = 1.f;
+                    if (DEFER_UV ? tri_test_raw(sv.p0, sv.p1, sv.p2, o, d, tnear, tfar, t, u, v, den_abs) : tri_test(sv.p0, sv.p1, sv.p2, o, d, tnear, tfar, t, u, v)) {
                         if (ANY_HIT) {
                             occluded = true;
                             return;
                         }
-                        accept(t, u, v, prim0, 0u);
+                        accept(t, u, v, prim0, 0u, den_abs);
                     }
                     if (prim1 != SLOT_NO_SECOND) {
                         if (COUNTERS) {
                             ++n_tris;
                         }
-                        if (tri_test(slot_pick(sv, sel), slot_pick(sv, sel >> 2), slot_pick(sv, sel >> 4), o, d, tnear, tfar, t, u, v)) {
+                        if (DEFER_UV ? tri_test_raw(slot_pick(sv, sel), slot_pick(sv, sel >> 2), slot_pick(sv, sel >> 4), o, d, tnear, tfar, t, u, v, den_abs)
+                                     : tri_test(slot_pick(sv, sel), slot_pick(sv, sel >> 2), slot_pick(sv, sel >> 4), o, d, tnear, tfar, t, u, v)) {
                             if (ANY_HIT) {
                                 occluded = true;
                                 return;
                             }
-                            accept(t, u, v, prim1, 1u);
+                            accept(t, u, v, prim1, 1u, den_abs);
                         }
                     }
                 };
@@ -783,6 +827,10 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
             if (TWO_LEVEL) {
                 hit.u = st.cold[6 * st.stride];
                 hit.v = st.cold[7 * st.stride];
+            }
+            if (DEFER_UV && hit.tri >= 0) { // the best hit's barycentrics: the divisions tri_test would have made when it was found
+                hit.u = hit.u / hit_den;
+                hit.v = hit.v / hit_den;
             }
             V3 wo = world_org(), wd = world_dir();
             uint32_t stage = 0, carry = 0;

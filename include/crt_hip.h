@@ -227,7 +227,8 @@ int crt_hip_render(crt_hip_ctx *ctx, const float pos[3], const float dir[3], con
  * the context's stream(s) and returns without waiting; crt_hip_render_end waits for the OLDEST frame in flight and fills
  * its statistics (render_time_ms is then the GPU's time from the frame's first to its last event). At most two frames may
  * be in flight; results are identical to crt_hip_render's (same launches, same order on the stream). While frames are in
- * flight only render_begin / render_end / tile_buffer / assemble_tiles / device_framebuffer may be called. The tile
+ * flight only render_begin / render_end / tile_buffer / assemble_tiles / device_framebuffer may be called (the others
+ * return CRT_HIP_ESTATE), and a frame with readback = 1 is refused while another is pending (there is one host image). The tile
  * buffer of a frame (crt_hip_tile_buffer right after its render_begin) is reused by the frame after the next one:
  * its gather must have been ordered before that frame is enqueued. No reference counterpart (the reference's render()
  * is synchronous, render_embree.cpp:135-216). */
