@@ -285,6 +285,9 @@ template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
+    if (pool_block_is_idle(pc->n_queue[bounce])) {
+        return; // (the queue ends before this block's first chunk: traverse.h)
+    }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
@@ -373,6 +376,9 @@ template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
+    if (pool_block_is_idle(pc->n_shadow_a[bounce])) {
+        return; // (the queue ends before this block's first chunk: traverse.h)
+    }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
@@ -472,12 +478,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                                                        PassCounters *pc, int bounce)
 {
     __shared__ ShadeStage stage;
+    // The grid is sized for the pass (the host does not know the queue's size): from the second bounce on a growing share of the
+    // blocks has nothing to do -- half of them on C3's bounce 1, 99 % on any bounce 4 -- and leaves before it sets anything up.
+    const uint32_t n = pc->n_queue[bounce];
+    if (CRT_IDLE_EXIT && blockIdx.x * blockDim.x >= n) {
+        return;
+    }
     if (threadIdx.x == 0) {
         stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = 0;
     }
     unorm8_init(); // (ends with the barrier that also publishes the counters)
     uint32_t parity = 0;
-    const uint32_t n = pc->n_queue[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
@@ -824,6 +835,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
                                                             int32_t *out_inst, int32_t *out_geom, int32_t *out_prim,
                                                             unsigned long long *counters)
 {
+    if (pool_block_is_idle(n)) {
+        return; // (the queue ends before this block's first chunk: traverse.h)
+    }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
     TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;

@@ -243,11 +243,20 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_POOL_CHUNK
 #define CRT_POOL_CHUNK 128
 #endif
-#ifndef CRT_POOL_GUIDED
-#define CRT_POOL_GUIDED 0
-#endif
-#ifndef CRT_POOL_CHUNK_MIN
-#define CRT_POOL_CHUNK_MIN 16
+// How a wave gets its chunks of the queue (CRT_POOL_STATIC_FIRST, round 5). Wave w of the grid OWNS chunk w from the start -- no
+// atomic -- and only the chunks beyond the grid's first helping are handed out by the cursor (which counts chunks, starting
+// after those). Before, a launch BEGAN with every wave of the grid (7 168) asking one word for its first chunk at the same
+// instant; same-address atomics retire at ~88 per microsecond on this chip (MI355X_MICROARCH.md "dequeue"), so the last wave
+// started tracing ~80 us into the launch, and a queue smaller than the grid's first helping -- the late bounces of small
+// frames, a rank's share at N = 8 -- paid for all of them all the same. C2 7.55 -> 6.85 ms, C3 9.21 -> 8.54, C4's eighth
+// 9.79 -> 8.65, C4 -0.2 % (sessions r5s5, r5s6; profiles/r05_static_first_chunk_ab.txt). Chunks are dealt in the same order as
+// before (consecutive chunks to consecutive waves); any dealing gives the same image.
+// Tried on top of it and dropped: reading the cursor (agent scope) before asking near the end of the queue, to spare the
+// launch the failing atomic every wave ENDS with -- the load costs more than the atomic (C2 6.96 -> 8.1 ms, C3 8.49 -> 9.0);
+// dealing a queue smaller than the first helping out evenly (chunks of ceil(n / waves) >= 64 rays: one generation of rays
+// instead of two over half the waves) -- no difference on C2, C3, C4 or C4's eighth.
+#ifndef CRT_POOL_STATIC_FIRST
+#define CRT_POOL_STATIC_FIRST 1
 #endif
 // closest-hit kernels of single trees and world trees: divide the best hit's barycentrics at retire (tri_test_raw): C4
 // closest-hit 24.37 -> 23.90 ms, C2 / C3 +-0 (sessions r5s3, r5s4); 0 = three divisions per accepted hit, as in rounds 1-4
@@ -267,6 +276,17 @@ CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_
 CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Has the block that holds waves [blockIdx.x * waves per block, ...) anything to do at all? With a static first helping, a
+// queue that ends before the block's first wave's own chunk never reaches it (there are no dynamic chunks then either): such
+// a block leaves before it stages anything (the late bounces of every frame: most blocks of the grid).
+#ifndef CRT_IDLE_EXIT
+#define CRT_IDLE_EXIT 1 // (0: every block sets itself up, as before -- the A/B switch of this and of k_shade's early exit)
+#endif
+CRT_DEV bool pool_block_is_idle(uint32_t n)
+{
+    return CRT_IDLE_EXIT && CRT_POOL_STATIC_FIRST && (uint64_t)(blockIdx.x * (blockDim.x >> 6)) * (uint32_t)CRT_POOL_CHUNK >= n;
 }
 
 // Source: struct with
@@ -467,34 +487,32 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
 
     // up to `want` ray indices [pool_next, pool_next + take) of the wave's pool, which is topped up from the queue cursor
     // (one atomic per CRT_POOL_CHUNK rays) when it is empty; the caller advances pool_next by what it uses
-    // GUIDED chunks (CRT_POOL_GUIDED): a wave asks for less as the queue runs out -- (what was left when it last asked) /
-    // (the next power of two above 2 x waves of the grid), between CRT_POOL_CHUNK_MIN and CRT_POOL_CHUNK -- so that the last
-    // rays of a launch are spread over all waves instead of sitting two deep in the pools of a few, and a queue smaller
-    // than the grid's appetite (bounce 4: 0.3 M rays for 6 144 waves) is dealt out one ray per lane. The estimate is
-    // one fetch old (n - the end of the wave's previous chunk) and costs no register: the shift is recomputed from the
-    // grid size at each fetch (scalar, once per chunk). Any chunk size gives the same image.
+    // (guided, shrinking chunks -- round 4, a measured loss: profiles/r04_guided_chunks_ab.txt -- are gone)
+    const uint32_t pool_waves = gridDim.x * (blockDim.x >> 6); // waves of the grid
+    bool pool_first = CRT_POOL_STATIC_FIRST != 0;               // the wave's own chunk is still to come
     auto pool_take = [&](uint32_t want) -> uint32_t {
         if (pool_next == pool_end && !exhausted) {
-            uint32_t base = 0;
-            uint32_t chunk = (uint32_t)CRT_POOL_CHUNK;
-            if (CRT_POOL_GUIDED) {
-                // (blocks of the traversal kernels hold whole waves, TRACE_BLOCK = 256; the clamp keeps the shift defined for any block)
-                const uint32_t shift = min(31u, 32u - (uint32_t)__builtin_clz((max(1u, 2u * gridDim.x * (blockDim.x >> 6)) - 1u) | 1u));
-                chunk = min((uint32_t)CRT_POOL_CHUNK, max((uint32_t)CRT_POOL_CHUNK_MIN, (((n - pool_end) >> shift) + 15u) & ~15u));
+            constexpr uint32_t chunk = (uint32_t)CRT_POOL_CHUNK;
+            uint32_t c; // chunk index
+            if (pool_first) {
+                pool_first = false;
+                c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+            } else {
+                uint32_t ticket = 0;
+                if (tv_lane_id() == 0) {
+                    ticket = atomicAdd(cursor, 1u);
+                }
+                c = (CRT_POOL_STATIC_FIRST ? pool_waves : 0u) + __builtin_amdgcn_readfirstlane(ticket);
             }
-            if (tv_lane_id() == 0) {
-                base = atomicAdd(cursor, chunk);
-            }
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= n) {
+            if ((uint64_t)c * chunk >= n) {
                 if (COUNTERS && t_marks != nullptr && tv_lane_id() == 0) {
                     atomicMin(&t_marks[MAX_PATH_DEPTH], (unsigned long long)wall_clock64());
                 }
                 exhausted = true;
                 pool_next = pool_end = 0;
             } else {
-                pool_next = base;
-                pool_end = min(base + chunk, n);
+                pool_next = c * chunk;
+                pool_end = min(pool_next + chunk, n);
             }
         }
         return min(want, pool_end - pool_next);

@@ -227,12 +227,12 @@ def test_pipelined_frames_equal_synchronous_frames(hip_lib):
                     b.render_begin(e, d, u, fovy, False, False)
                 with pytest.raises(core.CoreError, match="in flight"):
                     b.initialize(w, h)
-            if f == 4:  # one frame pending: a frame WITH host readback is refused (one host image), so are the debugging entry points
+            piped.append(b.render_end().rays)
+            if f == 4:  # ONE frame pending now: a frame WITH host readback is refused (one host image), so are the debugging entry points
                 with pytest.raises(core.CoreError, match="one host image"):
                     b.render_begin(e, d, u, fovy, False, True)
                 with pytest.raises(core.CoreError, match="in flight"):
                     b.bvh()
-            piped.append(b.render_end().rays)
         st = b.render_end()
         piped.append(st.rays)
         with pytest.raises(core.CoreError, match="without a frame in flight"):
