@@ -672,7 +672,7 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
     hipEvent_t e0 = get_event(ctx, 0), e1 = get_event(ctx, 1);
     float *base = d_rays.as<float>();
     if (closest) {
-        pc.n_queue[bounce] = (uint32_t)n;
+        pc.n_queue[bounce].v = (uint32_t)n;
         HIP_CHECK(hipMemcpyAsync(d_pc.ptr, &pc, sizeof(pc), hipMemcpyHostToDevice, s));
         PathQueue q{};
         for (int a = 0; a < 3; ++a) {
@@ -704,7 +704,7 @@ int trace_rays_production(crt_hip_ctx *ctx, uint64_t n, const float *org, const 
             out_prim[i] = tri < 0 ? -1 : (int32_t)((tri & 1) != 0 ? sl.prim1 : sl.prim0);
         }
     } else {
-        pc.n_shadow_a[bounce] = (uint32_t)n;
+        pc.n_shadow_a[bounce].v = (uint32_t)n;
         HIP_CHECK(hipMemcpyAsync(d_pc.ptr, &pc, sizeof(pc), hipMemcpyHostToDevice, s));
         // one ShadowQueueA item per ray, contribution (1, 0, 0), no second ray: a visible ray leaves radiance.x = 1
         std::vector<float4> extra(n);
@@ -1013,10 +1013,10 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
         for (uint32_t p = 0; p < pass; ++p) {
             const PassCounters &pc = h_pc[p];
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
-                st.closest_rays += pc.n_queue[b];
-                st.shadow_rays += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
-                st.closest_rays_bounce[b] += pc.n_queue[b];
-                st.shadow_rays_bounce[b] += (uint64_t)pc.n_shadow_a[b] + pc.n_shadow_b[b];
+                st.closest_rays += pc.n_queue[b].v;
+                st.shadow_rays += (uint64_t)pc.n_shadow_a[b].v + pc.n_shadow_b[b].v;
+                st.closest_rays_bounce[b] += pc.n_queue[b].v;
+                st.shadow_rays_bounce[b] += (uint64_t)pc.n_shadow_a[b].v + pc.n_shadow_b[b].v;
             }
             st.closest_nodes += pc.nodes_closest;
             st.closest_tris += pc.tris_closest;
@@ -1052,7 +1052,7 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
             }
             for (int b = 0; b < MAX_PATH_DEPTH; ++b) {
                 std::fprintf(stderr, "[crt_hip] frame %u bounce %d: closest %u shadow_a %u shadow_b %u\n", frame_id,
-                             b, pc.n_queue[b], pc.n_shadow_a[b], pc.n_shadow_b[b]);
+                             b, pc.n_queue[b].v, pc.n_shadow_a[b].v, pc.n_shadow_b[b].v);
             }
         }
         if (back_to_back) {

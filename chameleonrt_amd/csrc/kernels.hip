@@ -145,7 +145,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
         for (int w = 0; w < SHADE_BLOCK / 64; ++w) {
             total += s_wave[w];
         }
-        s_base = total ? atomicAdd(&pc->n_queue[0], total) : 0u;
+        s_base = total ? atomicAdd(&pc->n_queue[0].v, total) : 0u;
     }
     __syncthreads();
     uint32_t running = s_base;
@@ -285,7 +285,7 @@ template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_closest(SceneView sc, PathQueue q, HitBuf hits,
                                                                PassCounters *pc, int bounce)
 {
-    if (pool_block_is_idle(pc->n_queue[bounce])) {
+    if (pool_block_is_idle(pc->n_queue[bounce].v)) {
         return; // (the queue ends before this block's first chunk: traverse.h)
     }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
     const ClosestSource<levels_of(TWO_LEVEL, INST_TRIS)> src{q, hits, sc.slots, sc.instances, sc.material_ids};
-    trace_wavefront<false, TWO_LEVEL, COUNTERS, ClosestSource<levels_of(TWO_LEVEL, INST_TRIS)>, INST_TRIS>(sc, top, st, pc->n_queue[bounce], &pc->cur_closest[bounce],
+    trace_wavefront<false, TWO_LEVEL, COUNTERS, ClosestSource<levels_of(TWO_LEVEL, INST_TRIS)>, INST_TRIS>(sc, top, st, pc->n_queue[bounce].v, &pc->cur_closest[bounce].v,
                                                                           tnear, src, n_nodes, n_tris, n_slots, &pc->max_ray_nodes,
                                                                           pc->worst_ray, &pc->t_start[bounce], &pc->prof_cycles[0][0]);
     if (COUNTERS) {
@@ -376,7 +376,7 @@ template <bool TWO_LEVEL, bool COUNTERS, bool INST_TRIS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shadow(SceneView sc, ShadowQueueA sa, ShadowQueueB sb,
                                                               float4 *radiance, PassCounters *pc, int bounce)
 {
-    if (pool_block_is_idle(pc->n_shadow_a[bounce])) {
+    if (pool_block_is_idle(pc->n_shadow_a[bounce].v)) {
         return; // (the queue ends before this block's first chunk: traverse.h)
     }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
                                   (threadIdx.x & 63));
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
     const ShadowSource src{sa, sb, radiance};
-    trace_wavefront<true, TWO_LEVEL, COUNTERS, ShadowSource, INST_TRIS>(sc, top, st, pc->n_shadow_a[bounce], &pc->cur_shadow_a[bounce],
+    trace_wavefront<true, TWO_LEVEL, COUNTERS, ShadowSource, INST_TRIS>(sc, top, st, pc->n_shadow_a[bounce].v, &pc->cur_shadow_a[bounce].v,
                                                                         RAY_EPS, src, n_nodes, n_tris, n_slots, nullptr, nullptr, nullptr,
                                                                         &pc->prof_cycles[1][0]);
     if (COUNTERS) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
     __shared__ ShadeStage stage;
     // The grid is sized for the pass (the host does not know the queue's size): from the second bounce on a growing share of the
     // blocks has nothing to do -- half of them on C3's bounce 1, 99 % on any bounce 4 -- and leaves before it sets anything up.
-    const uint32_t n = pc->n_queue[bounce];
+    const uint32_t n = pc->n_queue[bounce].v;
     if (CRT_IDLE_EXIT && blockIdx.x * blockDim.x >= n) {
         return;
     }
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
 
         // Phase 2 (wave-uniform): stage the occlusion rays.
         // B rays are rare: straight to HBM with one atomic per wave that has any.
-        const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce], has_b);
+        const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce].v, has_b);
         if (has_b) {
             sb.o[0][slot_b] = hit_p.x;
             sb.o[1][slot_b] = hit_p.y;
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         // OTHER parity (last read before the previous step's final barrier) are zeroed for the next step
         if (threadIdx.x == 0) {
             const uint32_t na = stage.cnt_a[parity], nn = stage.cnt_next[parity];
-            stage.base = na ? atomicAdd(&pc->n_shadow_a[bounce], na) : 0u;
-            stage.base_next = nn ? atomicAdd(&pc->n_queue[bounce + 1], nn) : 0u;
+            stage.base = na ? atomicAdd(&pc->n_shadow_a[bounce].v, na) : 0u;
+            stage.base_next = nn ? atomicAdd(&pc->n_queue[bounce + 1].v, nn) : 0u;
             stage.cnt_a[parity ^ 1u] = 0;
             stage.cnt_next[parity ^ 1u] = 0;
         }

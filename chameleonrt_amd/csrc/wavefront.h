@@ -69,13 +69,25 @@ struct ShadowQueueB {
     int32_t *reserved;
 };
 
+// A counter that thousands of waves add to. Atomics on one address retire at ~88 per microsecond on this chip, and the unit
+// that executes them is found by the address's cache line: with all of a pass's queue sizes and cursors in ONE 128-byte line
+// (rounds 1-4) the appends of k_shade (two per 256 items), the chunk fetches of a closest-hit launch and those of the occlusion
+// launch running next to it all queued up behind each other. Each hot counter now has a line pair of its own
+// (CRT_COUNTER_ALIGN; 4 = the old, packed layout, for A/B).
+#ifndef CRT_COUNTER_ALIGN
+#define CRT_COUNTER_ALIGN 256
+#endif
+struct alignas(CRT_COUNTER_ALIGN) HotCounter {
+    uint32_t v;
+};
+
 struct PassCounters {
-    uint32_t n_queue[MAX_PATH_DEPTH + 1]; // closest-hit rays entering bounce b
-    uint32_t n_shadow_a[MAX_PATH_DEPTH];
-    uint32_t n_shadow_b[MAX_PATH_DEPTH];
-    uint32_t cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
-    uint32_t cur_shadow_a[MAX_PATH_DEPTH];
-    uint32_t cur_shadow_b[MAX_PATH_DEPTH];
+    HotCounter n_queue[MAX_PATH_DEPTH + 1]; // closest-hit rays entering bounce b
+    HotCounter n_shadow_a[MAX_PATH_DEPTH];
+    HotCounter n_shadow_b[MAX_PATH_DEPTH];
+    HotCounter cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
+    HotCounter cur_shadow_a[MAX_PATH_DEPTH];
+    HotCounter cur_shadow_b[MAX_PATH_DEPTH];
     uint32_t max_ray_nodes; // CRT_HIP_FLAG_COUNTERS: most node fetches spent on one ray, and that ray
     unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow; // CRT_HIP_FLAG_COUNTERS
     unsigned long long slots_closest, slots_shadow;                            // leaf slots fetched (1-2 triangles each)
