@@ -57,24 +57,8 @@ CRT_DEV uint32_t lanes_below(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Compacting append: every lane of the wave must call this (wave-uniform control flow). Lanes
-// with pred get consecutive slots; one atomic per wave. Returns the slot (undefined if !pred).
-CRT_DEV uint32_t wave_append(uint32_t *counter, bool pred)
-{
-    const uint64_t mask = __ballot(pred);
-    if (mask == 0) {
-        return 0;
-    }
-    const uint32_t rank = lanes_below(mask);
-    const int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane_id() == leader) {
-        base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    }
-    base = __shfl(base, leader);
-    return base + rank;
-}
-// Same compaction as wave_append but on an LDS counter (cheap, no memory-side atomic).
+// Compacting append on an LDS counter: every lane of the wave must call this (wave-uniform control flow); lanes with pred get
+// consecutive slots (undefined if !pred). No memory-side atomic: a block reserves its queue space once per step.
 CRT_DEV uint32_t wave_append_lds(uint32_t *lds_counter, bool pred)
 {
     const uint64_t mask = __ballot(pred);
@@ -468,6 +452,7 @@ struct ShadeStage {
     uint32_t next[11][STAGE_CAP]; // PathQueue fields in declaration order
     uint32_t a[12][STAGE_CAP];    // ShadowQueueA: o, d, tmax (its seven SoA fields in declaration order), c.xyz, path | has_b, slot in ShadowQueueB
     uint32_t cnt_a[2], cnt_next[2]; // entries staged in this step; the counters alternate with the step's parity
+    uint32_t cnt_b[2];              // B rays written in this step (counted for the ray statistics only)
     uint32_t base, base_next;       // where the step's entries go in the global queues
 };
 static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 9 * sizeof(void *) && offsetof(ShadowQueueA, cp) == 7 * sizeof(void *),
@@ -485,7 +470,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         return;
     }
     if (threadIdx.x == 0) {
-        stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = 0;
+        stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = stage.cnt_b[0] = stage.cnt_b[1] = 0;
     }
     unorm8_init(); // (ends with the barrier that also publishes the counters)
     uint32_t parity = 0;
@@ -577,8 +562,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         }
 
         // Phase 2 (wave-uniform): stage the occlusion rays.
-        // B rays are rare: straight to HBM with one atomic per wave that has any.
-        const uint32_t slot_b = wave_append(&pc->n_shadow_b[bounce].v, has_b);
+        // B rays go straight to HBM, into the slot of ShadowQueueB that carries the item's own index in the input queue: the
+        // queue is only ever reached through the slot an A record names, so it need not be dense, and no slot has to be
+        // reserved. (Rounds 1-4 compacted it with one memory-side atomic per wave that had a B ray, "rare" being true of C4 --
+        // one hit in 10^5 -- and false of C2, whose light is large and near: 8 % of the hits, i.e. practically every wave,
+        // 58 k atomics on one word per 0.6 ms launch = the chip's limit for one address, and half of k_shade's time there.)
+        // The count is kept for the ray statistics: per block, with the step's other appends.
+        // C2 7.0 -> 6.0 ms with this and the counters' own lines, C3 / C4 +-0 (sessions r5s9, r5s13).
+        const uint32_t slot_b = i;
+        {
+            const uint64_t b_mask = __ballot(has_b);
+            if (b_mask != 0 && lane_id() == 0) {
+                atomicAdd(&stage.cnt_b[parity], (uint32_t)__popcll(b_mask));
+            }
+        }
         if (has_b) {
             sb.o[0][slot_b] = hit_p.x;
             sb.o[1][slot_b] = hit_p.y;
@@ -673,8 +670,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             const uint32_t na = stage.cnt_a[parity], nn = stage.cnt_next[parity];
             stage.base = na ? atomicAdd(&pc->n_shadow_a[bounce].v, na) : 0u;
             stage.base_next = nn ? atomicAdd(&pc->n_queue[bounce + 1].v, nn) : 0u;
+            if (stage.cnt_b[parity] != 0u) {
+                atomicAdd(&pc->n_shadow_b[bounce].v, stage.cnt_b[parity]);
+            }
             stage.cnt_a[parity ^ 1u] = 0;
             stage.cnt_next[parity ^ 1u] = 0;
+            stage.cnt_b[parity ^ 1u] = 0;
         }
         __syncthreads();
         {
