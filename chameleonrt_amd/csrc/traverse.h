@@ -119,36 +119,10 @@ typedef uint32_t tv_u4 __attribute__((ext_vector_type(4))); // plain vector: loa
 // (a, b, c): the triangle's vertices in its index order. e1 = v0 - v1, e2 = v2 - v0 are formed here from
 // the leaf slot's vertices -- the IEEE subtractions the host made for the 48-byte records of rounds 1-2, so every bit of
 // t / u / v is what it was.
-CRT_DEV bool tri_test(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnear, float tfar, float &t, float &u, float &v)
-{
-    const V3 v0 = a, e1 = a - b, e2 = c - a;
-    const V3 Ng = cross3(e2, e1);
-    const V3 C = v0 - O;
-    const V3 R = cross3(C, D);
-    const float den = dot3(Ng, D);
-    const float abs_den = fabsf(den);
-    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-    const float U = __uint_as_float(__float_as_uint(dot3(R, e2)) ^ sgn);
-    const float V = __uint_as_float(__float_as_uint(dot3(R, e1)) ^ sgn);
-    const float T = __uint_as_float(__float_as_uint(dot3(Ng, C)) ^ sgn);
-    if (den == 0.f) {
-        return false;
-    }
-    if (!(U >= 0.f && V >= 0.f && U + V <= abs_den)) {
-        return false;
-    }
-    if (!(T > abs_den * tnear && T <= abs_den * tfar)) {
-        return false;
-    }
-    t = T / abs_den;
-    u = U / abs_den;
-    v = V / abs_den;
-    return true;
-}
-// The same test with the barycentrics left undivided: (U, V, |den|). Only t's quotient is needed while walking (it is what
-// hits are compared by); u = U / |den| and v = V / |den| of the BEST hit are formed once, when the ray retires -- the same
-// IEEE divisions on the same operands, so the same bits, but one division per accepted hit instead of three (a division
-// is ~10 instructions; CRT_DEFER_UV).
+// tri_test_raw leaves the barycentrics undivided -- (U, V, |den|): only t's quotient is needed while walking (it is what hits are
+// compared by); u = U / |den| and v = V / |den| of the BEST hit are formed once, when the ray retires -- the same IEEE divisions on
+// the same operands, so the same bits, but one division per accepted hit instead of three (a division is ~10 instructions;
+// CRT_DEFER_UV). tri_test divides at once (occlusion rays never look at u, v; the two-level kernels keep them in LDS).
 CRT_DEV bool tri_test_raw(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnear, float tfar, float &t, float &U_out, float &V_out, float &den_out)
 {
     const V3 v0 = a, e1 = a - b, e2 = c - a;
@@ -174,6 +148,16 @@ CRT_DEV bool tri_test_raw(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float 
     U_out = U;
     V_out = V;
     den_out = abs_den;
+    return true;
+}
+CRT_DEV bool tri_test(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float tnear, float tfar, float &t, float &u, float &v)
+{
+    float U, V, abs_den;
+    if (!tri_test_raw(a, b, c, O, D, tnear, tfar, t, U, V, abs_den)) {
+        return false;
+    }
+    u = U / abs_den;
+    v = V / abs_den;
     return true;
 }
 
