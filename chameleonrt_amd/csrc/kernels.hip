@@ -512,7 +512,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
                 is_hit = true;
                 const float t = h0.x, bu = h0.y, bv = h0.z;
                 const float4 h1 = hits.rec[2 * (size_t)i + 1]; // {normal, material}: K2 ran ispc:269-270, 288-293
+#ifdef CRT_EXP_SHADE_ONE_MAT // TIMING EXPERIMENT ONLY (wrong image): every hit of a wave takes the material of the wave's first hit -- what material divergence costs
+                const uint32_t mat_word = __builtin_amdgcn_readfirstlane(__float_as_uint(h1.w));
+#else
                 const uint32_t mat_word = __float_as_uint(h1.w);
+#endif
                 const uint32_t mat_id = mat_word & ~MATERIAL_TEXTURED;
                 w_o = -d;
                 hit_p = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); // ispc:264-267
