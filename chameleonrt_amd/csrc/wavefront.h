@@ -8,10 +8,11 @@
 //                              RNG state, throughput                       11 dwords / ray
 //   HitBuf                     t, u, v, triangle index | shading normal, material: ONE 32-byte record / ray
 //   ShadowQueueA               light-sample occlusion rays (one per hit)   12 dwords / ray (7 SoA + one 16-byte record + 1)
-//   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare) 18 dwords / ray
+//   ShadowQueueB               BSDF-sample-hits-light occlusion rays (rare on C4, 8 % of C2's hits) 18 dwords / ray; NOT dense:
+//                              a record sits at its item's index in the shading kernel's input queue (no slot reservation)
 //   radiance                   float4 per path: rgb = radiance so far, w = rays traced
 //
-// Queue sizes are produced on the device (wave ballot + one atomic per wave) and never read
+// Queue sizes are produced on the device (ballot + LDS ranks, one atomic per block and queue) and never read
 // by the host between bounces: every kernel takes its element count from PassCounters.
 #pragma once
 #include "crt_types.h"
