@@ -88,8 +88,12 @@ RenderHIP::RenderHIP()
         throw std::runtime_error("RenderHIP: libcrt_hip_core.so speaks ABI " + std::to_string(crt_hip_abi_version()) +
                                  ", this plugin was built for ABI " + std::to_string(CRT_HIP_ABI_VERSION));
     }
+    // CRT_HIP_ELIDE=1: do not trace the occlusion rays whose answer the reference never looks at (same image, same ray
+    // statistics; include/crt_hip.h CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS). Off by default: the backend then traces what Embree traces.
+    const char *elide = std::getenv("CRT_HIP_ELIDE");
+    const uint32_t flags = (elide != nullptr && elide[0] == '1') ? (uint32_t)CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS : (uint32_t)CRT_HIP_FLAG_NONE;
     for (int d = 0; d < n; ++d) {
-        crt_hip_ctx *c = crt_hip_create(d, CRT_HIP_FLAG_NONE);
+        crt_hip_ctx *c = crt_hip_create(d, flags);
         if (!c) {
             throw std::runtime_error(std::string("RenderHIP: ") + crt_hip_last_error(nullptr));
         }

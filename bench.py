@@ -187,6 +187,7 @@ def timed_frames(loop, args, dist, first_frame):
         acc["rays"] += st.rays
         acc["closest_rays"] += st.closest_rays
         acc["shadow_rays"] += st.shadow_rays
+        acc["shadow_rays_elided"] = acc.get("shadow_rays_elided", 0) + st.shadow_rays_elided
         acc["closest_ms"] += st.closest_ms
         acc["shadow_ms"] += st.shadow_ms
         acc["shade_ms"] += st.shade_ms
@@ -409,6 +410,26 @@ def main():
                             other_sched: {"ms_per_step": round(e2 / args.steps * 1e3, 4), "value": round(rays2 / e2 / 1e6, 2)},
                             "note": "serial: the 17 launches of a frame one after the other (headline: per-kernel spans are execution "
                                     "times); overlap: occlusion(b) next to closest-hit(b+1) on a second stream, the library's default"}
+
+    # ---- N = 1: the opt-in elision of occlusion rays whose result cannot reach the image (CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS,
+    # include/crt_hip.h): same frames, bit-identical images and ray statistics (tests/test_gpu_elide.py). The HEADLINE traces
+    # every ray the reference traces; this leg says what the reference's dead rays cost, with the rate over TRACED rays ----
+    if world == 1 and rank == 0 and not args.no_other_schedule:
+        r3 = RenderHIP(device=local_rank, flags=core.FLAG_TIMING | core.FLAG_ELIDE_UNUSED_SHADOW_RAYS, stream=stream.cuda_stream)
+        r3.initialize(width, height)
+        r3.set_prepared_scene(ps)
+        e3, rays3, acc3 = timed_frames(FrameLoop(r3, (eye, cdir, up, fovy), None, 0, 1), args, None, 0)
+        r3.close()
+        elided = int(acc3.get("shadow_rays_elided", 0))
+        out["elide_unused_shadow_rays"] = {
+            "ms_per_step": round(e3 / args.steps * 1e3, 4), "schedule": args.schedule,
+            "rays_reference_semantics_per_step": rays3 // args.steps, "rays_elided_per_step": elided // args.steps,
+            "share_of_occlusion_rays_elided": round(elided / max(1, elided + int(acc3["shadow_rays"])), 4),
+            "MRay_per_s_traced_only": round((rays3 - elided) / e3 / 1e6, 2),
+            "note": "opt-in (off in the headline): the reference traces the light-sample occlusion ray of every hit and uses its answer only if "
+                    "light_pdf >= EPSILON && bsdf_pdf >= EPSILON (render_embree.ispc:131-153); rays whose contribution is an exact zero "
+                    "whatever they hit are counted but not traced. Accumulated radiance, RGBA8 and per-pixel ray counts are bit-identical "
+                    "to the default path's. The rate counts traced rays only"}
 
     # ---- N = 1: the opt-in SPEED MODE build (fast-math, as the reference builds its own ISPC kernels: backends/embree/
     # CMakeLists.txt:12) on the same prepared scene, in a child process; reported next to the headline, never as it ----

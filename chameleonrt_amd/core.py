@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(
 
 FLAG_COUNTERS = 1
 FLAG_TIMING = 2
+FLAG_ELIDE_UNUSED_SHADOW_RAYS = 4  # opt-in: occlusion rays whose result cannot reach the image are counted, not traced (include/crt_hip.h)
 TRACE_PRODUCTION = 2  # crt_hip_trace_rays: run the kernels a frame launches (include/crt_hip.h)
 
 # every symbol include/crt_hip.h declares
@@ -49,7 +50,8 @@ class RenderStats(C.Structure):
                 ("closest_ms_bounce", C.c_float * 5), ("shadow_ms_bounce", C.c_float * 5), ("shade_ms_bounce", C.c_float * 5),
                 ("raygen_ms", C.c_float), ("accumulate_ms", C.c_float),
                 ("closest_slots", C.c_uint64), ("shadow_slots", C.c_uint64),
-                ("passes", C.c_uint32), ("pass_lanes", C.c_uint32)]  # ABI 3
+                ("passes", C.c_uint32), ("pass_lanes", C.c_uint32),  # ABI 3
+                ("shadow_rays_elided", C.c_uint64)]  # ABI 4 (FLAG_ELIDE_UNUSED_SHADOW_RAYS)
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

@@ -240,7 +240,7 @@ struct crt_hip_ctx {
             (void)hipStreamDestroy(own_stream);
         }
     }
-    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0}; }
+    LaunchCfg cfg() const { return LaunchCfg{stream, n_cus, (flags & CRT_HIP_FLAG_COUNTERS) != 0, (flags & CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS) != 0}; }
 };
 
 namespace {
@@ -1017,6 +1017,7 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
                 st.shadow_rays += (uint64_t)pc.n_shadow_a[b].v + pc.n_shadow_b[b].v;
                 st.closest_rays_bounce[b] += pc.n_queue[b].v;
                 st.shadow_rays_bounce[b] += (uint64_t)pc.n_shadow_a[b].v + pc.n_shadow_b[b].v;
+                st.shadow_rays_elided += pc.n_shadow_elided[b].v;
             }
             st.closest_nodes += pc.nodes_closest;
             st.closest_tris += pc.tris_closest;
@@ -1025,7 +1026,7 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
             st.closest_slots += pc.slots_closest;
             st.shadow_slots += pc.slots_shadow;
         }
-        st.rays = st.closest_rays + st.shadow_rays;
+        st.rays = st.closest_rays + st.shadow_rays + st.shadow_rays_elided; // REPORT_RAY_STATS semantics: every ray the reference issues
         if (std::getenv("CRT_HIP_DEBUG")) { // per-bounce queue sizes of the first pass
             const PassCounters &pc = h_pc[0];
             std::fprintf(stderr, "[crt_hip] frame %u worst closest ray: %u nodes, o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) t %.9g\n",
@@ -1086,7 +1087,7 @@ static int render_end(crt_hip_ctx *ctx, crt_render_stats *stats, bool back_to_ba
             }
             ++ctx->lane_tune;
         }
-        st.rays_per_second = (float)(st.rays / (st.render_time_ms * 1.0e-3));
+        st.rays_per_second = (float)((st.rays - st.shadow_rays_elided) / (st.render_time_ms * 1.0e-3)); // rays really traced
         if (timing) {
             const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
             for (const Span &sp : spans) {

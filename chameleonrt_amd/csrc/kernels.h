@@ -26,6 +26,7 @@ struct LaunchCfg {
     hipStream_t stream;
     int n_cus;      // compute units of the device (grid sizing)
     bool counters;  // instrumented traversal (CRT_HIP_FLAG_COUNTERS)
+    bool elide = false; // CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS (k_shade)
 };
 
 // Geometry of the persistent traversal grid (sizes the stack-overflow slab in SceneView).

@@ -453,6 +453,7 @@ struct ShadeStage {
     uint32_t a[12][STAGE_CAP];    // ShadowQueueA: o, d, tmax (its seven SoA fields in declaration order), c.xyz, path | has_b, slot in ShadowQueueB
     uint32_t cnt_a[2], cnt_next[2]; // entries staged in this step; the counters alternate with the step's parity
     uint32_t cnt_b[2];              // B rays written in this step (counted for the ray statistics only)
+    uint32_t cnt_e[2];              // A rays elided in this step (CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS; statistics only)
     uint32_t base, base_next;       // where the step's entries go in the global queues
 };
 static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 9 * sizeof(void *) && offsetof(ShadowQueueA, cp) == 7 * sizeof(void *),
@@ -460,7 +461,7 @@ static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) =
 
 __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
-                                                       PassCounters *pc, int bounce)
+                                                       PassCounters *pc, int bounce, int elide)
 {
     __shared__ ShadeStage stage;
     // The grid is sized for the pass (the host does not know the queue's size): from the second bounce on a growing share of the
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
         return;
     }
     if (threadIdx.x == 0) {
-        stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = stage.cnt_b[0] = stage.cnt_b[1] = 0;
+        stage.cnt_a[0] = stage.cnt_a[1] = stage.cnt_next[0] = stage.cnt_next[1] = stage.cnt_b[0] = stage.cnt_b[1] = stage.cnt_e[0] = stage.cnt_e[1] = 0;
     }
     unorm8_init(); // (ends with the barrier that also publishes the counters)
     uint32_t parity = 0;
@@ -599,9 +600,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             sb.tp[2][slot_b] = tp_in.z;
             sb.path[slot_b] = path;
         }
-        const uint32_t la = wave_append_lds(&stage.cnt_a[parity], is_hit);
-        if (is_hit) {
-            const V3 c = tp_in * c_a;
+        // The hit's light-sample ray. Its retire adds c = tp * cA to the path's radiance if nothing is in the way (ispc:148-151);
+        // c is an exact zero where the reference's `light_pdf >= EPSILON && bsdf_pdf >= EPSILON` fails or the BSDF evaluates to
+        // zero, and radiance + (+-0) is radiance (it is never -0: sums of a +0 start). With CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS
+        // such a ray is counted (n_rays above) but not traced -- unless the hit has a second ray, whose lane resolves both.
+        const V3 c = tp_in * c_a;
+        const bool dead_a = elide != 0 && is_hit && !has_b && c.x == 0.f && c.y == 0.f && c.z == 0.f;
+        if (elide != 0) {
+            const uint64_t e_mask = __ballot(dead_a);
+            if (e_mask != 0 && lane_id() == 0) {
+                atomicAdd(&stage.cnt_e[parity], (uint32_t)__popcll(e_mask));
+            }
+        }
+        const bool stage_a = is_hit && !dead_a;
+        const uint32_t la = wave_append_lds(&stage.cnt_a[parity], stage_a);
+        if (stage_a) {
             stage.a[0][la] = __float_as_uint(hit_p.x);
             stage.a[1][la] = __float_as_uint(hit_p.y);
             stage.a[2][la] = __float_as_uint(hit_p.z);
@@ -677,9 +690,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             if (stage.cnt_b[parity] != 0u) {
                 atomicAdd(&pc->n_shadow_b[bounce].v, stage.cnt_b[parity]);
             }
+            if (stage.cnt_e[parity] != 0u) {
+                atomicAdd(&pc->n_shadow_elided[bounce].v, stage.cnt_e[parity]);
+            }
             stage.cnt_a[parity ^ 1u] = 0;
             stage.cnt_next[parity ^ 1u] = 0;
             stage.cnt_b[parity ^ 1u] = 0;
+            stage.cnt_e[parity ^ 1u] = 0;
         }
         __syncthreads();
         {
@@ -1080,7 +1097,7 @@ void launch_shade(const LaunchCfg &cfg, const SceneView &sc, PathQueue qin, HitB
     const long want = (long)(n_paths_max / (uint32_t)(SHADE_BLOCK * CRT_SHADE_MIN_ITERS));
     const long lo = persistent_grid(cfg, CRT_SHADE_GRID), hi = persistent_grid(cfg, CRT_SHADE_GRID_MAX);
     const int grid = (int)(want < lo ? lo : want > hi ? hi : want);
-    k_shade<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce);
+    k_shade<<<grid, SHADE_BLOCK, 0, cfg.stream>>>(sc, qin, hits, qout, sa, sb, radiance, pc, bounce, cfg.elide ? 1 : 0);
 }
 
 void launch_accumulate(const LaunchCfg &cfg, const ViewParams &vp, const uint32_t *tile_ids, uint32_t slot0,

@@ -86,6 +86,7 @@ struct PassCounters {
     HotCounter n_queue[MAX_PATH_DEPTH + 1]; // closest-hit rays entering bounce b
     HotCounter n_shadow_a[MAX_PATH_DEPTH];
     HotCounter n_shadow_b[MAX_PATH_DEPTH];
+    HotCounter n_shadow_elided[MAX_PATH_DEPTH]; // CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS: A rays counted but not enqueued
     HotCounter cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
     HotCounter cur_shadow_a[MAX_PATH_DEPTH];
     HotCounter cur_shadow_b[MAX_PATH_DEPTH];

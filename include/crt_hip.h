@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CRT_HIP_ABI_VERSION 3
+#define CRT_HIP_ABI_VERSION 4
 #define CRT_HIP_MAX_PATH_DEPTH 5 /* MAX_PATH_DEPTH, backends/embree/util.ih:10 */
 
 enum {
@@ -119,7 +119,7 @@ typedef struct crt_scene_desc {
  * 64 bits (the reference's uint16/int accumulation overflows at 4K/64spp). */
 typedef struct crt_render_stats {
     float render_time_ms;  /* all kernels of the frame incl. tonemap + stat reduction */
-    float rays_per_second; /* rays / (render_time_ms * 1e-3) */
+    float rays_per_second; /* rays really traced / (render_time_ms * 1e-3) (= rays / ... without the elision flag) */
     uint64_t rays;
     uint64_t closest_rays; /* rays traced by the closest-hit traversal kernel */
     uint64_t shadow_rays;  /* rays traced by the any-hit traversal kernel */
@@ -140,6 +140,10 @@ typedef struct crt_render_stats {
     /* (ABI 3) how the frame was cut: passes (each at most the path capacity) and the pass lanes they ran on -- 1, or 2
      * where the library's trial found two faster for frames of this size (bit-identical images either way) */
     uint32_t passes, pass_lanes;
+    /* (ABI 4) CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS: occlusion rays the reference issues and counts but whose result it never
+     * looks at, not traced here. `rays` keeps the reference's count (closest_rays + shadow_rays + shadow_rays_elided);
+     * `shadow_rays` and `shadow_rays_bounce` are the rays the any-hit kernel really traced. 0 without the flag. */
+    uint64_t shadow_rays_elided;
 } crt_render_stats;
 
 typedef struct crt_hip_ctx crt_hip_ctx;
@@ -147,7 +151,17 @@ typedef struct crt_hip_ctx crt_hip_ctx;
 enum {
     CRT_HIP_FLAG_NONE = 0,
     CRT_HIP_FLAG_COUNTERS = 1, /* count BVH nodes / triangles touched (instrumented kernels) */
-    CRT_HIP_FLAG_TIMING = 2    /* per-kernel-class HIP event timing in crt_render_stats */
+    CRT_HIP_FLAG_TIMING = 2,   /* per-kernel-class HIP event timing in crt_render_stats */
+    /* Opt-in, off by default: do not trace the next-event occlusion rays whose result cannot reach the image. The reference
+     * (render_embree.ispc:131-153) traces the light-sample ray of EVERY hit, counts it, and then uses its answer only if
+     * light_pdf >= EPSILON && bsdf_pdf >= EPSILON; where those fail -- the light's back side, the wrong hemisphere of an
+     * opaque surface -- or the BSDF evaluates to exactly zero, the ray's contribution is an exact zero whatever it hits.
+     * With this flag such a ray (and only a hit's single ray: a hit with a second, BSDF-sampled occlusion ray keeps both) is
+     * dropped in the shading kernel: accumulated radiance, RGBA8 and the per-pixel ray counts are bit-identical to the
+     * default path's (tests/test_gpu_elide.py), the any-hit kernel has less to do. Ray statistics keep the reference's
+     * semantics (crt_render_stats::rays); the rays not traced are reported apart (shadow_rays_elided). The default traces
+     * every ray the reference traces. */
+    CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS = 4
 };
 
 int crt_hip_abi_version(void);

@@ -30,7 +30,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.crt_hip_abi_version() == 3
+    assert lib.crt_hip_abi_version() == 4
 
 
 def test_scene_io_library_exports_its_header():

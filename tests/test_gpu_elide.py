@@ -1,0 +1,51 @@
+"""GPU: CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS (include/crt_hip.h) -- opt-in, off by default.
+
+The reference traces the light-sample occlusion ray of every hit, counts it (REPORT_RAY_STATS) and then looks at its answer
+only if light_pdf >= EPSILON && bsdf_pdf >= EPSILON (render_embree.ispc:131-153). With the flag, a ray whose contribution is
+an exact zero whatever it hits is counted but not traced. Nothing observable may change: accumulated radiance (every bit,
+NaN pixels included), RGBA8, per-pixel ray counts and the frame's ray total are those of the default path -- and therefore
+the oracle's; only the number of rays the any-hit kernel traces goes down."""
+import numpy as np
+import pytest
+
+from chameleonrt_amd import core, scenes
+from chameleonrt_amd.camera import camera_of
+from chameleonrt_amd.render_hip import RenderHIP
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(sc, w, h, flags, n_frames):
+    e, d, u, fovy = camera_of(sc)
+    r = RenderHIP(flags=flags)
+    r.initialize(w, h)
+    r.set_scene(sc)
+    stats = [r.render(e, d, u, fovy, f == 0, True) for f in range(n_frames)]
+    out = (r.accum().copy(), r.ray_counts().copy(), r.img.copy(), stats)
+    r.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["cornell", "grove", "C2", "C3", "C4"])  # (C4 has glass: non-finite throughputs and NaN pixels must survive, too)
+def test_elision_changes_nothing_observable(name, hip_lib):
+    if name == "cornell":
+        sc, w, h = scenes.cornell(spp=4), 256, 256
+    elif name == "grove":
+        sc, w, h = scenes.instanced_grove(spp=4), 320, 200
+    else:
+        sc, w, h, _ = scenes.make_workload(name, **({} if name == "C3" else {"tex_size": 128}))
+        sc.samples_per_pixel = 2
+        w, h = w // 2, h // 2
+    a0, c0, i0, s0 = _frames(sc, w, h, core.FLAG_TIMING, 2)
+    a1, c1, i1, s1 = _frames(sc, w, h, core.FLAG_TIMING | core.FLAG_ELIDE_UNUSED_SHADOW_RAYS, 2)
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    assert np.array_equal(c0, c1) and np.array_equal(i0, i1)
+    for x, y in zip(s0, s1):
+        assert x.rays == y.rays and x.closest_rays == y.closest_rays
+        assert x.shadow_rays_elided == 0
+        assert y.shadow_rays + y.shadow_rays_elided == x.shadow_rays
+        assert list(x.closest_rays_bounce) == list(y.closest_rays_bounce)
+    share = s1[-1].shadow_rays_elided / max(1, s0[-1].shadow_rays)
+    print(f"\n{name}: {s1[-1].shadow_rays_elided} of {s0[-1].shadow_rays} occlusion rays never looked at by the reference ({100 * share:.1f} %)")
+    if name in ("C2", "C3", "C4"):
+        assert share > 0.1  # (the stand-ins' generated light is behind or below most of what the camera sees)
