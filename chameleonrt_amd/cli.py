@@ -13,11 +13,12 @@ at the end. `-validation <prefix>` writes `<prefix>crt_hip-f<frame>.png` every f
 (main.cpp:316-325). Defaults as in main.cpp:35-36,122-126: 1280x720, eye (0,0,5), center 0,
 up (0,1,0), fovy 65, 1 spp; a scene's own camera is used unless camera options are given.
 """
+import os
 import sys
 
 import numpy as np
 
-from . import scenes
+from . import core, scenes
 from .camera import look_at
 from .render_hip import RenderHIP
 
@@ -92,7 +93,8 @@ def main(argv=None) -> int:
         eye, center, up, fovy = list(c.position), list(c.center), list(c.up), float(c.fov_y)
     cam_eye, cam_dir, cam_up = look_at(eye, center, up)
 
-    renderer = RenderHIP()
+    # CRT_HIP_ELIDE=1, like the C++ plugin: occlusion rays the reference never looks at are counted, not traced (same image)
+    renderer = RenderHIP(flags=core.FLAG_ELIDE_UNUSED_SHADOW_RAYS if os.environ.get("CRT_HIP_ELIDE") == "1" else 0)
     renderer.initialize(width, height)
     renderer.set_scene(scene)
     from PIL import Image as PILImage
