@@ -137,8 +137,12 @@ def node_transform(n: dict) -> np.ndarray:
     if n.get("matrix"):
         return np.asarray(n["matrix"], np.float32).reshape(4, 4).T.copy()  # glm::make_mat4: column-major
     m = np.eye(4, dtype=np.float32)
+    eye = np.eye(4, dtype=np.float32)
     if n.get("scale"):
-        m = np.diag(np.float32(list(n["scale"]) + [1.0])).astype(np.float32)
+        # glm::scale(v) = scale(mat4(1), v): column i = identity column i * v[i] -- the zeros of a column take the SIGN of its
+        # factor (0 * -2 = -0), and the products below carry those signs on
+        sx, sy, sz = (np.float32(v) for v in n["scale"])
+        m = np.stack([eye[:, 0] * sx, eye[:, 1] * sy, eye[:, 2] * sz, eye[:, 3]], axis=1).astype(np.float32)
     if n.get("rotation"):
         x, y, z, w = (np.float32(v) for v in n["rotation"])
         one, two = np.float32(1), np.float32(2)
@@ -148,8 +152,10 @@ def node_transform(n: dict) -> np.ndarray:
         rot[0, 2], rot[1, 2], rot[2, 2] = two * (x * z + w * y), two * (y * z - w * x), one - two * (x * x + y * y)
         m = _mat4_mul(rot, m)
     if n.get("translation"):
-        t = np.eye(4, dtype=np.float32)
-        t[:3, 3] = np.float32(n["translation"])
+        # glm::translate(v) = translate(mat4(1), v): column 3 = ((I0 * v0 + I1 * v1) + I2 * v2) + I3, the other columns the identity's
+        tx, ty, tz = (np.float32(v) for v in n["translation"])
+        t = eye.copy()
+        t[:, 3] = ((eye[:, 0] * tx + eye[:, 1] * ty) + eye[:, 2] * tz) + eye[:, 3]
         m = _mat4_mul(t, m)
     return m
 

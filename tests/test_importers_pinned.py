@@ -74,3 +74,63 @@ def test_dumps_are_what_the_reference_importer_produces_now(name):
 def test_every_golden_scene_file_is_covered():
     dumps = {os.path.basename(p)[len("refscene_"):-4] for p in glob.glob(os.path.join(HERE, "golden", "refscene_*.npz"))}
     assert dumps == {n + s for n in FILES for s in ("", "_wd")}
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref_scene.so is built where /root/reference exists")
+def test_random_gltf_node_trees_against_the_live_reference_importer(tmp_path):
+    """40 seeded glTF files with random node graphs -- TRS nodes (random unit and NON-unit quaternions, negative and zero-ish
+    scales), explicit matrices, up to four levels of nesting, nodes without meshes in between, single-level and multi-level
+    scenes (util/flatten_gltf.cpp only flattens the latter) -- loaded by the reference's own importer and by gltf_io:
+    every instance transform bit for bit (read_node_transform's GLM products, flatten_gltf_node's parent * child), same
+    instance order, same mesh assignment."""
+    from tests.test_gltf_io import QUAD_IDX, QUAD_POS, Builder
+    n_instances = 0
+    for seed in range(40):
+        rng = np.random.default_rng(500 + seed)
+        b = Builder()
+        a_pos = b.accessor(b.view(QUAD_POS.tobytes()), 5126, "VEC3", 4)
+        a_idx = b.accessor(b.view(np.uint16(QUAD_IDX).tobytes()), 5123, "SCALAR", 6)
+        n_meshes = int(rng.integers(1, 4))
+        b.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": a_pos}, "indices": a_idx}]} for _ in range(n_meshes)]
+        nodes = []
+
+        def num(scale=1.0):
+            x = float(rng.normal()) * scale
+            return float(np.float32(x)) if rng.random() < 0.5 else x  # doubles that are not floats, too
+
+        def make(depth):
+            n = {}
+            if rng.random() < 0.8 or depth >= 3:
+                n["mesh"] = int(rng.integers(0, n_meshes))
+            kind = rng.random()
+            if kind < 0.2:
+                m = np.eye(4) + rng.normal(size=(4, 4)) * 0.5
+                m[3] = [0, 0, 0, 1]
+                n["matrix"] = [float(x) for x in m.T.reshape(16)]  # column-major
+            else:
+                if rng.random() < 0.7:
+                    n["translation"] = [num(5), num(5), num(5)]
+                if rng.random() < 0.7:
+                    q = rng.normal(size=4)
+                    if rng.random() < 0.7:
+                        q /= np.linalg.norm(q)
+                    n["rotation"] = [float(x) for x in q]
+                if rng.random() < 0.6:
+                    n["scale"] = [num(2) if rng.random() < 0.9 else 1e-3 * num() for _ in range(3)]
+            idx = len(nodes)
+            nodes.append(n)
+            if depth < 3 and rng.random() < (0.0 if single_level else 0.6):
+                n["children"] = [make(depth + 1) for _ in range(int(rng.integers(1, 4)))]
+            return idx
+
+        single_level = seed % 4 == 0
+        roots = [make(0) for _ in range(int(rng.integers(1, 4)))]
+        b.doc["nodes"] = nodes
+        b.doc["scenes"][0]["nodes"] = roots
+        path = os.path.join(tmp_path, f"n{seed}." + ("glb" if seed % 2 else "gltf"))
+        b.finish(path, glb=bool(seed % 2))
+        ref, mine = R.load(path), _ours(path, False)
+        for k in ("instance_transforms", "instance_pmesh", "counts"):
+            assert ref[k].shape == mine[k].shape and ref[k].tobytes() == np.asarray(mine[k]).astype(ref[k].dtype).tobytes(), (seed, k)
+        n_instances += len(ref["instance_pmesh"])
+    assert n_instances > 150
