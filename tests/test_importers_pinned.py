@@ -134,3 +134,31 @@ def test_random_gltf_node_trees_against_the_live_reference_importer(tmp_path):
             assert ref[k].shape == mine[k].shape and ref[k].tobytes() == np.asarray(mine[k]).astype(ref[k].dtype).tobytes(), (seed, k)
         n_instances += len(ref["instance_pmesh"])
     assert n_instances > 150
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref_scene.so is built where /root/reference exists")
+def test_random_crts_scenes_against_the_live_reference_importer(tmp_path):
+    """24 seeded instanced scenes (random instance counts, transforms, materials, textures, lights, with and without a camera /
+    lights of their own) written by save_crts and loaded by the reference's load_crts (util/scene.cpp:417-624) and by crts_io:
+    every array bit for bit, in both material modes."""
+    from chameleonrt_amd import scenes
+    from chameleonrt_amd.crts_io import save_crts
+    compared = 0
+    for seed in range(24):
+        rng = np.random.default_rng(900 + seed)
+        sc = scenes.instanced_grove(n_instances=int(rng.integers(1, 9)), leaves_per_tree=int(rng.integers(4, 30)),
+                                    tex_size=int(rng.choice([2, 4, 8])), seed=seed + 1)
+        for inst in sc.instances:  # arbitrary (also non-rigid, mirrored) transforms
+            m = np.eye(4) + rng.normal(size=(4, 4)) * 0.3
+            m[3] = [0, 0, 0, 1]
+            inst.transform = np.float32(m.T.reshape(16))
+        if seed % 3 == 0:
+            sc.lights = []      # load_crts then generates its own (scene.cpp:605-623)
+        if seed % 4 == 0:
+            sc.cameras = []
+        path = os.path.join(tmp_path, f"s{seed}.crts")
+        save_crts(sc, path)
+        for wd in (False, True):
+            _compare(R.load(path, white_diffuse=wd), _ours(path, wd), f"crts fuzz seed {seed} wd {wd}")
+            compared += 1
+    assert compared == 48
