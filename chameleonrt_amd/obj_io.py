@@ -26,24 +26,79 @@ from .scene import (SRGB, Geometry, Image, Instance, Mesh, ParameterizedMesh, Sc
                     obj_default_light, textured_param)
 
 
-def _parse_mtl(path: str) -> List[dict]:
-    mats: List[dict] = []
-    cur = None
-    with open(path) as f:
-        for line in f:
-            tok = line.split()
-            if not tok or tok[0].startswith("#"):
+_SPACE = " \t"
+
+
+def _mtl_real(rest: str, default: float):
+    """tinyobjloader's parseReal (util/tiny_obj_loader.h:682-690): skip blanks, take the token up to the next blank, parse it with
+    tryParseDouble's grammar; what does not parse -- or is not there -- reads as the default. (MTL has legitimate non-numeric
+    forms, `Kd spectral file.rfl`; geometry numbers in the OBJ file are held to the grammar strictly, see _num.)"""
+    rest = rest.lstrip(_SPACE)
+    n = 0
+    while n < len(rest) and rest[n] not in " \t\r":
+        n += 1
+    tok, rest = rest[:n], rest[n:]
+    num = _number_prefix(tok)
+    return (float(np.float32(float(num))) if num is not None else default), rest
+
+
+def _mtl_texture_name(rest: str):
+    """ParseTextureNameAndOption (util/tiny_obj_loader.h:906-976): options with their fixed numbers of arguments are skipped, the
+    texture name is THE REST OF THE LINE from the first thing that is not an option (file names may contain blanks)."""
+    one = ("-blendu", "-blendv", "-clamp", "-boost", "-bm", "-imfchan", "-colorspace")
+    name = None
+    while rest:
+        rest = rest.lstrip(_SPACE)
+        if not rest:
+            break
+        for opt, n_args in [(o, 1) for o in one] + [("-o", 3), ("-s", 3), ("-t", 3), ("-mm", 2)]:
+            if rest.startswith(opt) and len(rest) > len(opt) and rest[len(opt)] in _SPACE:
+                rest = rest[len(opt) + 1:]
+                for _ in range(n_args):
+                    _, rest = _mtl_real(rest, 0.0)  # (every argument is one blank-delimited token, numeric or not)
+                break
+        else:
+            if rest.startswith("-type") and len(rest) > 5 and rest[5] in _SPACE:
+                _, rest = _mtl_real(rest[5:], 0.0)
                 continue
-            if tok[0] == "newmtl":
-                cur = {"name": " ".join(tok[1:]), "Kd": (0.6, 0.6, 0.6), "Ns": 1.0, "map_Kd": ""}  # tinyobj defaults
+            name, rest = rest, ""
+    return name
+
+
+def _parse_mtl(path: str) -> List[dict]:
+    """tinyobjloader's LoadMtl (util/tiny_obj_loader.h:1353-1725) for the three things the reference's importer reads from a
+    material (util/scene.cpp:191-216): Kd, Ns, map_Kd. Its defaults are ZERO diffuse and shininess 1 (InitMaterial); missing
+    components of `Kd` read as 0; a material is flushed by the next `newmtl` only if it has a name, and the last one always --
+    so a file without any `newmtl` still yields one (unnamed) material; the name is everything after `newmtl` and ONE blank."""
+    def fresh(name=""):
+        return {"name": name, "Kd": (0.0, 0.0, 0.0), "Ns": 1.0, "map_Kd": ""}
+    mats: List[dict] = []
+    cur = fresh()
+    with open(path, newline="") as f:
+        text = f.read()
+    for line in re.split(r"\r\n|\n|\r", text):
+        line = line.rstrip(_SPACE)
+        tok = line.lstrip(_SPACE)
+        if not tok or tok[0] == "#":
+            continue
+        def key(k):
+            return tok.startswith(k) and len(tok) > len(k) and tok[len(k)] in _SPACE
+        if key("newmtl"):
+            if cur["name"] != "":
                 mats.append(cur)
-            elif cur is not None:
-                if tok[0] == "Kd":
-                    cur["Kd"] = tuple(float(x) for x in tok[1:4])
-                elif tok[0] == "Ns":
-                    cur["Ns"] = float(tok[1])
-                elif tok[0] == "map_Kd":
-                    cur["map_Kd"] = tok[-1]
+            cur = fresh(tok[7:])
+        elif key("Kd"):
+            r, rest = _mtl_real(tok[2:], 0.0)
+            g, rest = _mtl_real(rest, 0.0)
+            b, rest = _mtl_real(rest, 0.0)
+            cur["Kd"] = (r, g, b)
+        elif key("Ns"):
+            cur["Ns"], _ = _mtl_real(tok[2:], 0.0)
+        elif key("map_Kd"):
+            name = _mtl_texture_name(tok[7:])
+            if name is not None:
+                cur["map_Kd"] = name
+    mats.append(cur)
     return mats
 
 
@@ -123,7 +178,7 @@ def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int =
     for lib in libs:
         idx = dict(mat_index_after[-1])
         for m in _parse_mtl(os.path.join(base_dir, lib)):
-            idx[m["name"]] = len(obj_materials)
+            idx.setdefault(m["name"], len(obj_materials))  # (tinyobjloader: std::map::insert -- the FIRST material of a name is the one `usemtl` finds)
             obj_materials.append(m)
         mat_index_after.append(idx)
     geoms = [Geometry(v, ix, uv) for v, ix, uv, _, _ in raw]
@@ -133,6 +188,35 @@ def load_obj(path: str, material_mode: str = "default", samples_per_pixel: int =
 
 
 _NUMBER = re.compile(r"[+-]?[0-9]+(\.[0-9]*)?([eE][+-]?[0-9]+)?\Z")
+
+
+def _number_prefix(tok: str):
+    """What tryParseDouble (util/tiny_obj_loader.h:567-680) makes of a token that need not be a number to its end: the longest
+    prefix sign? digits+ ('.' digits*)? ([eE] sign? digits+)? -- it stops, successfully, at the first character that does not
+    continue the number ("1.5abc" is 1.5) but FAILS as a whole on an exponent marker without digits ("1e", "2.5E+"). None = fails."""
+    i, n = 0, len(tok)
+    if i < n and tok[i] in "+-":
+        i += 1
+    d0 = i
+    while i < n and tok[i].isdigit() and tok[i].isascii():
+        i += 1
+    if i == d0:
+        return None
+    if i < n and tok[i] == ".":
+        i += 1
+        while i < n and tok[i].isdigit() and tok[i].isascii():
+            i += 1
+    if i < n and tok[i] in "eE":
+        j = i + 1
+        if j < n and tok[j] in "+-":
+            j += 1
+        e0 = j
+        while j < n and tok[j].isdigit() and tok[j].isascii():
+            j += 1
+        if j == e0:
+            return None
+        i = j
+    return tok[:i]
 
 
 def _num(tok: str) -> float:
@@ -259,7 +343,7 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
                 cur = None
             elif k == "mtllib":
                 for m in _parse_mtl(os.path.join(base_dir, tok[1])):
-                    mat_index[m["name"]] = len(obj_materials)
+                    mat_index.setdefault(m["name"], len(obj_materials))
                     obj_materials.append(m)
             elif k == "usemtl":
                 cur_mat = mat_index.get(" ".join(tok[1:]), -1)

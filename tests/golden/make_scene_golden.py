@@ -49,6 +49,25 @@ def write_files():
     with open(p, "w") as f:  # what tinyobjloader's ear clipping (tiny_obj_loader.h:1107-1310) makes of non-trivial polygons
         f.write(polygons_obj())
     out["obj_polygons"] = p
+    from PIL import Image as _PIL
+    for k, n in enumerate(["mq0.png", "mq my tex.png"]):
+        _PIL.fromarray(np.random.default_rng(40 + k).integers(0, 256, (4, 4, 3), dtype=np.uint8)).save(os.path.join(SCENES, n))
+    with open(os.path.join(SCENES, "mtlquirks.mtl"), "w", newline="") as f:  # what tinyobjloader's LoadMtl makes of the odd corners of MTL
+        f.write("Kd 0.1 0.2 0.3\r\n"                                   # before any newmtl: the unnamed material, dropped by the first newmtl
+                "newmtl nokd\r\nNs 250\r\n"                            # no Kd: diffuse is ZERO, not grey
+                "newmtl one\r\n  Kd\t0.5\r\n"                          # missing components read as 0
+                "newmtl dup\r\nKd 1 0 0\r\nnewmtl dup\r\nKd 0 1 0\r\n"   # usemtl finds the FIRST of a name
+                "newmtl spectral\r\nKd spectral file.rfl 1\r\nNs 2e\r\n"  # what is not a number reads as the default
+                "newmtl tex\r\nmap_Kd -s 2 2 1 -o 0.5 0 0 -clamp on -bm 2 -mm 0 1 -imfchan r mq0.png\r\n"
+                "newmtl texsp  \r\nmap_Kd mq my tex.png\r\n"           # the name is the rest of the line; trailing blanks of a line are trimmed
+                "newmtl\r\n"                                            # not a newmtl line at all
+                "newmtl last\r\nKd .5 7. 1.5abc")                      # no newline at the end; `.5` is not a number there, `1.5abc` is 1.5
+    p = os.path.join(SCENES, "mtlquirks.obj")
+    with open(p, "w") as f:
+        f.write("mtllib mtlquirks.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n" +
+                "".join(f"o g{i}\nusemtl {n}\nf 1/1 2/2 3/3\n" for i, n in enumerate(
+                    ["nokd", "one", "dup", "spectral", "tex", "texsp", "last", "missing"])))
+    out["obj_mtlquirks"] = p
     p = os.path.join(SCENES, "bare.obj")
     with open(p, "w") as f:
         f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")

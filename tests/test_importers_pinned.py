@@ -24,7 +24,7 @@ from tests import ref_scene_lib as R
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCENES = os.path.join(HERE, "golden", "scenes")
-FILES = {"obj_cornell": "cornell.obj", "obj_atrium": "atrium.obj", "obj_quirks": "quirks.obj", "obj_bare": "bare.obj", "obj_polygons": "polygons.obj",
+FILES = {"obj_cornell": "cornell.obj", "obj_atrium": "atrium.obj", "obj_quirks": "quirks.obj", "obj_bare": "bare.obj", "obj_polygons": "polygons.obj", "obj_mtlquirks": "mtlquirks.obj",
          "gltf_scene": "scene.gltf", "glb_scene": "scene.glb", "gltf_tree": "tree.gltf", "crts_handmade": "handmade.crts",
          "crts_nolight": "nolight.crts", "crts_grove": "grove.crts"}
 

@@ -255,3 +255,50 @@ def test_native_reader_checks_every_face_index_before_narrowing(tmp_path, face, 
         for reader in ("native", "python"):
             with pytest.raises(ValueError, match="face index out of range"):
                 load_obj(str(path), reader=reader)
+
+
+def test_random_mtl_files_against_the_live_reference_importer(tmp_path):
+    """120 seeded MTL files exercising tinyobjloader's LoadMtl (util/tiny_obj_loader.h:1353-1725) where it is least obvious --
+    defaults (zero diffuse), `Kd` with 0 ... 4 components, tokens that are not numbers (`spectral`, `.5`, `2e`, `1.5abc`),
+    duplicate names, statements before the first `newmtl`, a bare `newmtl`, `map_Kd` with every option and file names with
+    blanks, CR LF, no final newline, an empty file -- each with an OBJ that uses the materials, loaded by the reference's own
+    importer and by load_obj: materials, material ids and textures bit for bit."""
+    from PIL import Image as PILImage
+    from tests import ref_scene_lib as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libref_scene.so is built where /root/reference exists")
+    d = str(tmp_path)
+    for k, n in enumerate(["t0.png", "t1.png", "my tex.png"]):
+        PILImage.fromarray(np.random.default_rng(k).integers(0, 256, (4, 4, 3), dtype=np.uint8)).save(os.path.join(d, n))
+    for seed in range(120):
+        rng = np.random.default_rng(7000 + seed)
+
+        def num(lo=0.0, hi=1.0):
+            x = float(rng.uniform(lo, hi))
+            return rng.choice([f"{x:.4f}", f"{x:.3e}", f"{x:.6g}", f"{x:+.3f}", f"{x:.3f}".replace("0.", ".", 1), "spectral", "1.5abc", "2e", "7."])
+        lines, names = [], []
+        if rng.random() < 0.3:
+            lines.append("Kd 0.1 0.2 0.3")
+        for m in range(int(rng.integers(0, 5))):
+            nm = str(rng.choice(["a", "b c", f"mat_{m}", "a"]))
+            names.append(nm)
+            lines.append(str(rng.choice(["newmtl ", "newmtl\t", "  newmtl "])) + nm + str(rng.choice(["", " ", "\t"])))
+            for _ in range(int(rng.integers(0, 6))):
+                k = rng.choice(["Kd", "Ns", "map_Kd", "junk", "#c", "opt", "sp", "after", "Kdx", "bare"])
+                lines.append({"Kd": str(rng.choice(["Kd ", "Kd\t", "  Kd  "])) + " ".join(num() for _ in range(int(rng.choice([3, 3, 1, 2, 0, 4])))),
+                              "Ns": "Ns " + num(0, 900), "map_Kd": f"map_Kd t{rng.integers(0, 2)}.png", "junk": "foo bar 1 2", "#c": " # comment",
+                              "opt": f"map_Kd -s 2 2 1 -o 0.5 0 0 -clamp on -bm 2 -mm 0 1 -imfchan r t{rng.integers(0, 2)}.png",
+                              "sp": "map_Kd my tex.png", "after": "map_Kd -blendu off t0.png", "Kdx": "Kdx 1 1 1", "bare": "newmtl"}[str(k)])
+        eol = str(rng.choice(["\n", "\r\n"]))
+        with open(os.path.join(d, "m.mtl"), "w", newline="") as f:
+            f.write(eol.join(lines) + (eol if rng.random() < 0.7 else ""))
+        obj = ["mtllib m.mtl", "v 0 0 0", "v 1 0 0", "v 0 1 0", "vt 0 0", "vt 1 0", "vt 0 1"]
+        for g in range(int(rng.integers(1, 4))):
+            obj += [f"o g{g}", "usemtl " + str(rng.choice(names + ["nope"])), "f 1/1 2/2 3/3"]
+        p = os.path.join(d, "f.obj")
+        with open(p, "w") as f:
+            f.write("\n".join(obj) + "\n")
+        ref, mine = R.load(p), R.flatten(load_obj(p))
+        for k, v in ref.items():
+            if not k.endswith("_n_normals"):
+                assert k in mine and v.shape == mine[k].shape and v.tobytes() == np.asarray(mine[k]).astype(v.dtype).tobytes(), (seed, k)
