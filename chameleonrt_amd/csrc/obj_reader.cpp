@@ -21,8 +21,10 @@
 #include <cstddef>
 #include <limits>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/crt_scene_io.h"
@@ -65,6 +67,14 @@ struct Parser {
     int cur_mat_libs = 0;
     int cur = -1; // index into shapes, -1: the next face opens a new one
     std::string error;
+    // material ids as tinyobjloader numbers them (every material of every library read so far, in order; a name resolves to the
+    // FIRST material that carries it). Only their (in)equality matters here: a `usemtl` that CHANGES the id hands the faces
+    // read so far over to the shape, and an `o` statement keeps a shape only if there are faces not handed over yet --
+    // see the `o` branch of run().
+    std::string base_dir;
+    std::vector<std::pair<std::string, int>> material_ids;
+    int n_materials = 0, cur_mat_id = -1;
+    bool faces_since_change = false;
 
     static bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
     void skip_space()
@@ -138,6 +148,88 @@ struct Parser {
             p = q;
         }
         return s;
+    }
+    int material_id_of(const std::string &name) const
+    {
+        for (const auto &m : material_ids) {
+            if (m.first == name) {
+                return m.second;
+            }
+        }
+        return -1;
+    }
+    // The NAMES of a material library, numbered like tinyobjloader's LoadMtl numbers its materials (util/tiny_obj_loader.h:
+    // 1353-1725; obj_io.py _parse_mtl is the full statement): a material is flushed by the next `newmtl` only if it has a name,
+    // the last one always; the name is what follows `newmtl` and ONE blank, without the line's trailing blanks. A directory
+    // ("mtllib  a.mtl": the first name is empty) reads as an empty file. false: the file cannot be opened (the reference throws).
+    bool read_material_names(const std::string &file)
+    {
+        const std::string path = base_dir + file;
+        std::string text;
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0) {
+            return false;
+        }
+        if (!S_ISDIR(st.st_mode)) {
+            FILE *f = std::fopen(path.c_str(), "rb");
+            if (!f) {
+                return false;
+            }
+            char buf[65536];
+            size_t n;
+            while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) {
+                text.append(buf, n);
+            }
+            std::fclose(f);
+        }
+        std::string name;
+        auto flush = [&](bool always) {
+            if (always || !name.empty()) {
+                if (material_id_of(name) < 0) {
+                    material_ids.emplace_back(name, n_materials);
+                }
+                ++n_materials;
+            }
+        };
+        size_t i = 0;
+        while (i <= text.size()) {
+            size_t e = i;
+            while (e < text.size() && text[e] != '\n' && text[e] != '\r') {
+                ++e;
+            }
+            size_t b = i, t = e;
+            while (t > b && (text[t - 1] == ' ' || text[t - 1] == '\t')) {
+                --t;
+            }
+            while (b < t && (text[b] == ' ' || text[b] == '\t')) {
+                ++b;
+            }
+            if (t - b > 6 && text.compare(b, 6, "newmtl") == 0 && (text[b + 6] == ' ' || text[b + 6] == '\t')) {
+                flush(false);
+                name = text.substr(b + 7, t - (b + 7));
+            }
+            if (e >= text.size()) {
+                break;
+            }
+            i = (text[e] == '\r' && e + 1 < text.size() && text[e + 1] == '\n') ? e + 2 : e + 1;
+        }
+        flush(true);
+        return true;
+    }
+    // from `from` to the end of the line as it stands (a CR before the LF is not part of the line)
+    std::string raw_rest(const char *from) const
+    {
+        if (from > end) {
+            from = end;
+        }
+        const char *e = from;
+        while (e < end && *e != '\n') {
+            ++e;
+        }
+        if (e > from && e[-1] == '\r') {
+            --e;
+        }
+        return std::string(from, e);
     }
     static bool parse_int(const char *b, const char *e, long &out)
     {
@@ -334,9 +426,14 @@ struct Parser {
                 continue;
             }
             const char *q = token_end();
-            const size_t len = (size_t)(q - p);
+            size_t len = (size_t)(q - p);
             const char *kw = p;
             p = q;
+            // tinyobjloader recognises a statement by its keyword AND a blank (space or tab) right after it: `o`, `g`, `usemtl`, `v` ...
+            // alone on a line are not statements at all and are skipped (util/tiny_obj_loader.h: `token[0] == 'g' && IS_SPACE(token[1])`)
+            if (!(q < end && (*q == ' ' || *q == '\t'))) {
+                len = 0;
+            }
             if (len == 1 && kw[0] == 'v') {
                 float x[3];
                 if (!read_float(x[0]) || !read_float(x[1]) || !read_float(x[2])) {
@@ -359,23 +456,43 @@ struct Parser {
             } else if (len == 2 && kw[0] == 'v' && kw[1] == 'n') {
                 ++n_normals; // vertex normals only take part in the re-indexing key (the renderer ignores them: quirk Q7)
             } else if (len == 1 && kw[0] == 'f') {
+                faces_since_change = true;
                 if (!parse_face()) {
                     return false;
                 }
             } else if (len == 1 && (kw[0] == 'o' || kw[0] == 'g')) {
+                // tinyobjloader hands the faces read so far to the current shape when the material changes, and its `o` statement
+                // keeps the shape only if there are faces it has not handed over yet (util/tiny_obj_loader.h:2117-2123; `g` and
+                // the end of the file look at the shape itself): an `o` right after a material-changing `usemtl` LOSES the
+                // object before it. The reference's scenes are what that makes of a file, so the faces are dropped here, too.
+                if (kw[0] == 'o' && cur >= 0 && !shapes[(size_t)cur].pending.empty() && !faces_since_change) {
+                    shapes[(size_t)cur].pending.clear();
+                }
+                faces_since_change = false;
                 // a new group; tinyobj does not emit empty shapes, so one without faces is simply continued
                 if (!(cur >= 0 && shapes[(size_t)cur].pending.empty())) {
                     cur = -1;
                 }
             } else if (len == 6 && std::memcmp(kw, "usemtl", 6) == 0) {
-                cur_mat = rest_joined();
+                // the name is everything after the keyword and ONE blank, to the end of the line, as it stands (tinyobjloader:
+                // `token += 7; ss << token`): "usemtl  a" names " a", "usemtl a " names "a " -- neither is the material "a"
+                cur_mat = raw_rest(p + 1);
                 have_mat = true;
                 cur_mat_libs = (int)mtllibs.size();
+                const int id = material_id_of(cur_mat);
+                if (id != cur_mat_id) {
+                    cur_mat_id = id;
+                    faces_since_change = false;
+                }
             } else if (len == 6 && std::memcmp(kw, "mtllib", 6) == 0) {
-                skip_space();
-                const char *e = token_end();
-                mtllibs.emplace_back(p, e);
-                p = e;
+                // file names separated by single blanks; tinyobjloader tries them in turn and stops at the first that loads --
+                // and the reference's importer throws on any that does not -- so the first name is the file (obj_io.py)
+                const std::string rest = raw_rest(p + 1);
+                mtllibs.emplace_back(rest.substr(0, rest.find(' ')));
+                if (!read_material_names(mtllibs.back())) {
+                    error = "cannot read the material library " + mtllibs.back();
+                    return false;
+                }
             }
             skip_line();
         }
@@ -448,6 +565,11 @@ crt_obj_file *crt_obj_parse(const char *path)
     if (size && map == MAP_FAILED) {
         f->error = std::string("cannot map ") + path;
         return f;
+    }
+    {
+        const std::string sp(path);
+        const size_t slash = sp.rfind('/');
+        f->parser.base_dir = slash == std::string::npos ? std::string() : sp.substr(0, slash + 1);
     }
     f->parser.p = static_cast<const char *>(map);
     f->parser.end = f->parser.p + size;

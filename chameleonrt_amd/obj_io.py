@@ -74,8 +74,13 @@ def _parse_mtl(path: str) -> List[dict]:
         return {"name": name, "Kd": (0.0, 0.0, 0.0), "Ns": 1.0, "map_Kd": ""}
     mats: List[dict] = []
     cur = fresh()
-    with open(path, newline="") as f:
-        text = f.read()
+    if os.path.isdir(path):
+        # `mtllib  a.mtl` (two blanks) names "" first: the reference then opens the OBJ's directory as a stream, reads nothing from
+        # it and is content -- one unnamed material, and a.mtl is never looked at
+        text = ""
+    else:
+        with open(path, newline="") as f:
+            text = f.read()
     for line in re.split(r"\r\n|\n|\r", text):
         line = line.rstrip(_SPACE)
         tok = line.lstrip(_SPACE)
@@ -310,6 +315,7 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
     shapes: List[dict] = []
     cur = None
     cur_mat = -1
+    since_change = False  # an `f` statement since the last group statement or change of material
 
     def shape():
         nonlocal cur
@@ -325,40 +331,56 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
             raise ValueError("face index out of range")
         return i - 1 if i > 0 else n + i
 
-    with open(path) as f:
-        for line in f:
-            tok = line.split()
-            if not tok or tok[0].startswith("#"):
-                continue
-            k = tok[0]
-            if k == "v":
-                positions.append([_num(x) for x in tok[1:4]])
-            elif k == "vn":
-                normals.append(None)  # counted only: the hot path reads no normals (quirk Q7); the native reader does the same
-            elif k == "vt":
-                texcoords.append([_num(tok[1]), _num(tok[2]) if len(tok) > 2 else 0.0])
-            elif k in ("o", "g"):
-                if cur is not None and not cur["faces"]:
-                    continue  # tinyobj does not emit empty shapes
-                cur = None
-            elif k == "mtllib":
-                for m in _parse_mtl(os.path.join(base_dir, tok[1])):
-                    mat_index.setdefault(m["name"], len(obj_materials))
-                    obj_materials.append(m)
-            elif k == "usemtl":
-                cur_mat = mat_index.get(" ".join(tok[1:]), -1)
-            elif k == "f":
-                corners = []
-                for c in tok[1:]:
-                    parts = c.split("/")
-                    vi = resolve(int(parts[0]), len(positions))
-                    ti = resolve(int(parts[1]), len(texcoords)) if len(parts) > 1 and parts[1] else -1
-                    ni = resolve(int(parts[2]), len(normals), True) if len(parts) > 2 and parts[2] else -1
-                    corners.append((vi, ni, ti))
-                for tri in _triangulate(corners, positions):
-                    s = shape()
-                    s["faces"].append(tri)
-                    s["mats"].append(cur_mat)
+    with open(path, newline="") as f:
+        text = f.read()
+    for line in re.split(r"\r\n|\n|\r", text):
+        tok = line.split()
+        if not tok or tok[0].startswith("#"):
+            continue
+        k = tok[0]
+        body = line.lstrip(" \t")
+        # tinyobjloader recognises a statement by its keyword AND a blank right after it: a bare `o`, `g`, `usemtl`, `v` is skipped
+        if not (len(body) > len(k) and body[len(k)] in " \t"):
+            continue
+        if k == "v":
+            positions.append([_num(x) for x in tok[1:4]])
+        elif k == "vn":
+            normals.append(None)  # counted only: the hot path reads no normals (quirk Q7); the native reader does the same
+        elif k == "vt":
+            texcoords.append([_num(tok[1]), _num(tok[2]) if len(tok) > 2 else 0.0])
+        elif k in ("o", "g"):
+            # tinyobjloader hands the faces read so far to the current shape when the MATERIAL changes (usemtl), and its `o`
+            # statement keeps the shape only if there are faces it has not handed over yet (util/tiny_obj_loader.h:2117-2123;
+            # `g` and the end of the file look at the shape itself): an `o` right after a material-changing `usemtl` LOSES the
+            # object before it. The reference's scenes are what that makes of a file, so the faces are dropped here, too.
+            if k == "o" and cur is not None and cur["faces"] and not since_change:
+                cur["faces"], cur["mats"] = [], []
+            since_change = False
+            if cur is not None and not cur["faces"]:
+                continue  # tinyobj does not emit empty shapes
+            cur = None
+        elif k == "mtllib":
+            for m in _parse_mtl(os.path.join(base_dir, body[7:].split(" ")[0])):  # (the first of several names is the file, see load_obj)
+                mat_index.setdefault(m["name"], len(obj_materials))
+                obj_materials.append(m)
+        elif k == "usemtl":
+            new_mat = mat_index.get(body[7:], -1)  # the name as it stands after the keyword and ONE blank
+            if new_mat != cur_mat:
+                since_change = False
+                cur_mat = new_mat
+        elif k == "f":
+            since_change = True
+            corners = []
+            for c in tok[1:]:
+                parts = c.split("/")
+                vi = resolve(int(parts[0]), len(positions))
+                ti = resolve(int(parts[1]), len(texcoords)) if len(parts) > 1 and parts[1] else -1
+                ni = resolve(int(parts[2]), len(normals), True) if len(parts) > 2 and parts[2] else -1
+                corners.append((vi, ni, ti))
+            for tri in _triangulate(corners, positions):
+                s = shape()
+                s["faces"].append(tri)
+                s["mats"].append(cur_mat)
     shapes = [s for s in shapes if s["faces"]]
     if not shapes:
         raise ValueError(f"no faces in {path}")

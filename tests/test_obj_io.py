@@ -302,3 +302,48 @@ def test_random_mtl_files_against_the_live_reference_importer(tmp_path):
         for k, v in ref.items():
             if not k.endswith("_n_normals"):
                 assert k in mine and v.shape == mine[k].shape and v.tobytes() == np.asarray(mine[k]).astype(v.dtype).tobytes(), (seed, k)
+
+
+def test_statement_level_quirks_against_the_live_reference_importer(tmp_path):
+    """80 seeded OBJ files about STATEMENTS rather than numbers: bare `o` / `g` / `usemtl` (not statements for tinyobjloader: a
+    keyword needs a blank after it), `usemtl` names with a second blank before or a blank after them (they name another
+    material, i.e. none), `mtllib` with two names, with two blanks (the first name is then empty and the OBJ's directory is
+    "read"), a second `mtllib` further down that redefines a name (the first definition stays), `g` with several names, `s`,
+    `vp`, vertices with 4 and 6 values, texture coordinates with 1 and 3. Native reader == Python twin == reference, every array."""
+    from tests import ref_scene_lib as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libref_scene.so is built where /root/reference exists")
+    d = str(tmp_path)
+    open(os.path.join(d, "m.mtl"), "w").write("newmtl shiny\nKd 0.2 0.4 0.6\nNs 250\nnewmtl dull stuff\nKd 1 0 0\nNs 0\n")
+    open(os.path.join(d, "n.mtl"), "w").write("newmtl other\nKd 0 0 1\nnewmtl shiny\nKd 1 1 1\n")
+    p = os.path.join(d, "f.obj")
+    for seed in range(80):
+        rng = np.random.default_rng(3000 + seed)
+        num = lambda: f"{float(rng.normal()):.5g}"
+        lines, nv, nvt = ["vn 0 0 1"], 0, 0
+        if rng.random() < 0.8:
+            lines.append(str(rng.choice(["mtllib m.mtl", "mtllib m.mtl n.mtl", "mtllib  m.mtl", "mtllib n.mtl"])))
+        for _ in range(int(rng.integers(1, 4))):
+            for _ in range(int(rng.integers(3, 8))):
+                lines.append("v " + " ".join(num() for _ in range(int(rng.choice([3, 3, 3, 4, 6])))))
+                nv += 1
+            for _ in range(int(rng.integers(1, 4))):
+                lines.append("vt " + " ".join(num() for _ in range(int(rng.choice([2, 2, 3, 1])))))
+                nvt += 1
+            lines.append(str(rng.choice(["o a", "g a b", "g", "o", "g a", "s 1", "s off", "o  spaced  name "])))
+            if rng.random() < 0.3:
+                lines.append("mtllib n.mtl")
+            if rng.random() < 0.8:
+                lines.append(str(rng.choice(["usemtl shiny", "usemtl  shiny", "usemtl shiny ", "usemtl dull stuff", "usemtl other", "usemtl\tshiny", "usemtl"])))
+            for _ in range(int(rng.integers(1, 5))):
+                lines.append("f " + " ".join(f"{int(rng.integers(1, nv + 1))}/{int(rng.integers(1, nvt + 1))}" for _ in range(int(rng.choice([3, 3, 4])))))
+                if rng.random() < 0.2:
+                    lines.append(str(rng.choice(["s 2", "g", "usemtl dull stuff", "# c", "vp 0 0"])))
+        with open(p, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        native, twin = load_obj(p), load_obj(p, reader="python")
+        _same_scene(native, twin)
+        ref, mine = R.load(p), R.flatten(native)
+        for k, v in ref.items():
+            if not k.endswith("_n_normals"):
+                assert k in mine and v.shape == mine[k].shape and v.tobytes() == np.asarray(mine[k]).astype(v.dtype).tobytes(), (seed, k)
