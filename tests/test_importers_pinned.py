@@ -162,3 +162,91 @@ def test_random_crts_scenes_against_the_live_reference_importer(tmp_path):
             _compare(R.load(path, white_diffuse=wd), _ours(path, wd), f"crts fuzz seed {seed} wd {wd}")
             compared += 1
     assert compared == 48
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref_scene.so is built where /root/reference exists")
+def test_random_gltf_contents_against_the_live_reference_importer(tmp_path):
+    """60 seeded glTF / GLB files about CONTENT (util/scene.cpp:230-415): 0 ... 3 embedded or data-URI PNG images of 3 and 4
+    channels, textures, materials with any subset of baseColorFactor / metallicFactor / roughnessFactor / baseColorTexture /
+    metallicRoughnessTexture (or none at all), meshes of 1 ... 3 primitives with interleaved or separate POSITION / TEXCOORD_0,
+    16- and 32-bit indices whose count need not be a multiple of three, primitives with and without a material, nodes with and
+    without meshes, a missing default scene -- in both material modes: every array of the reference's Scene bit for bit, or
+    both importers refuse."""
+    import base64
+    from chameleonrt_amd.gltf_io import load_gltf
+    from tests.test_gltf_io import Builder, _png
+    d, bad = str(tmp_path), 0
+    for seed in range(60):
+        rng=np.random.default_rng(seed)
+        b=Builder()
+        n_img=int(rng.integers(0,3))
+        b.doc["images"]=[]; b.doc["textures"]=[]
+        for k in range(n_img):
+            ch=int(rng.choice([4,4,3]))
+            arr=rng.integers(0,256,(int(rng.integers(1,5)),int(rng.integers(1,5)),4),dtype=np.uint8)
+            if ch==3: arr[...,3]=255
+            png=_png(arr)
+            if rng.random()<0.5:
+                b.doc["images"].append({"bufferView": b.view(png), "mimeType":"image/png", "name": f"img{k}"})
+            else:
+                            b.doc["images"].append({"uri":"data:image/png;base64,"+base64.b64encode(png).decode()})
+        for k in range(int(rng.integers(0,4)) if n_img else 0):
+            b.doc["textures"].append({"source": int(rng.integers(0,n_img))})
+        mats=[]
+        for m in range(int(rng.integers(0,4))):
+            pbr={}
+            if rng.random()<0.7: pbr["baseColorFactor"]=[float(x) for x in rng.random(4)]
+            if rng.random()<0.6: pbr["metallicFactor"]=float(rng.random())
+            if rng.random()<0.6: pbr["roughnessFactor"]=float(rng.random())
+            if b.doc["textures"] and rng.random()<0.5: pbr["baseColorTexture"]={"index": int(rng.integers(0,len(b.doc["textures"])))}
+            if b.doc["textures"] and rng.random()<0.4: pbr["metallicRoughnessTexture"]={"index": int(rng.integers(0,len(b.doc["textures"])))}
+            mat={"pbrMetallicRoughness": pbr} if (pbr or rng.random()<0.5) else {}
+            if rng.random()<0.3: mat["name"]="m%d"%m
+            mats.append(mat)
+        if mats: b.doc["materials"]=mats
+        meshes=[]
+        for me in range(int(rng.integers(1,4))):
+            prims=[]
+            for p in range(int(rng.integers(1,4))):
+                nv=int(rng.integers(3,9)); nt=int(rng.integers(1,5))
+                pos=rng.normal(size=(nv,3)).astype(np.float32)
+                att={}
+                if rng.random()<0.5:
+                    uv=rng.random((nv,2)).astype(np.float32)
+                    inter=np.concatenate([pos,uv],1).astype(np.float32)
+                    vi=b.view(inter.tobytes(), stride=20)
+                    att["POSITION"]=b.accessor(vi,5126,"VEC3",nv); att["TEXCOORD_0"]=b.accessor(vi,5126,"VEC2",nv,offset=12)
+                else:
+                    att["POSITION"]=b.accessor(b.view(pos.tobytes()),5126,"VEC3",nv)
+                    if rng.random()<0.4: att["TEXCOORD_0"]=b.accessor(b.view(rng.random((nv,2)).astype(np.float32).tobytes()),5126,"VEC2",nv)
+                idx=rng.integers(0,nv,nt*3+int(rng.choice([0,0,1,2])))
+                if rng.random()<0.5: ai=b.accessor(b.view(np.uint16(idx).tobytes()),5123,"SCALAR",len(idx))
+                else: ai=b.accessor(b.view(np.uint32(idx).tobytes()),5125,"SCALAR",len(idx))
+                pr={"attributes":att,"indices":ai}
+                if mats and rng.random()<0.7: pr["material"]=int(rng.integers(0,len(mats)))
+                if rng.random()<0.3: pr["mode"]=4
+                prims.append(pr)
+            meshes.append({"primitives":prims})
+        b.doc["meshes"]=meshes
+        nodes=[]
+        for n in range(int(rng.integers(1,5))):
+            nd={}
+            if rng.random()<0.85: nd["mesh"]=int(rng.integers(0,len(meshes)))
+            if rng.random()<0.5: nd["translation"]=[float(x) for x in rng.normal(size=3)]
+            nodes.append(nd)
+        b.doc["nodes"]=nodes; b.doc["scenes"][0]["nodes"]=list(range(len(nodes)))
+        if rng.random()<0.3: del b.doc["scene"]
+        glb=bool(seed%2)
+        path=os.path.join(d,"f."+("glb" if glb else "gltf")); b.finish(path,glb=glb)
+        for wd in (False,True):
+            try: ref=R.load(path,white_diffuse=wd)
+            except Exception as e: ref=e
+            try: mine=R.flatten(load_gltf(path, material_mode="white_diffuse" if wd else "default"))
+            except Exception as e: mine=e
+            if isinstance(ref,Exception) or isinstance(mine,Exception):
+                if not (isinstance(ref,Exception) and isinstance(mine,Exception)):
+                    bad+=1; print(seed,wd,'RAISE ref',repr(ref)[:100] if isinstance(ref,Exception) else 'ok','| mine',repr(mine)[:100] if isinstance(mine,Exception) else 'ok')
+                continue
+            diff=[k for k in ref if not k.endswith('n_normals') and (k not in mine or ref[k].shape!=np.asarray(mine[k]).shape or ref[k].tobytes()!=np.asarray(mine[k]).astype(ref[k].dtype).tobytes())]
+            if diff: bad+=1; print(seed,wd,'DIFF',diff[:5])
+    assert bad == 0
