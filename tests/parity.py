@@ -103,3 +103,39 @@ def awkward_instances():
                instances=insts, materials=[disney_material(), disney_material()], lights=[obj_default_light()],
                cameras=[Camera(np.array([0, 2, 14], np.float32), np.zeros(3, np.float32), np.array([0, 1, 0], np.float32), 50.0)])
     return sc
+
+
+def random_material_grove(seed):
+    """(scene, width, height): the instanced grove with EVERY material replaced by random Disney parameters over their whole ranges
+    -- metallic, specular, roughness down to 0, anisotropy, sheen, clearcoat, ior in [1, 2.5], specular transmission on a third of
+    them (the reference's glass: negative pdfs, non-finite throughputs, NaN pixels) --, 1 ... 3 quad lights of random size,
+    place and direction, an odd framebuffer size, 1 ... 3 spp. (Parameters are >= 0: a sign bit is a texture handle.)"""
+    from chameleonrt_amd import scenes
+    from chameleonrt_amd.scene import ortho_basis, quad_light
+    rng = np.random.default_rng(4242 + seed)
+    sc = scenes.instanced_grove(spp=int(rng.integers(1, 4)), n_instances=int(rng.integers(2, 10)), leaves_per_tree=int(rng.integers(10, 60)),
+                                tex_size=8, seed=seed + 11)
+    for m in sc.materials:
+        textured = np.asarray(m[0:1], np.float32).view(np.uint32)[0] & 0x80000000
+        r = rng.random(16).astype(np.float32)
+        if not (textured and rng.random() < 0.5):
+            m[0:3] = r[0:3]                      # base colour (half of the textured ones keep their texture handle)
+        m[3] = r[3] if rng.random() < 0.7 else np.float32(rng.choice([0.0, 1.0]))     # metallic
+        m[4] = r[4]                              # specular
+        m[5] = r[5] if rng.random() < 0.8 else np.float32(rng.choice([0.0, 1.0]))     # roughness
+        m[6] = r[6]                              # specular tint
+        m[7] = r[7] if rng.random() < 0.5 else np.float32(0)                           # anisotropy
+        m[8], m[9] = (r[8], r[9]) if rng.random() < 0.5 else (np.float32(0), np.float32(0))    # sheen, sheen tint
+        m[10], m[11] = (r[10], r[11]) if rng.random() < 0.5 else (np.float32(0), np.float32(0))  # clearcoat, gloss
+        m[12] = np.float32(1.0 + 1.5 * r[12])    # ior
+        m[13] = r[13] if rng.random() < 0.33 else np.float32(0)                         # specular transmission
+    lights = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = rng.normal(size=3).astype(np.float32)
+        n /= np.linalg.norm(n)
+        pos = (rng.normal(size=3) * 6).astype(np.float32)
+        v_x, v_y = ortho_basis(n)
+        e = float(rng.uniform(2, 40))
+        lights.append(quad_light([e, e, e, e], pos, n, v_x, v_y, float(rng.uniform(0.2, 8)), float(rng.uniform(0.2, 8))))
+    sc.lights = lights
+    return sc, int(rng.integers(33, 97)), int(rng.integers(17, 65))

@@ -88,3 +88,21 @@ def test_oracle_matches_reference_kernel_live(case, oracle):
         o.render(*cam, f == 0)
     ofb = o.framebuffer().view(np.uint8).reshape(h, w, 4)
     _assert_identical((o.accum(), ofb, o.ray_counts()), ref_lib.render(sc, w, h, *cam, frames), case)
+
+
+@needs_ref
+def test_oracle_matches_reference_kernel_on_random_materials(oracle):
+    """24 seeded variations of the instanced grove: EVERY material replaced by random Disney parameters over their whole ranges --
+    metallic, specular, roughness down to 0, anisotropy, sheen, clearcoat, ior in [1, 2.5], specular transmission on a
+    third of them (the reference's glass: negative pdfs, non-finite throughputs, NaN pixels) -- random light sizes and positions,
+    1 ... 3 lights, odd framebuffer sizes, 1 ... 3 spp, two accumulated frames. Oracle == the reference's own kernel, every bit of
+    the accumulated radiance (NaN and inf included), RGBA8 and the per-pixel ray statistics."""
+    from tests.parity import random_material_grove
+    for seed in range(24):
+        sc, w, h = random_material_grove(seed)
+        cam = camera_of(sc)
+        o = oracle.OracleRenderer(sc, w, h)
+        for f in range(2):
+            o.render(*cam, f == 0)
+        ofb = o.framebuffer().view(np.uint8).reshape(h, w, 4)
+        _assert_identical((o.accum(), ofb, o.ray_counts()), ref_lib.render(sc, w, h, *cam, 2), f"random materials, seed {seed}")
