@@ -3,6 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload C4] [--scaling strong|weak]
 
+With N > 1 and no launcher around it (no WORLD_SIZE in the environment) the command starts its own ranks: it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 --master-port <free>`
+with G = min(N, devices present), forwards its arguments, lets rank 0 print the ONE JSON line and returns the launcher's
+exit code (non-zero if any rank failed). On a box with fewer than N devices the line says so (`requested_gpus`,
+`degraded`) and `n_gpus` is what actually ran. Under a launcher (the driver's torchrun form) it is one rank, as before.
+
 A "step" is one frame: one pass of the hot path over every pixel-sample of the workload
 (`-benchmark-frames` protocol of the reference, main.cpp:293-345: fixed camera, camera_changed only on
 frame 0). Default workload: the north-star target, the San-Miguel-like scene at 1920x1080, 16 spp
@@ -42,7 +48,7 @@ NODE_VISIT_CYCLES_L2, NODE_VISIT_CYCLES_HBM = 2.06, 10.25
 SLOT_VISIT_CYCLES_L2, SLOT_VISIT_CYCLES_HBM = 2.77, 10.64
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -67,10 +73,67 @@ def parse():
     ap.add_argument("--no-speed-mode", action="store_true", help="N = 1: do not also time the opt-in fast-math build")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic = null)")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-kernel counter sums in")
+    ap.add_argument("--requested-gpus", type=int, default=None, help=argparse.SUPPRESS)  # set by self_launch for its ranks
+    ap.add_argument("--dump-image", default=None, metavar="PATH",
+                    help="rank 0: np.save the last timed frame's assembled RGBA8 image (uint32, height x width) here (tests: the "
+                         "gathered N > 1 image must equal the N = 1 image bit for bit)")
     ap.add_argument("--also", default=None, metavar="WxHxSPP",
                     help="N > 1: after the headline, time the same scene at another resolution / spp too (reported as `c5`); default "
                          "at --gpus 8 on C4: 3840x2160x64 = BASELINE.json's own 8-GPU configuration C5; 'none' switches it off")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(argv, requested, ranks, port):
+    """The command line `python bench.py --gpus <requested> ...` turns into when it starts its own `ranks` processes:
+    the driver's own launcher form, argv forwarded with --gpus set to what runs and the request kept in --requested-gpus."""
+    fwd, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("--gpus", "--requested-gpus"):
+            skip = True
+            continue
+        if a.startswith("--gpus=") or a.startswith("--requested-gpus="):
+            continue
+        fwd.append(a)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(ranks), "--requested-gpus", str(requested)] + fwd
+
+
+def devices_present():
+    """HIP devices on this box, asked of the product library (hipGetDeviceCount: no context is created in the parent)."""
+    from chameleonrt_amd import core
+    return int(core.load().crt_hip_device_count())
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside any launcher. Returns None if this process should go on as the only
+    rank (one usable device: the degraded N = 1 run), otherwise the exit code of the launcher it ran."""
+    import subprocess
+    share = os.environ.get("CRT_BENCH_SHARE_GPU") == "1"  # tests: N ranks on one device over gloo
+    have = devices_present()
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    ranks = args.gpus if share else min(args.gpus, have)
+    args.requested_gpus = args.gpus
+    if ranks == 1:
+        print(f"[bench] --gpus {args.gpus} asked for, {have} device(s) present: running 1 rank in this process", file=sys.stderr)
+        args.gpus = 1
+        return None
+    if ranks < args.gpus:
+        print(f"[bench] --gpus {args.gpus} asked for, {have} device(s) present: launching {ranks} ranks", file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // ranks)))
+    return subprocess.call(launch_command(argv, args.gpus, ranks, free_port()), env=env)
 
 
 def usable_cores():
@@ -234,6 +297,10 @@ def timed_frames(loop, args, dist, first_frame):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        rc = self_launch(args, sys.argv[1:])
+        if rc is not None:
+            sys.exit(rc)
     import numpy as np
     import torch
     from chameleonrt_amd import core, scenes
@@ -243,9 +310,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus:  # under a launcher the launcher's world size is what runs; the line reports it as n_gpus
+        if args.requested_gpus is None:
+            args.requested_gpus = args.gpus
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -394,6 +461,26 @@ def main():
                                                if cache_hit else "miss",
                        "set_scene_upload_s": round(t_upload, 2), "host_build_threads": usable_cores()},
         }
+        if args.requested_gpus is not None and args.requested_gpus != world:
+            out["requested_gpus"] = args.requested_gpus
+            out["degraded"] = (f"--gpus {args.requested_gpus} needs {args.requested_gpus} devices, this box has "
+                               f"{devices_present()}: ran {world} rank(s); n_gpus and value are what ran")
+
+    if args.dump_image:
+        # the frame the timed loop ended on, through the same hand-off at every N: the compact tile buffers of that frame are
+        # gathered (N = 1: taken as they are), K8 assembles them on rank 0 and the row-major image is read back
+        ptr, nbytes = r.tile_buffer()
+        view = loop.views.get(ptr)
+        if view is None:
+            view = wrap_device_buffer(ptr, nbytes)
+        if world > 1:
+            g = loop.multi_gpu.gather_tile_buffers(view.cpu() if share_gpu else view)
+        else:
+            g = view.clone()
+        torch.cuda.synchronize()
+        if rank == 0:
+            r.assemble_tiles((g.cuda() if (share_gpu and world > 1) else g).data_ptr(), world, readback=True)
+            np.save(args.dump_image, np.array(r.img, copy=True).view(np.uint32).reshape(height, width))
 
     # ---- N = 1: the same frames with the other launch schedule (the library's default is the overlapped one; the
     # headline times the serial one because only then is a kernel's event span its own execution time) ----
@@ -410,6 +497,11 @@ def main():
                             other_sched: {"ms_per_step": round(e2 / args.steps * 1e3, 4), "value": round(rays2 / e2 / 1e6, 2)},
                             "note": "serial: the 17 launches of a frame one after the other (headline: per-kernel spans are execution "
                                     "times); overlap: occlusion(b) next to closest-hit(b+1) on a second stream, the library's default"}
+        ov = out["schedules"]["overlap"]
+        out["strong_scaling_base"] = {"schedule": "overlap", "ms_per_step": ov["ms_per_step"], "value": ov["value"],
+                                      "note": "bench.py --gpus N (N > 1) times the overlapped schedule by default (config.schedule says which): "
+                                              "a strong-scaling ratio divides its value by THIS one, not by the serial headline of N = 1 "
+                                              "(or pass --schedule to both)"}
 
     # ---- N = 1: the opt-in elision of occlusion rays whose result cannot reach the image (CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS,
     # include/crt_hip.h): same frames, bit-identical images and ray statistics (tests/test_gpu_elide.py). The HEADLINE traces
