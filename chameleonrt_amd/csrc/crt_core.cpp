@@ -429,13 +429,6 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
     try {
         c->device = device_id;
         c->flags = flags;
-        // test hook: CRT_HIP_FORCE_ELIDE=1 turns CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS on for EVERY context of the process, so that the whole
-        // parity suite (frames against the oracle at every configuration) can be run over the elision path (profiles/r05_gpu_tests_elide.txt)
-        if (const char *force = std::getenv("CRT_HIP_FORCE_ELIDE")) {
-            if (force[0] == '1') {
-                c->flags |= CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS;
-            }
-        }
         HIP_CHECK(hipSetDevice(device_id));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device_id));

@@ -320,8 +320,10 @@ private:
             h_max = std::max(h_max, comp[i].h);
             v_max = std::max(v_max, comp[i].v);
         }
-        // every component's sampling factor must divide the largest one (as current stb_image demands): to_rgba up-samples by
-        // the integer ratio h_max / h, and with H = 3, 2, 1 that ratio would read past a plane only mcu_x * h * 8 wide
+        // every component's sampling factor must divide the largest one: to_rgba up-samples by the integer ratio h_max / h, and
+        // with H = 3, 2, 1 that ratio would read past a plane only mcu_x * h * 8 wide. A DELIBERATE DIVERGENCE for malformed files:
+        // the reference's bundled stb_image (v2.23, util/stb_image.h) has no such check and decodes them (reading out of bounds);
+        // later stb_image releases added it. Refusing is the safe choice; it is not parity for these files.
         for (int i = 0; i < n_comp; ++i) {
             if (h_max % comp[i].h != 0 || v_max % comp[i].v != 0) {
                 throw Fail("bad H / V: sampling factors that do not divide the largest");
@@ -411,7 +413,7 @@ private:
     void decode_block(int16_t data[64], Component &c)
     {
         const int t = huff_decode(dc_tab[c.hd]);
-        if (t < 0 || t > 15) { // (a DC category is a bit count: more than 15 would shift by >= 32 in receive_extend)
+        if (t < 0 || t > 15) { // (a DC category is a bit count: more than 15 would shift by >= 32 in receive_extend; the reference's stb_image v2.23 does not check and has undefined behaviour there -- refusing the file is deliberate, not parity)
             throw Fail("bad huffman code");
         }
         std::memset(data, 0, 64 * sizeof(int16_t));

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstddef>
 #include <cstdlib>
 
@@ -1026,7 +1027,18 @@ uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_
 uint32_t traversal_lds_stack(uint32_t levels) { return (uint32_t)lds_stack_of((int)levels); }
 int traversal_child_order() { return CRT_CHILD_ORDER; }
 
-static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu) { return cfg.n_cus * blocks_per_cu; }
+static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu)
+{
+    // the ray pool's chunk indices are 32-bit (traverse.h pool_take: wave w owns chunk w, the cursor hands out the chunks after the
+    // grid's first helping): every wave of the grid must have a first chunk whose first ray index still fits 32 bits. 256 CUs x 7
+    // blocks x 4 waves x 128 rays = 917 504; the bound is 2^32 / CRT_POOL_CHUNK waves.
+    const long long waves = (long long)cfg.n_cus * blocks_per_cu * (TRACE_BLOCK / 64);
+    if (waves * (long long)CRT_POOL_CHUNK >= (1ll << 32)) {
+        std::fprintf(stderr, "[crt_hip] traversal grid of %lld waves x %d-ray chunks overflows the ray pool's 32-bit indices\n", waves, (int)CRT_POOL_CHUNK);
+        std::abort();
+    }
+    return cfg.n_cus * blocks_per_cu;
+}
 static inline int capped_grid(const LaunchCfg &cfg, uint32_t n, int block)
 {
     const uint32_t want = (n + block - 1) / block;

@@ -485,13 +485,31 @@ struct Parser {
                     faces_since_change = false;
                 }
             } else if (len == 6 && std::memcmp(kw, "mtllib", 6) == 0) {
-                // file names separated by single blanks; tinyobjloader tries them in turn and stops at the first that loads --
-                // and the reference's importer throws on any that does not -- so the first name is the file (obj_io.py)
+                // File names separated by single blanks (SplitString = std::getline with ' ', util/tiny_obj_loader.h:1343-1351: two
+                // blanks in a row name "" in between, a trailing blank names nothing). tinyobjloader tries them in turn and stops at
+                // the first that OPENS (tiny_obj_loader.h:2031-2049; MaterialFileReader, :1741-1749, only WARNS about a file it
+                // cannot open and returns false). If none opens it warns "Failed to load material file(s). Use default material."
+                // and goes on: no material is defined by this statement, every later `usemtl` of an unknown name resolves to -1,
+                // and the reference's importer gives those geometries its default material (Scene::load_obj throws only on
+                // !ret || !err.empty(), util/scene.cpp:110; a missing .mtl sets neither). OBJ files whose .mtl is absent are common.
                 const std::string rest = raw_rest(p + 1);
-                mtllibs.emplace_back(rest.substr(0, rest.find(' ')));
-                if (!read_material_names(mtllibs.back())) {
-                    error = "cannot read the material library " + mtllibs.back();
-                    return false;
+                bool found = false;
+                size_t at = 0;
+                while (!found && at < rest.size()) {
+                    const size_t blank = rest.find(' ', at);
+                    const std::string name = rest.substr(at, blank == std::string::npos ? std::string::npos : blank - at);
+                    if (read_material_names(name)) {
+                        mtllibs.emplace_back(name);
+                        found = true;
+                    }
+                    if (blank == std::string::npos) {
+                        break;
+                    }
+                    at = blank + 1;
+                }
+                if (!found) {
+                    std::fprintf(stderr, "[crt_scene_io] no material library of `mtllib %s` could be opened in %s: the default material is used\n",
+                                 rest.c_str(), base_dir.empty() ? "." : base_dir.c_str());
                 }
             }
             skip_line();

@@ -8,6 +8,12 @@
 // executed. Only the libm transcendentals (pow, log, sin, cos, atan2, acos) differ from a
 // CPU build by a few ulp.
 #pragma once
+// Timing experiments that render a WRONG image (CRT_EXP_SHADE_*: what a part of k_shade costs, by leaving it out) must never reach
+// a product build through a stray -D: they compile only together with an explicit -DCRT_EXPERIMENTS=1 (tools/variants.py builds).
+#if (defined(CRT_EXP_SHADE_ONE_MAT) || defined(CRT_EXP_SHADE_NO_UV) || defined(CRT_EXP_SHADE_NO_NEE) || defined(CRT_EXP_SHADE_NO_SAMPLE) || \
+     defined(CRT_EXP_SHADE_NO_TEX)) && !defined(CRT_EXPERIMENTS)
+#error "CRT_EXP_SHADE_* builds render wrong images (timing experiments only): define CRT_EXPERIMENTS=1 as well"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -253,6 +253,21 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #ifndef CRT_ENTRY_IN_INNER
 #define CRT_ENTRY_IN_INNER 0
 #endif
+// Postponed leaves ("speculative while-while", Aila & Laine 2009), single trees and world trees. A lane that reaches a leaf does
+// not drop out of the inner-node phase: it keeps the leaf's reference (`post`), pops its next reference and walks on; the
+// leaf phase tests postponed leaves. More lanes per inner step, denser leaf steps -- for node visits whose children are
+// tested against a hit distance the postponed leaf has not shortened yet (closest hit), or that an occluder in the postponed
+// leaf makes useless (occlusion). Results do not depend on it: closest hit = lexicographic minimum, occlusion = boolean.
+//   0  off: a lane on a leaf waits for the leaf phase (rounds 1-5)
+//   1  opportunistic: the leaf phase tests every postponed leaf, wherever its lane has got to meanwhile
+//   2  deterministic: a postponed leaf is tested only once its lane has reached its NEXT leaf (or emptied its stack) -- the
+//      per-ray visit sequence then does not depend on the other lanes of the wave
+#ifndef CRT_SPECULATE_CLOSEST
+#define CRT_SPECULATE_CLOSEST 0
+#endif
+#ifndef CRT_SPECULATE_ANYHIT
+#define CRT_SPECULATE_ANYHIT 0
+#endif
 constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
 constexpr int32_t CUR_EXIT = (int32_t)0x80000003; // two level: the lane popped the sentinel and has to leave its instance
 
@@ -385,6 +400,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         const uint32_t bg = b.geom_sel & SLOT_GEOM_MASK, bp = (hit.tri & 1) != 0 ? b.prim1 : b.prim0;
         return geom != bg ? geom < bg : prim < bp;
     };
+    constexpr int SPEC = TWO_LEVEL ? 0 : ANY_HIT ? CRT_SPECULATE_ANYHIT : CRT_SPECULATE_CLOSEST;
+    int32_t post = 0; // SPEC: the postponed leaf reference (negative), 0 = none
     int32_t cur_inst = TWO_LEVEL ? sc.world_inst : 0;
     bool in_blas = !TWO_LEVEL;
     static_assert(!(INST_TRIS && TWO_LEVEL), "per-triangle instances belong to the single tree in world space");
@@ -452,6 +469,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         hit.inst = -1;
         st.clear();
         cur = sc.root;
+        if (SPEC) {
+            post = 0;
+        }
     };
 
     // Take the next reference off the stack (or finish). Popping the instance-exit sentinel only MARKS the lane
@@ -537,12 +557,16 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
             continue;
         }
         // lanes with a ray still being traversed (a finished ray may wait for its batch to retire)
-        const uint32_t n_active = (uint32_t)__popcll(__ballot(ray >= 0 && cur != CUR_DONE));
+        const uint32_t n_active = (uint32_t)__popcll(__ballot(ray >= 0 && (cur != CUR_DONE || (SPEC && post < 0))));
 
         // ---- inner-node phase: step while at least 2/3 of the active lanes are on an inner node
         for (;;) {
             // (two level, CRT_ENTRY_IN_INNER = 1, a measured loss) a lane whose next reference is a TLAS leaf enters its
             // instance in THIS phase, sharing the wave's wait with the other lanes' node fetches
+            if (SPEC && ray >= 0 && cur < 0 && cur != CUR_DONE && post >= 0) { // postpone the leaf, walk on
+                post = cur;
+                pop_next();
+            }
             const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur != CUR_DONE && !in_blas && is_instance_leaf(cur);
             const bool inner = (ray >= 0 && cur >= 0) || enter;
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
@@ -661,8 +685,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         }
 
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
-        const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(__ballot(ray >= 0 && cur < 0 && cur != CUR_DONE)) : 0u;
-        if (ray >= 0 && cur < 0 && cur != CUR_DONE) {
+        const bool leaf_lane = SPEC ? (ray >= 0 && post < 0 && (SPEC == 1 || cur < 0)) : (ray >= 0 && cur < 0 && cur != CUR_DONE);
+        const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(__ballot(leaf_lane)) : 0u;
+        if (leaf_lane) {
             bool entered = false;
             if (TWO_LEVEL && cur == CUR_EXIT) {
                 // Leave the instance. If the next reference is another instance (rays through a layer of instanced
@@ -678,7 +703,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 }
                 entered = true; // this lane's step is used up unless it enters an instance now
             }
-            const uint32_t x = ~(uint32_t)cur;
+            const uint32_t x = ~(uint32_t)(SPEC ? post : cur);
             const uint32_t first = x >> 3;
             // top level: a leaf is an instance (count field 7) or, in a scene whose static mesh was grafted into the
             // top-level tree (scene_prepare.cpp), triangles of that mesh, tested right here with the world-space ray
@@ -692,7 +717,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 in_blas = true;
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
-            } else if (!entered && cur < 0 && cur != CUR_DONE) {
+            } else if (SPEC || (!entered && cur < 0 && cur != CUR_DONE)) {
                 const uint32_t count = (x & 7u) + 1u; // leaf slots (the builders make leaves of one)
                 bool occluded = false;
                 // ALL of the step's loads are issued before anything is tested: the slot -- one 64-byte line holding the
@@ -701,7 +726,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 // instance than the last one tested).
                 const float4 *p = reinterpret_cast<const float4 *>(sc.slots + first);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const bool have_next = !st.empty();
+                // (SPEC: the lane's next reference was popped when the leaf was postponed; nothing to fetch from the stack)
+                const bool have_next = !SPEC && !st.empty();
                 const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
                 // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
                 const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
@@ -783,10 +809,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                     q3 = pk[3];
                     test_slot(k);
                 }
+                if (SPEC) {
+                    post = 0;
+                }
                 if (ANY_HIT && occluded) {
                     hit.tri = 0;
                     hit.t = 0.f;
                     cur = CUR_DONE;
+                } else if (SPEC) {
+                    // cur is what the lane walked on to
                 } else if (!have_next) {
                     cur = CUR_DONE;
                 } else {
@@ -806,12 +837,12 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         // threshold (or nothing else is left to do in this wave), not one or two per iteration.
         bool do_retire = true;
         if (CRT_DEFER_RETIRE) {
-            const uint32_t n_done = (uint32_t)__popcll(__ballot(ray >= 0 && cur == CUR_DONE));
+            const uint32_t n_done = (uint32_t)__popcll(__ballot(ray >= 0 && cur == CUR_DONE && !(SPEC && post < 0)));
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(ray < 0));
             const uint32_t n_wait = exhausted ? n_done : n_done + n_idle;
             do_retire = n_wait >= CRT_REFILL_MIN || n_done + n_idle == 64u;
         }
-        if (do_retire && ray >= 0 && cur == CUR_DONE) {
+        if (do_retire && ray >= 0 && cur == CUR_DONE && !(SPEC && post < 0)) {
             if (COUNTERS && max_ray_nodes != nullptr && ray_nodes > 2000u) {
                 if (atomicMax(max_ray_nodes, ray_nodes) < ray_nodes) {
                     const V3 org = world_org(), dir = world_dir();

@@ -87,7 +87,11 @@ struct PassCounters {
     HotCounter n_shadow_a[MAX_PATH_DEPTH];
     HotCounter n_shadow_b[MAX_PATH_DEPTH];
     HotCounter n_shadow_elided[MAX_PATH_DEPTH]; // CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS: A rays counted but not enqueued
-    HotCounter cur_closest[MAX_PATH_DEPTH]; // dynamic ray-fetch cursors (one per launch)
+    // dynamic ray-fetch cursors (one per launch). They count CHUNKS of CRT_POOL_CHUNK rays, not rays, and only the chunks BEYOND the
+    // grid's static first helping (wave w owns chunk w, traverse.h CRT_POOL_STATIC_FIRST): a value's meaning is tied to the grid size
+    // of the launch that used it. Chunk indices are 32-bit: (cursor + waves of the grid) * CRT_POOL_CHUNK is compared with the queue
+    // size in 64 bits (pool_take), and the grid itself is checked on the host (kernels.hip persistent_grid).
+    HotCounter cur_closest[MAX_PATH_DEPTH];
     HotCounter cur_shadow_a[MAX_PATH_DEPTH];
     HotCounter cur_shadow_b[MAX_PATH_DEPTH];
     uint32_t max_ray_nodes; // CRT_HIP_FLAG_COUNTERS: most node fetches spent on one ray, and that ray

@@ -65,6 +65,27 @@ def _mtl_texture_name(rest: str):
     return name
 
 
+def _first_mtllib_that_opens(base_dir: str, rest: str):
+    """`mtllib a.mtl b.mtl`: tinyobjloader splits the rest of the line at single blanks (SplitString = std::getline with ' ',
+    util/tiny_obj_loader.h:1343-1351: two blanks in a row name "" in between, a trailing blank names nothing), tries the names in
+    turn and stops at the first that OPENS (:2031-2049). MaterialFileReader (:1741-1749) only WARNS about a file it cannot open; if
+    none opens, LoadObj warns "Failed to load material file(s). Use default material." and goes on -- the reference's importer
+    throws only on !ret || !err.empty() (util/scene.cpp:110), which a missing .mtl does not set: no material is defined, every
+    `usemtl` resolves to -1 and those geometries get the importer's default material. Returns the name, or None (with a warning)."""
+    names = rest.split(" ")
+    if names and names[-1] == "":
+        names.pop()  # (std::getline yields no empty item after a trailing delimiter)
+    for name in names:
+        path = os.path.join(base_dir, name)
+        # what std::ifstream opens: a readable file -- or a directory (`mtllib  a.mtl` names "" first: the OBJ's own directory
+        # opens as a stream, nothing can be read from it, and tinyobjloader is content with that: see _parse_mtl)
+        if os.path.isdir(path) or (os.path.isfile(path) and os.access(path, os.R_OK)):
+            return name
+    import warnings
+    warnings.warn(f"no material library of `mtllib {rest}` could be opened in {base_dir}: the default material is used")
+    return None
+
+
 def _parse_mtl(path: str) -> List[dict]:
     """tinyobjloader's LoadMtl (util/tiny_obj_loader.h:1353-1725) for the three things the reference's importer reads from a
     material (util/scene.cpp:191-216): Kd, Ns, map_Kd. Its defaults are ZERO diffuse and shininess 1 (InitMaterial); missing
@@ -360,7 +381,8 @@ def _load_obj_python(path: str, material_mode: str = "default", samples_per_pixe
                 continue  # tinyobj does not emit empty shapes
             cur = None
         elif k == "mtllib":
-            for m in _parse_mtl(os.path.join(base_dir, body[7:].split(" ")[0])):  # (the first of several names is the file, see load_obj)
+            lib = _first_mtllib_that_opens(base_dir, body[7:])
+            for m in (_parse_mtl(os.path.join(base_dir, lib)) if lib is not None else []):
                 mat_index.setdefault(m["name"], len(obj_materials))
                 obj_materials.append(m)
         elif k == "usemtl":

@@ -10,6 +10,19 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")
+    # CRT_TEST_FORCE_ELIDE=1 runs the whole suite over the opt-in elision path (CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS: occlusion rays
+    # whose answer the reference never looks at are counted, not traced -- same images, same ray statistics): every RenderHIP the
+    # tests create gets the flag, and the C++ plugin reads its own documented switch. The hook lives HERE, in the test harness, not in
+    # the shipped library (round 5 had it in crt_hip_create, where it silently changed every context of a process).
+    if os.environ.get("CRT_TEST_FORCE_ELIDE") == "1":
+        from chameleonrt_amd import core, render_hip
+        plain_init = render_hip.RenderHIP.__init__
+
+        def init_with_elision(self, device=0, flags=0, *args, **kwargs):
+            plain_init(self, device, flags | core.FLAG_ELIDE_UNUSED_SHADOW_RAYS, *args, **kwargs)
+
+        render_hip.RenderHIP.__init__ = init_with_elision
+        os.environ["CRT_HIP_ELIDE"] = "1"
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,7 @@
 """CPU: OBJ/MTL ingest (util/scene.cpp:94-228 semantics) -- round trip of synthetic scenes, vertex
 re-indexing on (position, normal, uv) triples, first-face material, MTL -> Disney mapping (quirk
 Q14), texture flip + 4 channels (quirk Q13), default material for material-less groups."""
+import contextlib
 import os
 
 import numpy as np
@@ -304,6 +305,35 @@ def test_random_mtl_files_against_the_live_reference_importer(tmp_path):
                 assert k in mine and v.shape == mine[k].shape and v.tobytes() == np.asarray(mine[k]).astype(v.dtype).tobytes(), (seed, k)
 
 
+def test_missing_material_library_is_a_warning_not_an_error(tmp_path):
+    """An OBJ whose `mtllib` names a file that is not there (common in the wild): tinyobjloader warns, tries the next name on
+    the line, and with none left uses no materials -- the reference renders the file with its default material
+    (util/tiny_obj_loader.h:1741-1749, 2031-2057; util/scene.cpp:110 throws on err only). Both readers do the same, and where
+    the reference's importer is built here, produce its arrays bit for bit."""
+    from tests import ref_scene_lib as R
+    d = str(tmp_path)
+    open(os.path.join(d, "real.mtl"), "w").write("newmtl red\nKd 1 0 0\nNs 10\n")
+    body = "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\ng a\nusemtl red\nf 1 2 3\ng b\nusemtl blue\nf 2 4 3\n"
+    for k, first in enumerate(("mtllib nothere.mtl", "mtllib nothere.mtl real.mtl", "mtllib my materials.mtl", "mtllib nothere.mtl\nmtllib real.mtl",
+                               "mtllib real.mtl nothere.mtl")):
+        p = os.path.join(d, f"f{k}.obj")
+        open(p, "w").write(first + "\n" + body)
+        with pytest.warns(UserWarning) if k in (0, 2) else contextlib.nullcontext():
+            twin = load_obj(p, reader="python")
+        native = load_obj(p)
+        _same_scene(native, twin)
+        ids = [int(x) for pm in native.parameterized_meshes for x in pm.material_ids]
+        if k in (0, 2):  # no library at all: nothing but the importer's default material
+            assert len(native.materials) == 1 and set(ids) == {0}
+        else:            # `red` is found in real.mtl, `blue` nowhere
+            assert len(set(ids)) == 2
+        if R.available():
+            ref, mine = R.load(p), R.flatten(native)
+            for key, v in ref.items():
+                if not key.endswith("_n_normals"):
+                    assert key in mine and v.shape == mine[key].shape and v.tobytes() == np.asarray(mine[key]).astype(v.dtype).tobytes(), (k, key)
+
+
 def test_statement_level_quirks_against_the_live_reference_importer(tmp_path):
     """80 seeded OBJ files about STATEMENTS rather than numbers: bare `o` / `g` / `usemtl` (not statements for tinyobjloader: a
     keyword needs a blank after it), `usemtl` names with a second blank before or a blank after them (they name another
@@ -322,7 +352,8 @@ def test_statement_level_quirks_against_the_live_reference_importer(tmp_path):
         num = lambda: f"{float(rng.normal()):.5g}"
         lines, nv, nvt = ["vn 0 0 1"], 0, 0
         if rng.random() < 0.8:
-            lines.append(str(rng.choice(["mtllib m.mtl", "mtllib m.mtl n.mtl", "mtllib  m.mtl", "mtllib n.mtl"])))
+            lines.append(str(rng.choice(["mtllib m.mtl", "mtllib m.mtl n.mtl", "mtllib  m.mtl", "mtllib n.mtl", "mtllib nothere.mtl",
+                                         "mtllib nothere.mtl n.mtl", "mtllib nothere.mtl alsonot.mtl", "mtllib m.mtl "])))
         for _ in range(int(rng.integers(1, 4))):
             for _ in range(int(rng.integers(3, 8))):
                 lines.append("v " + " ".join(num() for _ in range(int(rng.choice([3, 3, 3, 4, 6])))))
