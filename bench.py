@@ -41,12 +41,41 @@ NODE_BYTES, SLOT_BYTES = 48, 64  # bytes a visit fetches: 48 of a packed BVH4 no
 QUEUE_BYTES_CLOSEST = 24 + 32   # o,d read + the 32-byte hit record {t,u,v,tri | normal,material} written per ray
 QUEUE_BYTES_SHADOW = 28 + 16    # o,d,tmax + the 16-byte {c, path} record read per ray
 MAX_PATH_DEPTH = 5
-# CU-cycles of the vector-memory front end per divergent visit (tools/node_bytes_microbench.hip, 100 % of the lanes active,
-# profiles/r04_node_bytes_microbench.txt): the 48 bytes of a 64-byte node record (three dwordx4 per lane) / a 64-byte leaf
-# slot (four), working set in L2 (1 MB) / in HBM (1 GB)
+# CU-cycles of the vector-memory front end per divergent visit when the working set is L2-resident / in HBM, all lanes on (tools/
+# node_bytes_microbench.hip, profiles/r04_node_bytes_microbench.txt): the two-point LINEAR blend of rounds 4-5, kept for continuity
 NODE_VISIT_CYCLES_L2, NODE_VISIT_CYCLES_HBM = 2.06, 10.25
 SLOT_VISIT_CYCLES_L2, SLOT_VISIT_CYCLES_HBM = 2.77, 10.64
+# Round 6: the MEASURED cost of a divergent visit as a function of the L2 hit rate -- (hit rate, CU-cycles per lane-visit) of dependent
+# chains of uniformly random records whose working set goes from 1 MB (inside L2) through the Infinity Cache's reach to 1 GB (HBM), 7
+# waves per SIMD, at 100 % and at 66 % of the lanes per step (tools/miss_cost_microbench.hip, profiles/r06_miss_cost_microbench.txt, which
+# also has the latency of the L2's memory-side reads per row). A visit's cost is NOT a linear blend of a hit price and a miss price: a
+# wave's step waits for its slowest lane, so the first few per cent of misses cost most of a miss -- the linear blend was optimistic at
+# 90 % hits (C4) and, pricing every miss at the HBM figure, pessimistic at 50 % hits served by the Infinity Cache (C3).
+NODE_VISIT_CURVE = {100: [(0.999, 2.20), (0.998, 2.30), (0.942, 3.03), (0.732, 4.28), (0.427, 5.98), (0.258, 9.85), (0.168, 9.10), (0.107, 9.90), (0.066, 10.35)],
+                    66: [(1.000, 2.67), (0.998, 2.75), (0.531, 4.98), (0.281, 7.29), (0.156, 8.89), (0.091, 9.96), (0.059, 10.47), (0.042, 10.71), (0.032, 10.69)]}
+SLOT_VISIT_CURVE = {100: [(0.999, 2.86), (0.999, 2.94), (0.823, 4.18), (0.584, 5.05), (0.390, 6.63), (0.250, 8.42), (0.155, 9.66), (0.100, 10.37), (0.057, 10.66)],
+                    66: [(1.000, 3.32), (0.998, 3.35), (0.544, 4.99), (0.272, 7.14), (0.139, 8.69), (0.071, 9.76), (0.037, 10.26), (0.020, 10.46), (0.007, 10.69)]}
 
+
+def visit_cycles(curve, hit):
+    """Piecewise-linear reading of a measured (hit rate -> cycles per visit) curve, made monotone first (the cost never falls as the hit
+    rate falls: one row of the 100 %-lane node sweep, 67 MB, measured above its neighbours)."""
+    pts = sorted(curve, key=lambda p: -p[0])  # from all hits down
+    xs, ys, worst = [], [], 0.0
+    for h, c in pts:
+        worst = max(worst, c)
+        if xs and h == xs[-1]:
+            ys[-1] = max(ys[-1], worst)
+            continue
+        xs.append(h)
+        ys.append(worst)
+    if hit >= xs[0]:
+        return ys[0]
+    for k in range(1, len(xs)):
+        if hit >= xs[k]:
+            t = (xs[k - 1] - hit) / (xs[k - 1] - xs[k])
+            return ys[k - 1] + t * (ys[k] - ys[k - 1])
+    return ys[-1]
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
@@ -687,6 +716,11 @@ def main():
             if ta and gui_m:
                 out_k["vmem_front_end"] = {"ta_busy_frac": round(ta / (N_CUS * gui_m / 8.0), 4),
                                            "l2_hit_rate": round(hit / (hit + miss), 4) if hit is not None and miss else None}
+            lv, _ = counter("ea", name, "TCC_EA0_RDREQ_LEVEL_sum")
+            rq, _ = counter("ea", name, "TCC_EA0_RDREQ_sum")
+            if lv and rq:
+                # average latency of the L2's memory-side reads (L2 clocks): which regime the kernel's L2 misses are served in
+                out_k["ea_read_latency_l2_clocks"] = round(lv / rq)
             out_k["traffic"] = None if traffic is None else round(traffic)
             return out_k
 
@@ -726,15 +760,29 @@ def main():
                 b["cycles_per_line_visit"] = round(cyc, 2)
                 if hit is not None:
                     ns = k.get("node_share", 1.0)
-                    ceil = (ns * (hit * NODE_VISIT_CYCLES_L2 + (1.0 - hit) * NODE_VISIT_CYCLES_HBM) +
-                            (1.0 - ns) * (hit * SLOT_VISIT_CYCLES_L2 + (1.0 - hit) * SLOT_VISIT_CYCLES_HBM))
+                    ceil = {lanes: ns * visit_cycles(NODE_VISIT_CURVE[lanes], hit) + (1.0 - ns) * visit_cycles(SLOT_VISIT_CURVE[lanes], hit) for lanes in (100, 66)}
+                    linear = (ns * (hit * NODE_VISIT_CYCLES_L2 + (1.0 - hit) * NODE_VISIT_CYCLES_HBM) +
+                              (1.0 - ns) * (hit * SLOT_VISIT_CYCLES_L2 + (1.0 - hit) * SLOT_VISIT_CYCLES_HBM))
                     b["node_share_of_visits"] = round(ns, 3)
-                    b["ceiling_cycles"] = round(ceil, 2)
-                    b["frac_of_front_end_ceiling"] = round(ceil / cyc, 3)
-                    b["ceiling_note"] = (f"front end alone: {NODE_VISIT_CYCLES_L2} / {SLOT_VISIT_CYCLES_L2} CU-cycles per divergent node / leaf-slot "
-                                         f"visit that hits L2, {NODE_VISIT_CYCLES_HBM} / {SLOT_VISIT_CYCLES_HBM} from HBM (tools/node_bytes_microbench.hip, "
-                                         "profiles/r04_node_bytes_microbench.txt), blended by node share and l2_hit_rate; the kernels also "
-                                         "answer to the instructions they issue per step (profiles/r04_issue_bound_ab.txt)")
+                    b["ceiling_cycles"] = round(ceil[100], 2)
+                    b["frac_of_front_end_ceiling"] = round(ceil[100] / cyc, 3)
+                    b["ceiling_cycles_at_66pct_lanes"] = round(ceil[66], 2)
+                    b["frac_of_ceiling_at_66pct_lanes"] = round(ceil[66] / cyc, 3)
+                    b["ceiling_cycles_linear_blend_r05"] = round(linear, 2)
+                    b["frac_of_linear_blend_r05"] = round(linear / cyc, 3)
+                    lat = k.get("ea_read_latency_l2_clocks")
+                    if lat is not None:
+                        b["l2_miss_read_latency_l2_clocks"] = lat
+                        b["l2_misses_served_by"] = ("mostly the Infinity Cache (the microbenchmark's 8 ... 34 MB rows measure 630 ... 1 020)" if lat < 1030
+                                                    else "mostly HBM (the microbenchmark's rows beyond the Infinity Cache measure 1 050 ... 1 350)")
+                    b["ceiling_note"] = ("ceiling_cycles: what dependent chains of UNIFORMLY RANDOM node / leaf-slot visits cost the CU at this run's L2 hit rate with "
+                                         "every lane on (tools/miss_cost_microbench.hip, profiles/r06_miss_cost_microbench.txt: measured per working set from 1 MB to "
+                                         "1 GB, interpolated in the hit rate, blended by node share); _at_66pct_lanes: the same with 66 % of the lanes per step (the "
+                                         "kernels run 33 - 42 of 64). A fraction >= 1 says the kernel beats uniformly random chains at its hit rate -- its lanes' "
+                                         "misses are correlated (neighbouring rays miss together) -- i.e. it is AT the memory system's pace and only a higher hit rate "
+                                         "or fewer visits would speed it up. _linear_blend_r05: rounds 4-5's two-point blend (L2 price x hits + HBM price x misses), "
+                                         "kept for continuity; it has no Infinity-Cache regime. The kernels also answer to the instructions they issue per step "
+                                         "(profiles/r04_issue_bound_ab.txt)")
             return base
 
         out["roofline"] = contract(dom)

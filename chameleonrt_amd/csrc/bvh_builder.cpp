@@ -931,6 +931,47 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     return out;
 }
 
+// The level-by-level collapse of a binary tree (root = node 0) to 4-wide nodes in BFS order, as bvh_device.hip's k_collapse does it.
+// first_of: per internal node the first sorted position it covers (leaves of several items; nullptr with max_leaf = 1).
+static void collapse_binary_tree(const LbvhTree &tree, const int32_t *first_of, int max_leaf, uint32_t max_top_nodes, BuiltBvh &out)
+{
+    std::vector<int32_t> frontier{0}, next;
+    uint32_t level_base = 0, depth = 0;
+    while (!frontier.empty()) {
+        next.clear();
+        const uint32_t n_in = (uint32_t)frontier.size();
+        for (uint32_t i = 0; i < n_in; ++i) {
+            int32_t sub[BVH_WIDTH];
+            const int nc = lbvh_wide_children(tree, frontier[i], (uint32_t)max_leaf, sub);
+            BvhNode nd;
+            std::memset(&nd, 0, sizeof(nd));
+            for (int c = 0; c < BVH_WIDTH; ++c) {
+                nd.c[c] = EMPTY_CHILD;
+            }
+            for (int c = 0; c < nc; ++c) {
+                const uint32_t count = lbvh_count(tree, sub[c]);
+                if (count <= (uint32_t)max_leaf) {
+                    nd.c[c] = lbvh_leaf_ref(sub[c] >= 0 ? (uint32_t)first_of[sub[c]] : (uint32_t)~sub[c], count);
+                } else {
+                    nd.c[c] = (int32_t)(level_base + n_in + next.size());
+                    next.push_back(sub[c]);
+                }
+                const Aabb &b = lbvh_box(tree, sub[c]);
+                for (int a = 0; a < 3; ++a) {
+                    nd.lo[c][a] = b.lo[a];
+                    nd.hi[c][a] = b.hi[a];
+                }
+            }
+            out.nodes.push_back(nd);
+        }
+        level_base += n_in;
+        frontier.swap(next);
+        ++depth;
+    }
+    out.max_depth = depth;
+    out.n_top = std::min<uint32_t>((uint32_t)out.nodes.size(), max_top_nodes);
+}
+
 // ---- linear BVH on the host: the device builder's algorithm (lbvh.h), run serially ---------------------
 BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes)
 {
@@ -983,42 +1024,113 @@ BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max
     if (cost0 <= cost1) {
         build_binary(0);
     }
-    const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
-    std::vector<int32_t> frontier{0}, next;
-    uint32_t level_base = 0, depth = 0;
-    while (!frontier.empty()) {
-        next.clear();
-        const uint32_t n_in = (uint32_t)frontier.size();
-        for (uint32_t i = 0; i < n_in; ++i) {
-            int32_t sub[BVH_WIDTH];
-            const int nc = lbvh_wide_children(tree, frontier[i], (uint32_t)max_leaf, sub);
-            BvhNode nd;
-            std::memset(&nd, 0, sizeof(nd));
-            for (int c = 0; c < BVH_WIDTH; ++c) {
-                nd.c[c] = EMPTY_CHILD;
-            }
-            for (int c = 0; c < nc; ++c) {
-                const uint32_t count = lbvh_count(tree, sub[c]);
-                if (count <= (uint32_t)max_leaf) {
-                    nd.c[c] = lbvh_leaf_ref(sub[c] >= 0 ? (uint32_t)lo[sub[c]] : (uint32_t)~sub[c], count);
-                } else {
-                    nd.c[c] = (int32_t)(level_base + n_in + next.size());
-                    next.push_back(sub[c]);
-                }
-                const Aabb &b = lbvh_box(tree, sub[c]);
-                for (int a = 0; a < 3; ++a) {
-                    nd.lo[c][a] = b.lo[a];
-                    nd.hi[c][a] = b.hi[a];
-                }
-            }
-            out.nodes.push_back(nd);
-        }
-        level_base += n_in;
-        frontier.swap(next);
-        ++depth;
+    if (std::getenv("CRT_BVH_REPORT")) {
+        std::fprintf(stderr, "[crt_hip] Karras tree over %zu items: summed half-area of the binary tree %.6g (keys per axis) / %.6g (cubic keys)\n", n, cost0, cost1);
     }
-    out.max_depth = depth;
-    out.n_top = std::min<uint32_t>((uint32_t)out.nodes.size(), max_top_nodes);
+    const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
+    collapse_binary_tree(tree, lo.data(), max_leaf, max_top_nodes, out);
+    return out;
+}
+
+// ---- PLOC on the host: the device builder's other binary tree (lbvh.h "PLOC"), run serially -----------------------------------
+// Leaves of one item only (the default; a leaf of several slots needs a contiguous range of sorted positions, which clustering
+// by area does not give): with CRT_BVH_MAX_LEAF > 1 the Karras tree is built instead.
+uint32_t ploc_radius()
+{
+    if (const char *e = std::getenv("CRT_PLOC_RADIUS")) {
+        const long r = std::atol(e);
+        if (r >= 1 && r <= 1024) {
+            return (uint32_t)r;
+        }
+    }
+    return PLOC_DEFAULT_RADIUS;
+}
+
+BuiltBvh build_ploc_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes)
+{
+    const uint32_t radius = ploc_radius();
+    if (n < 3 || max_leaf != 1) {
+        return build_lbvh_host(boxes, n, max_leaf, max_top_nodes);
+    }
+    BuiltBvh out;
+    box_reset(out.bounds);
+    for (size_t i = 0; i < n; ++i) {
+        box_grow(out.bounds, boxes[i]);
+    }
+    std::vector<Aabb> pbox(n), ibox(n);
+    std::vector<int32_t> left(n), right(n), lo(n, 0), hi(n, 1); // (lo / hi: every internal node "holds two items", i.e. more than max_leaf = 1)
+    std::vector<uint32_t> best_order;
+    // clusters in Morton order of either key normalisation; returns the summed half-area of the internal nodes
+    auto build_binary = [&](int mode) -> double {
+        std::vector<std::pair<uint64_t, uint32_t>> ki(n);
+        for (size_t i = 0; i < n; ++i) {
+            ki[i] = {lbvh_key(boxes[i], out.bounds, mode), (uint32_t)i};
+        }
+        std::stable_sort(ki.begin(), ki.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        out.order.resize(n);
+        std::vector<int32_t> cid(n), cid2;
+        std::vector<Aabb> cbox(n), cbox2;
+        for (size_t i = 0; i < n; ++i) {
+            out.order[i] = ki[i].second;
+            pbox[i] = boxes[ki[i].second];
+            cid[i] = ~(int32_t)i;
+            cbox[i] = pbox[i];
+        }
+        std::vector<uint32_t> nn(n);
+        uint32_t m = (uint32_t)n;
+        int32_t next_id = (int32_t)n - 1; // ids are handed out downwards: the last merge makes node 0, the root
+        double cost = 0.0;
+        while (m > 1) {
+            for (uint32_t i = 0; i < m; ++i) {
+                nn[i] = ploc_nearest(cbox.data(), m, i, radius);
+            }
+            uint32_t merges = 0;
+            for (uint32_t i = 0; i < m; ++i) {
+                merges += nn[nn[i]] == i && i < nn[i];
+            }
+            if (merges == 0) { // (cannot happen with finite boxes -- the pair of smallest area chooses each other; NaN boxes compare false everywhere)
+                nn[0] = 1;
+                nn[1] = 0;
+                merges = 1;
+            }
+            cid2.clear();
+            cbox2.clear();
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t j = nn[i];
+                if (nn[j] == i) {
+                    if (i < j) {
+                        const int32_t id = next_id - 1 - (int32_t)k; // the k-th merge of this iteration, in array order
+                        ++k;
+                        left[id] = cid[i];
+                        right[id] = cid[j];
+                        ibox[id] = ploc_union(cbox[i], cbox[j]);
+                        cost += (double)lbvh_half_area(ibox[id]);
+                        cid2.push_back(id);
+                        cbox2.push_back(ibox[id]);
+                    }
+                } else {
+                    cid2.push_back(cid[i]);
+                    cbox2.push_back(cbox[i]);
+                }
+            }
+            next_id -= (int32_t)merges;
+            cid.swap(cid2);
+            cbox.swap(cbox2);
+            m = (uint32_t)cid.size();
+        }
+        return cost;
+    };
+    const double cost0 = build_binary(0), cost1 = build_binary(1);
+    if (cost0 <= cost1) {
+        build_binary(0);
+    }
+    if (std::getenv("CRT_BVH_REPORT")) {
+        std::fprintf(stderr, "[crt_hip] PLOC tree (radius %d) over %zu items: summed half-area of the binary tree %.6g (keys per axis) / %.6g (cubic keys)\n",
+                     (int)radius, n, cost0, cost1);
+    }
+    const LbvhTree tree{left.data(), right.data(), lo.data(), hi.data(), ibox.data(), pbox.data()};
+    collapse_binary_tree(tree, nullptr, max_leaf, max_top_nodes, out);
     return out;
 }
 

@@ -41,5 +41,8 @@ bool device_build_world(int device, const crt_scene_desc *scene, const std::vect
 // The same algorithm run serially on the host (shares lbvh.h with the kernels): what the CPU tests
 // check, and the reference the device result is compared against (CRT_BVH_BUILDER=lbvh).
 BuiltBvh build_lbvh_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes);
+// ... and of the device builder's PLOC tree (lbvh.h "PLOC"; CRT_BVH_BUILDER=ploc)
+BuiltBvh build_ploc_host(const Aabb *boxes, size_t n, int max_leaf, uint32_t max_top_nodes);
+uint32_t ploc_radius(); // the search radius both use: lbvh.h PLOC_DEFAULT_RADIUS, or CRT_PLOC_RADIUS from the environment
 
 } // namespace crt

@@ -460,11 +460,84 @@ struct ShadeStage {
 static_assert(sizeof(PathQueue) == 11 * sizeof(void *) && sizeof(ShadowQueueA) == 9 * sizeof(void *) && offsetof(ShadowQueueA, cp) == 7 * sizeof(void *),
               "PathQueue is an array of field pointers, ShadowQueueA starts with seven");
 
+// In-block regrouping of a step's items by material (round 6; CRT_SHADE_SORT=1, default 0 = items in queue order). k_shade runs at
+// ~32 of 64 lanes per vector instruction; perfect per-wave material uniformity was priced at -1.4 ms of 12.5 on C4 (round 5,
+// CRT_EXP_SHADE_ONE_MAT). Which lane evaluates which item of the block's 256 is free: per-pixel results do not depend on it and
+// the output compaction re-orders the queues anyway. So before phase 1 the block sorts its items by a 6-bit key of the hit's
+// material id (64: a miss; 65: beyond the queue) -- a STABLE counting sort (ranks by ballot inside a wave, a 4 x 66 histogram
+// across the waves), so the order, and with it the order of the output queues, is deterministic.
+#ifndef CRT_SHADE_SORT
+#define CRT_SHADE_SORT 0
+#endif
+constexpr int SHADE_SORT_KEYS = 66;
+struct ShadeSort {
+    uint32_t hist[SHADE_BLOCK / 64][SHADE_SORT_KEYS]; // items of wave w with key k, then: first sorted position of those items
+    uint16_t perm[SHADE_BLOCK];                       // sorted position -> item of the step
+};
+// every thread of the block must call this; returns the item (0 .. SHADE_BLOCK - 1) the calling thread evaluates
+CRT_DEV uint32_t shade_sort_items(ShadeSort &ss, uint32_t key)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    for (uint32_t k = threadIdx.x; k < (SHADE_BLOCK / 64) * SHADE_SORT_KEYS; k += SHADE_BLOCK) {
+        (&ss.hist[0][0])[k] = 0u;
+    }
+    __syncthreads();
+    // stable rank of the lane among the lanes of its wave with the same key, one round per distinct key of the wave
+    uint32_t rank = 0;
+    uint64_t todo = ~0ull;
+    while (todo != 0ull) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const uint64_t same = __ballot(key == k);
+        if (key == k) {
+            rank = lanes_below(same);
+        }
+        if ((int)lane == leader) {
+            ss.hist[wave][k] = (uint32_t)__popcll(same);
+        }
+        todo &= ~same;
+    }
+    __syncthreads();
+    // first sorted position of (key, wave): keys ascending, waves ascending inside a key. Wave 0 scans the 66 key totals.
+    if (wave == 0) {
+        uint32_t tot = 0, tot_hi = 0; // lane l: key l; lanes 0 and 1 also: keys 64 and 65
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w) {
+            tot += ss.hist[w][lane];
+            tot_hi += lane < 2u ? ss.hist[w][64 + lane] : 0u;
+        }
+        uint32_t incl = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            incl += lane >= (uint32_t)d ? up : 0u;
+        }
+        const uint32_t all64 = __shfl(incl, 63);
+        const uint32_t tot64 = __shfl(tot_hi, 0);
+        uint32_t at = incl - tot, at_hi = all64 + (lane == 1u ? tot64 : 0u);
+        for (int w = 0; w < SHADE_BLOCK / 64; ++w) {
+            const uint32_t c = ss.hist[w][lane];
+            ss.hist[w][lane] = at;
+            at += c;
+            if (lane < 2u) {
+                const uint32_t ch = ss.hist[w][64 + lane];
+                ss.hist[w][64 + lane] = at_hi;
+                at_hi += ch;
+            }
+        }
+    }
+    __syncthreads();
+    ss.perm[ss.hist[wave][key] + rank] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    return ss.perm[threadIdx.x];
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneView sc, PathQueue qin, HitBuf hits, PathQueue qout,
                                                        ShadowQueueA sa, ShadowQueueB sb, float4 *radiance,
                                                        PassCounters *pc, int bounce, int elide)
 {
     __shared__ ShadeStage stage;
+#if CRT_SHADE_SORT
+    __shared__ ShadeSort sort_ws;
+#endif
     // The grid is sized for the pass (the host does not know the queue's size): from the second bounce on a growing share of the
     // blocks has nothing to do -- half of them on C3's bounce 1, 99 % on any bounce 4 -- and leaves before it sets anything up.
     const uint32_t n = pc->n_queue[bounce].v;
@@ -478,7 +551,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
     uint32_t parity = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+#if CRT_SHADE_SORT
+        uint32_t i;
+        {
+            const uint32_t mine = base + threadIdx.x;
+            uint32_t key = 65u;
+            if (mine < n) {
+                const int32_t tri0 = __float_as_int(hits.rec[2 * (size_t)mine].w);
+                key = tri0 < 0 ? 64u : ((__float_as_uint(hits.rec[2 * (size_t)mine + 1].w) & ~MATERIAL_TEXTURED) & 63u);
+            }
+            i = base + shade_sort_items(sort_ws, key);
+        }
+#else
         const uint32_t i = base + threadIdx.x;
+#endif
         const bool valid = i < n;
         // Phase 1 (per lane): hit -> surface, next-event estimation (sample_direct_light, ispc:105-181).
         // Its outputs are staged immediately (phase 2) so their registers are free again before the
@@ -651,13 +737,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, CRT_SHADE_WAVES) void k_shade(SceneVie
             alive = !(pdf == 0.f || is_black(bsdf));
             if (alive) {
                 tp = tp * bsdf * fabsf(dot3(w_i, normal)) / pdf;
-                if (bounce + 1 > 3) { // Russian roulette, ispc:327-335
-                    const float qr = fmaxf(0.05f, 1.f - fmaxf(tp.x, fmaxf(tp.y, tp.z)));
-                    if (rng_nextf(rng) < qr) {
-                        alive = false;
-                    } else {
-                        tp = tp / (1.f - qr);
-                    }
+                if (bounce + 1 > 3 && russian_roulette(tp, rng)) { // ispc:327-335
+                    alive = false;
                 }
             }
         }
@@ -950,6 +1031,17 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
         o[16] = has_b ? 2.f : 1.f;
         break;
     }
+    case CRT_KAT_ROULETTE: {
+        V3 tp = ld3(a);
+        uint32_t rng = __float_as_uint(a[3]);
+        float q = 0.f;
+        const bool ended = russian_roulette(tp, rng, &q);
+        o[0] = ended ? 1.f : 0.f;
+        st3(o + 1, tp);
+        o[4] = __uint_as_float(rng);
+        o[5] = q;
+        break;
+    }
     case CRT_KAT_LIGHT: {
         const QuadLight l = load_light(a);
         const V3 orig = ld3(a + 20), dir = ld3(a + 23);
@@ -1146,7 +1238,7 @@ void launch_trace_diag(const LaunchCfg &cfg, const SceneView &sc, uint32_t n, co
 int launch_kat(const LaunchCfg &cfg, const SceneView &sc, int fn, uint32_t n, const float *in, int in_stride,
                float *out, int out_stride)
 {
-    if (fn < CRT_KAT_DISNEY_EVAL || fn > CRT_KAT_NEE) {
+    if (fn < CRT_KAT_DISNEY_EVAL || fn > CRT_KAT_ROULETTE) {
         return -1;
     }
     k_kat<<<(n + 63) / 64, 64, 0, cfg.stream>>>(sc, fn, n, in, in_stride, out, out_stride);

@@ -127,6 +127,49 @@ CRT_HD float lbvh_half_area(const Aabb &b)
     return dx * dy + dy * dz + dz * dx;
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume
+// Hierarchy Construction", IEEE TVCG 2018) -- the other way to turn the Morton-sorted items into a binary tree (round 6). The
+// Karras tree splits where the Morton codes say; PLOC builds BOTTOM-UP by surface area: the clusters -- at first the items in
+// Morton order -- each look for the neighbour, among the `radius` clusters on either side of them in the array, whose union with
+// them has the smallest surface area; two clusters that choose EACH OTHER merge into a node that takes the place of the first,
+// the array is compacted, and so on until one cluster is left. Everything an iteration decides is a function of the cluster
+// array alone, so the serial host twin (bvh_builder.cpp build_ploc_host) and the kernels (bvh_device.hip) build the SAME tree.
+constexpr uint32_t PLOC_DEFAULT_RADIUS = 16; // (CRT_PLOC_RADIUS in the environment overrides it: bvh_builder.cpp ploc_radius())
+CRT_HD float ploc_union_half_area(const Aabb &a, const Aabb &b)
+{
+    const float lx = a.lo[0] < b.lo[0] ? a.lo[0] : b.lo[0], ly = a.lo[1] < b.lo[1] ? a.lo[1] : b.lo[1], lz = a.lo[2] < b.lo[2] ? a.lo[2] : b.lo[2];
+    const float hx = a.hi[0] > b.hi[0] ? a.hi[0] : b.hi[0], hy = a.hi[1] > b.hi[1] ? a.hi[1] : b.hi[1], hz = a.hi[2] > b.hi[2] ? a.hi[2] : b.hi[2];
+    const float dx = hx - lx, dy = hy - ly, dz = hz - lz;
+    return dx * dy + dy * dz + dz * dx;
+}
+CRT_HD Aabb ploc_union(const Aabb &a, const Aabb &b)
+{
+    Aabb u;
+    for (int k = 0; k < 3; ++k) {
+        u.lo[k] = a.lo[k] < b.lo[k] ? a.lo[k] : b.lo[k];
+        u.hi[k] = a.hi[k] > b.hi[k] ? a.hi[k] : b.hi[k];
+    }
+    return u;
+}
+// the neighbour cluster i chooses among [i - radius, i + radius] of m clusters: smallest union area, the lower index on a tie
+CRT_HD uint32_t ploc_nearest(const Aabb *cbox, uint32_t m, uint32_t i, uint32_t radius)
+{
+    const uint32_t lo = i > radius ? i - radius : 0u, hi = i + radius < m - 1u ? i + radius : m - 1u;
+    const Aabb me = cbox[i];
+    uint32_t best = i;
+    float best_area = 3.4e38f;
+    for (uint32_t j = lo; j <= hi; ++j) {
+        if (j != i) {
+            const float a = ploc_union_half_area(me, cbox[j]);
+            if (a < best_area) {
+                best_area = a;
+                best = j;
+            }
+        }
+    }
+    return best;
+}
+
 // The binary tree as the collapse sees it.
 struct LbvhTree {
     const int32_t *left, *right; // per internal node

@@ -762,4 +762,23 @@ CRT_DEV V3 miss_color(V3 dir)
     return v3(0.1f);
 }
 
+// Russian roulette of the path loop, render_embree.ispc:327-335 (applied by the caller once bounce > 3): returns true if the path
+// ends; otherwise the throughput is divided by the survival probability. `max` is the reference's own two-operand select --
+// sycl::max(x, y) = x < y ? y : x in the kernel the oracle is pinned to (embree_sycl/render_embree_kernel.inl:284-287), std::max in
+// the oracle -- and NOT fmaxf: with a NaN in throughput.x and finite y, z the select keeps the NaN (q = 0.05), fmaxf would drop it
+// (q = 1 - max(y, z)). Non-finite throughputs do occur (glass at grazing angles: inf * 0); CRT_KAT_ROULETTE holds this to the bit.
+CRT_DEV float ref_max(float a, float b) { return a < b ? b : a; }
+CRT_DEV bool russian_roulette(V3 &tp, uint32_t &rng, float *q_out = nullptr)
+{
+    const float q = ref_max(0.05f, 1.f - ref_max(tp.x, ref_max(tp.y, tp.z)));
+    if (q_out) {
+        *q_out = q;
+    }
+    if (rng_nextf(rng) < q) {
+        return true;
+    }
+    tp = tp / (1.f - q);
+    return false;
+}
+
 } // namespace crt

@@ -264,7 +264,7 @@ struct ScenePreparer {
     const int n_threads;
     const int build_device; // >= 0: meshes large enough to be worth it get their BLAS from the device builder on that HIP device
     const int max_leaf = max_leaf_setting();
-    bool host_lbvh = false;  // CRT_BVH_BUILDER=lbvh: the device builder's algorithm, run serially on the host
+    int host_lbvh = 0;       // CRT_BVH_BUILDER=lbvh / ploc: one of the device builder's algorithms (1 Karras tree, 2 PLOC), run serially on the host
     bool world_tree = false; // several instances, one tree in world space (crt_types.h LEVELS_WORLD_TREE)
     bool two_level = false;  // several instances, a top-level tree over them
     bool empty_scene = false; // no instance has a triangle: one node without children, every ray misses (like the reference's empty Embree scene)
@@ -361,7 +361,7 @@ struct ScenePreparer {
         built.resize(s->n_meshes);
         built_q.resize(s->n_meshes);
         const char *builder_env = std::getenv("CRT_BVH_BUILDER");
-        host_lbvh = builder_env && std::strcmp(builder_env, "lbvh") == 0;
+        host_lbvh = builder_env && std::strcmp(builder_env, "lbvh") == 0 ? 1 : builder_env && std::strcmp(builder_env, "ploc") == 0 ? 2 : 0;
         // The static part of an instanced scene -- an identity instance whose mesh nothing else uses: the building
         // of a San-Miguel-like scene with its instanced plants -- is not entered like an instance. Its BLAS is
         // opened from the root down to a CUT of subtrees about as large as the other instances, the top-level tree is
@@ -549,7 +549,8 @@ struct ScenePreparer {
                 report_presplit(presplit_items(recs, boxes, [](const LeafSlot &, const float *&mm, float &pad) { mm = nullptr; pad = 0.f; },
                                                presplit_fraction()));
             }
-            built[m] = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
+            built[m] = host_lbvh == 2 ? build_ploc_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
+                       : host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
                                              two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
             blas_depth = std::max(blas_depth, built[m].max_depth);
@@ -821,7 +822,8 @@ struct ScenePreparer {
                     pad = pads[r.tag >> 1];
                 }, presplit_fraction()));
             }
-            BuiltBvh tree = host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
+            BuiltBvh tree = host_lbvh == 2 ? build_ploc_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
+                            : host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
                                       : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
             boxes = std::vector<Aabb>();
             blas_depth = tree.max_depth;

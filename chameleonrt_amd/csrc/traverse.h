@@ -603,6 +603,13 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                     ++n_nodes;
                     ++ray_nodes;
                 }
+#if defined(CRT_EXP_NODE_EXTRA_REQUEST) // timing experiment (same image): a FOURTH 16-byte request per node visit -- the record's unused quarter, all zero -- to price
+                                        // one request more on the production kernels, hence one request less (profiles/r06_node32_pricing.txt)
+                if (!(cur >= top_lo && cur < top_hi)) {
+                    const tv_u4 k3 = ((const TV_HBM tv_u4 *)(sc.nodes + cur))[3];
+                    k2.x |= k3.x;
+                }
+#endif
 #if defined(CRT_EXP_INNER_PAD) // timing experiment: N extra VALU instructions per inner step (is the step issue-bound?)
 #pragma unroll
                 for (int pad_i = 0; pad_i < CRT_EXP_INNER_PAD; ++pad_i) {

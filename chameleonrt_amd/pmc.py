@@ -28,6 +28,9 @@ PASSES = {
            "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
     # the per-CU vector-memory front end (texture addresser): busy cycles summed over the 256 CUs, and the L2's hit rate
     "mem": ["TA_TA_BUSY_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"],
+    # how far away an L2 miss is served from: LEVEL / RDREQ = the average latency of the L2's memory-side reads in L2 clocks (short:
+    # the Infinity Cache; long: HBM). bench.py prices the misses of a traversal kernel with it (tools/miss_cost_microbench.hip)
+    "ea": ["TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_sum", "GRBM_GUI_ACTIVE"],
 }
 
 
@@ -58,7 +61,7 @@ def read_db(path):
     return out
 
 
-def measure(prepared_path, meta_path, frames=3, passes=("fetch", "write", "sq", "mem"), timeout=240, keep_dir=None):
+def measure(prepared_path, meta_path, frames=3, passes=("fetch", "write", "sq", "mem", "ea"), timeout=240, keep_dir=None):
     """Returns {pass: {kernel: {...}}}; a pass that fails or times out is reported as {"error": ...}."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     res = {}

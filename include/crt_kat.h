@@ -50,7 +50,13 @@ enum {
      * out (17): c_a[3] (contribution of the light-sample ray, 0 if a pdf < EPSILON), light_dir[3], light_dist,
      *           has_b(0/1), c_b[3], w_i_b[3], light_dist_b (zeros without a second ray), rng_state_after(bits),
      *           occlusion rays counted (1 or 2) */
-    CRT_KAT_NEE = 10
+    CRT_KAT_NEE = 10,
+    /* render_embree.ispc:327-335 Russian roulette, as the path loop applies it once bounce > 3: q = max(0.05, 1 - max(tp.x,
+     * max(tp.y, tp.z))), one lcg_randomf draw, termination if it is < q, else tp /= 1 - q. max(a, b) is the reference's
+     * `a < b ? b : a` (sycl::max as embree_sycl/render_embree_kernel.inl:284-287 uses it; NOT fmax: a NaN first operand stays)
+     * in   (4): tp[3] rng_state(bits)
+     * out  (6): terminated(0/1), tp_after[3] (tp itself if terminated), rng_state_after(bits), q */
+    CRT_KAT_ROULETTE = 11
 };
 
 #define CRT_KAT_MAX_IN 32

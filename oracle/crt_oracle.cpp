@@ -298,7 +298,20 @@ inline float power_heuristic(float n_f, float pdf_f, float n_g, float pdf_g)
     return (f * f) / (f * f + g * g);
 }
 // disney_bsdf.ih:74-76
-inline float schlick_weight(float cos_theta) { return std::pow(saturate(1.f - cos_theta), 5.f); }
+// g_schlick_by_multiplication (orc_set_schlick_by_multiplication, default off): a TEST switch that makes the oracle form the fifth
+// power the way the product does, (x^2)^2 * x, instead of the reference's pow(x, 5). With it the Disney evaluation KAT must be
+// BIT-EXACT wherever no other transcendental reaches the result (tests/test_gpu_kat.py) -- which shows that the 2e-5 bar of that KAT
+// is this one documented deviation plus libm's log in the clear-coat lobe, not a tolerance hiding something else. Every parity
+// statement (and the pin to the reference's kernel, tests/test_oracle_pinned.py) is about the default, the reference's pow.
+static bool g_schlick_by_multiplication = false;
+inline float schlick_weight(float cos_theta)
+{
+    if (g_schlick_by_multiplication) {
+        const float x = saturate(1.f - cos_theta), x2 = x * x;
+        return x2 * x2 * x;
+    }
+    return std::pow(saturate(1.f - cos_theta), 5.f);
+}
 // disney_bsdf.ih:82-89
 inline float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t)
 {
@@ -1916,6 +1929,8 @@ inline bool fbox(const FNode &nd, uint32_t c, const FAxis ax[3], float tmin, flo
 }
 } // namespace
 
+extern "C" void orc_set_schlick_by_multiplication(int on) { g_schlick_by_multiplication = on != 0; }
+
 extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const void *instances_,
                                     uint64_t n_instances, int32_t world_inst, int32_t root, const float root_frame[6], int child_order,
                                     uint64_t n, const float *org, const float *dir, const float *tmin,
@@ -1930,7 +1945,12 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     // space whose triangle records carry (instance << 1) | identity in their last word; < 0: 0 or 1 by instance count
     const bool world_tree = levels == 2 && insts != nullptr;
     const bool two_level = !world_tree && (levels < 0 ? insts != nullptr && n_instances > 1 : levels == 1);
-    const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    // diagnostic (tools/node_replay_microbench.hip): ORC_WALK_TRACE=<file> records every ray's visit sequence -- node index, or
+    // 0x80000000 | leaf-slot index -- so that a microbenchmark can replay the REAL access pattern of a workload with other record
+    // sizes. File: u32 n_rays, u32 n_visits, u32 offsets[n_rays + 1], u32 visits[n_visits]. One thread (rays stay in order).
+    const char *trace_env = std::getenv("ORC_WALK_TRACE");
+    std::vector<uint32_t> trace_visits, trace_offsets;
+    const int nthreads = trace_env ? 1 : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<uint64_t> nv_t(nthreads, 0), tt_t(nthreads, 0), ne_t(nthreads, 0), nb_t(nthreads, 0), ls_t(nthreads, 0);
     std::vector<uint32_t> ms_t(nthreads, 0);
     std::vector<int> bad_t(nthreads, 0);
@@ -1946,6 +1966,9 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
             const f3 worg = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
             const f3 wdir = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+            if (trace_env) {
+                trace_offsets.push_back((uint32_t)trace_visits.size());
+            }
             f3 o = worg, d = wdir, qa, qb;
             // the product clamps |d| to >= 1e-18 for the box tests (exactly zero components)
             auto box_dir = [](float x) { return std::fabs(x) < 1e-18f ? std::copysign(1e-18f, x) : x; };
@@ -1973,6 +1996,9 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                 if (cur >= 0) {
                     const FNode &nd = nodes[cur];
                     ++nv;
+                    if (trace_env) {
+                        trace_visits.push_back((uint32_t)cur);
+                    }
                     if (two_level && in_blas) {
                         ++nb;
                     }
@@ -2048,6 +2074,9 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                     for (uint32_t k = first; k < first + count && !done; ++k) {
                         const FSlot &sl = slots[k];
                         ++ls;
+                        if (trace_env) {
+                            trace_visits.push_back(0x80000000u | k);
+                        }
                         const uint32_t geom = sl.geom_sel & 0x03ffffffu, sel = sl.geom_sel >> 26;
                         f3 ro = o, rd = d;
                         if (world_tree) { // the slot's own instance; tested in its object space (traverse.h INST_TRIS)
@@ -2162,6 +2191,16 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         std::fprintf(stderr, "[orc walk] %.3f pops per ray, %.3f of them above entry %zu; deepest %u\n", (double)b / (double)std::max<uint64_t>(n, 1),
                      (double)a / (double)std::max<uint64_t>(n, 1), spill_depth, ms);
     }
+    if (trace_env) {
+        trace_offsets.push_back((uint32_t)trace_visits.size());
+        if (FILE *tf = std::fopen(trace_env, "wb")) {
+            const uint32_t head[2] = {(uint32_t)n, (uint32_t)trace_visits.size()};
+            std::fwrite(head, 4, 2, tf);
+            std::fwrite(trace_offsets.data(), 4, trace_offsets.size(), tf);
+            std::fwrite(trace_visits.data(), 4, trace_visits.size(), tf);
+            std::fclose(tf);
+        }
+    }
     *nodes_visited = nv;
     *tris_tested = tt;
     if (max_stack) {
@@ -2264,6 +2303,23 @@ extern "C" int orc_kat(const orc_scene *s, int fn, uint64_t n, const float *in, 
             o[14] = rec.light_dist_b;
             o[15] = fbits(rng.state);
             o[16] = (float)n_rays;
+            break;
+        }
+        case CRT_KAT_ROULETTE: {
+            // render_embree.ispc:327-335 (= embree_sycl/render_embree_kernel.inl:283-292), the statements of the path loop above
+            f3 path_throughput = ld3(a);
+            Lcg rng{bits(a[3])};
+            const float q =
+                std::max(0.05f, 1.f - std::max(path_throughput.x,
+                                               std::max(path_throughput.y, path_throughput.z)));
+            const bool ended = lcg_randomf(rng) < q;
+            if (!ended) {
+                path_throughput = path_throughput / (1.f - q);
+            }
+            o[0] = ended ? 1.f : 0.f;
+            st3(o + 1, path_throughput);
+            o[4] = fbits(rng.state);
+            o[5] = q;
             break;
         }
         case CRT_KAT_LIGHT: {

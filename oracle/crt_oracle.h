@@ -107,6 +107,11 @@ int orc_walk_foreign_bvh(const void *nodes, const void *tris, const void *instan
 int orc_kat(const orc_scene *s, int fn, uint64_t n, const float *in, int in_stride, float *out,
             int out_stride);
 
+/* TEST switch (default 0 = the reference's pow(x, 5), disney_bsdf.ih:74-76): form schlick_weight's fifth power by three
+ * multiplications, as the product does, so that a test can show the Disney KAT's tolerance is that one documented deviation
+ * (tests/test_gpu_kat.py::test_disney_eval_is_bit_exact_once_the_oracle_forms_schlick_like_the_product). Process-wide. */
+void orc_set_schlick_by_multiplication(int on);
+
 #ifdef __cplusplus
 }
 #endif

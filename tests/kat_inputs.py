@@ -4,7 +4,7 @@ import numpy as np
 from chameleonrt_amd.scene import ortho_basis, obj_default_light
 
 KAT_DISNEY_EVAL, KAT_DISNEY_SAMPLE, KAT_LIGHT, KAT_TEXTURE, KAT_MISS = 1, 2, 3, 4, 5
-KAT_ORTHO_BASIS, KAT_SRGB8, KAT_RNG, KAT_UNPACK_MATERIAL, KAT_NEE = 6, 7, 8, 9, 10
+KAT_ORTHO_BASIS, KAT_SRGB8, KAT_RNG, KAT_UNPACK_MATERIAL, KAT_NEE, KAT_ROULETTE = 6, 7, 8, 9, 10, 11
 N_OUT = {1: 4, 2: 8, 3: 9, 4: 5, 5: 3, 6: 6, 7: 1, 8: 17, 9: 14, 10: 17}
 
 
@@ -132,3 +132,32 @@ def unpack_records(n, n_mat, seed=17):
     mid = rng.integers(0, n_mat, size=(n, 1)).astype(np.uint32).view(np.float32)
     uv = (rng.random((n, 2)) * 5 - 2).astype(np.float32)
     return np.concatenate([mid, uv], axis=1).astype(np.float32)
+
+
+def roulette_records(n, seed=23):
+    """Throughputs for render_embree.ispc:327-335 over every regime of q = max(0.05, 1 - max(tp)): dim paths (q near 1), bright ones
+    (max(tp) >= 1 -> q = 0.05 exactly), throughputs around the 0.95 switch-over, zeros, negatives, and the non-finite values glass
+    produces (inf, NaN in any subset of the channels -- the reference's max is a select, `a < b ? b : a`, which treats a NaN
+    differently by operand position), each with a random RNG state."""
+    rng = np.random.default_rng(seed)
+    tp = np.empty((n, 3), np.float32)
+    kind = rng.integers(0, 8, n)
+    tp[:] = rng.random((n, 3)).astype(np.float32)                                   # 0: ordinary
+    m = kind == 1; tp[m] *= np.float32(1e-3)                                        # dim
+    m = kind == 2; tp[m] = (rng.random((m.sum(), 3)) * 4).astype(np.float32)        # bright: often >= 1
+    m = kind == 3; tp[m] = (0.95 + (rng.random((m.sum(), 3)) - 0.5) * 1e-6).astype(np.float32)  # at the q = 0.05 switch-over
+    m = kind == 4; tp[m] = 0.0
+    m = kind == 5; tp[m] = -tp[m]
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, 1.0, 0.5], np.float32)
+    m = kind >= 6                                                                   # non-finite values in random channels
+    pick = rng.integers(0, len(special), (m.sum(), 3))
+    keep = rng.random((m.sum(), 3)) < 0.4
+    tp[m] = np.where(keep, tp[m], special[pick])
+    rec = np.zeros((n, 4), np.float32)
+    rec[:, :3] = tp
+    rec[:, 3] = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    # the position-dependent NaN cases, explicitly: NaN first with finite others, and the other way round
+    fixed = np.array([[np.nan, 0.5, 0.2], [0.5, np.nan, 0.2], [0.5, 0.2, np.nan], [np.nan, np.nan, 0.3], [np.inf, 0.1, 0.1],
+                      [0.1, -np.inf, 0.1], [1.0, 1.0, 1.0], [0.95, 0.0, 0.0], [0.0, 0.0, 0.0]], np.float32)
+    rec[:len(fixed), :3] = fixed
+    return rec

@@ -50,6 +50,8 @@ def lib():
                                            C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint32), fp, i32p, i32p, i32p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         L.orc_kat.argtypes = [vp, C.c_int, C.c_uint64, fp, C.c_int, fp, C.c_int]
+        L.orc_set_schlick_by_multiplication.argtypes = [C.c_int]
+        L.orc_set_schlick_by_multiplication.restype = None
         _LIB = L
     return _LIB
 

@@ -27,7 +27,7 @@ CASES = {
     "C3": ("C3", None, 32, 0, 1),
     "C4": ("C4", None, 32, 2, 1),            # the library's choice for the instanced scene: a world tree
     "C4_two_level": ("C4", "two", 32, 1, 1),
-    "C5": ("C5", None, 8, 2, 16),            # 3840x2160 x 64 spp = 531 M paths = 16 passes of the default 32 Mi capacity
+    "C5": ("C5", None, 24, 2, 16),           # 3840x2160 x 64 spp = 531 M paths = 16 passes of the default 32 Mi capacity
 }
 _scene_cache = {}
 

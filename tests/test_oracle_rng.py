@@ -80,3 +80,26 @@ def test_randomf_can_reach_one(oracle):
     """Quirk Q2: states >= 0xFFFFFF80 convert to exactly 1.0f."""
     assert np.float32(np.uint32(0xFFFFFF80)) * np.float32(2.0 ** -32) == np.float32(1.0)
     assert np.float32(np.uint32(0xFFFFFF7F)) * np.float32(2.0 ** -32) < np.float32(1.0)
+
+
+def test_russian_roulette_against_an_independent_float32_derivation(oracle):
+    """render_embree.ispc:327-335 as the oracle states it (CRT_KAT_ROULETTE), against numpy float32 arithmetic with the reference's
+    select-max `a < b ? b : a` (embree_sycl/render_embree_kernel.inl:284-287: sycl::max) and the LCG above: q, the decision, the
+    divided throughput and the RNG state after one draw -- every bit, NaN and inf throughputs included."""
+    rec = K.roulette_records(4000)
+    out = oracle.kat(K.KAT_ROULETTE, rec, 6)
+    tp = rec[:, :3].astype(np.float32)
+    sel = lambda a, b: np.where(a < b, b, a).astype(np.float32)  # noqa: E731
+    with np.errstate(all="ignore"):
+        q = sel(np.full(len(rec), 0.05, np.float32), np.float32(1.0) - sel(tp[:, 0], sel(tp[:, 1], tp[:, 2])))
+        state = (rec[:, 3].view(np.uint32).astype(np.uint64) * 1664525 + 1013904223) & M32
+        draw = (state.astype(np.uint32).astype(np.float32).astype(np.float64) * 2.0 ** -32).astype(np.float32)
+        ended = draw < q
+        after = np.where(ended[:, None], tp, tp / (np.float32(1.0) - q)[:, None]).astype(np.float32)
+    assert np.array_equal(out[:, 0], ended.astype(np.float32))
+    assert np.array_equal(out[:, 4].view(np.uint32), state.astype(np.uint32))
+    assert np.array_equal(out[:, 5].view(np.uint32), q.view(np.uint32))
+    # (a NaN's payload / sign after a division is the platform's; which values are NaN and every other bit must agree)
+    got, want = out[:, 1:4], after
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)])

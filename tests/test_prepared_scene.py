@@ -378,14 +378,16 @@ def test_malformed_scenes_are_refused_not_crashed():
         refused(m)
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["grove_two_level", "sponza_small", "rungholt_small"])
-def test_linear_bvh_build_on_the_host(name, oracle, monkeypatch):
+def test_linear_bvh_build_on_the_host(name, builder, oracle, monkeypatch):
     """The device builder's algorithm (lbvh.h: Morton keys with two normalisations, Karras' radix tree,
     bottom-up boxes, area-greedy collapse to 4-wide nodes) run serially on the host: a correct tree
-    (walk == brute force) of bounded extra cost against the SAH tree."""
+    (walk == brute force) of bounded extra cost against the SAH tree. `ploc`: the same pipeline with the binary tree built
+    bottom-up by locally-ordered clustering instead (Meister & Bittner 2018; round 6, priced and not adopted: DESIGN.md section 7)."""
     sc = SCENES[name]()
     sah = PreparedScene(sc).bvh()
-    monkeypatch.setenv("CRT_BVH_BUILDER", "lbvh")
+    monkeypatch.setenv("CRT_BVH_BUILDER", builder)
     lin = PreparedScene(sc).bvh()
     assert lin["tris"].shape == sah["tris"].shape
     org, dirs = probe_rays(sc, 6000, seed=23)

@@ -6,7 +6,7 @@
 # Everything a step writes goes to gpurun_out/TAG/ (merged back into the working tree by gpurun); the summaries worth
 # keeping are copied into profiles/ by hand. Steps:
 #   tests[:EXPR[:ENV=V,...]]  pytest -m gpu (optionally -k EXPR, with environment settings) -> pytest_<n>.log
-#   bench:W[:ARGS]      python bench.py --workload W ARGS (',' separates ARGS)   -> bench_W.json / .err
+#   bench:W[:ARGS[:ENV=V,...]]  python bench.py --workload W ARGS (',' separates ARGS)   -> bench_W.json / .err
 #   ab:W:V1,V2[:N]      frames of workload W with library variants (tools/variants.py; `prod` = the product) -> ab_W.log
 #   phase:W             wave-phase profile of the instrumented kernels (CRT_HIP_DEBUG) -> phase_W.log
 #   trace[:W]           rocprofv3 --kernel-trace --stats of the bench command    -> kernel_stats_W.md
@@ -28,7 +28,7 @@ for step in "$@"; do
       grep -E "passed|failed|error|diverged|deepest" "$OUT/pytest_$n.log" | tail -12 ;;
     bench)
       ARGS=${b//,/ }
-      ( time timeout -k 5 900 python bench.py --workload "$a" $ARGS ) > "$OUT/bench_$a.json" 2> "$OUT/bench_$a.err"
+      ( [ -n "$c" ] && export ${c//,/ }; time timeout -k 5 900 python bench.py --workload "$a" $ARGS ) > "$OUT/bench_$a.json" 2> "$OUT/bench_$a.err"
       tail -3 "$OUT/bench_$a.err" | head -1
       python - "$OUT/bench_$a.json" <<'PY'
 import json, sys
