@@ -91,7 +91,14 @@ RenderHIP::RenderHIP()
     // CRT_HIP_ELIDE=1: do not trace the occlusion rays whose answer the reference never looks at (same image, same ray
     // statistics; include/crt_hip.h CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS). Off by default: the backend then traces what Embree traces.
     const char *elide = std::getenv("CRT_HIP_ELIDE");
-    const uint32_t flags = (elide != nullptr && elide[0] == '1') ? (uint32_t)CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS : (uint32_t)CRT_HIP_FLAG_NONE;
+    uint32_t flags = (elide != nullptr && elide[0] == '1') ? (uint32_t)CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS : (uint32_t)CRT_HIP_FLAG_NONE;
+    // One GPU (`./chameleonrt hip <scene>`): set_scene returns with a quickly built tree and the full-quality one is swapped in a few
+    // seconds later, between two frames of the accumulation -- same images (they do not depend on the tree), no multi-second wait
+    // in set_scene (include/crt_hip.h CRT_HIP_FLAG_REFINE_IN_BACKGROUND; CRT_HIP_REFINE=0 waits for the full tree like rtcCommitScene).
+    const char *refine_env = std::getenv("CRT_HIP_REFINE");
+    if (n == 1 && !(refine_env != nullptr && refine_env[0] == '0')) {
+        flags |= (uint32_t)CRT_HIP_FLAG_REFINE_IN_BACKGROUND;
+    }
     for (int d = 0; d < n; ++d) {
         crt_hip_ctx *c = crt_hip_create(d, flags);
         if (!c) {
@@ -219,6 +226,10 @@ void RenderHIP::set_scene(const Scene &scene)
     // Every GPU keeps a full scene replica (a San-Miguel-class scene is ~2 GB of 288 GB). The host
     // half of set_scene (BVH build = rtcCommitScene's job, texture linearisation) runs ONCE with all
     // host cores; only the uploads are per device.
+    if (ctxs.size() == 1) { // one GPU: prepare + upload in one call (which may refine the tree in the background, see the constructor)
+        check(ctxs[0], crt_hip_set_scene(ctxs[0], &desc), "crt_hip_set_scene");
+        return;
+    }
     crt_hip_prepared_scene *prepared = crt_hip_prepare_scene(&desc, 0);
     if (!prepared) {
         throw std::runtime_error(std::string("RenderHIP: crt_hip_prepare_scene: ") + crt_hip_last_error(nullptr));

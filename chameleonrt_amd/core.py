@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("CRT_HIP_LIB") or os.path.join(
 
 FLAG_COUNTERS = 1
 FLAG_TIMING = 2
+FLAG_REFINE_IN_BACKGROUND = 8  # opt-in: set_scene returns with a quickly built tree, the full-quality one is swapped in later (include/crt_hip.h)
 FLAG_ELIDE_UNUSED_SHADOW_RAYS = 4  # opt-in: occlusion rays whose result cannot reach the image are counted, not traced (include/crt_hip.h)
 TRACE_PRODUCTION = 2  # crt_hip_trace_rays: run the kernels a frame launches (include/crt_hip.h)
 
@@ -35,7 +36,7 @@ EXPORTS = [
     "crt_hip_prepare_scene_on", "crt_hip_free_prepared_scene", "crt_hip_set_prepared_scene", "crt_hip_save_prepared_scene",
     "crt_hip_load_prepared_scene", "crt_hip_prepared_scene_info", "crt_hip_prepared_scene_copy",
     "crt_hip_child_order", "crt_hip_lds_stack_entries", "crt_hip_prepared_scene_set_spp", "crt_hip_debug_copy_queue",
-    "crt_hip_render_begin", "crt_hip_render_end",
+    "crt_hip_render_begin", "crt_hip_render_end", "crt_hip_refine_state",
 ]
 
 
@@ -137,6 +138,8 @@ def load():
     L.crt_hip_prepared_scene_info.argtypes = [vp, u64p, u64p, u64p, i32p, fp, i32p, u32p, u32p, C.POINTER(C.c_double)]
     L.crt_hip_prepared_scene_copy.argtypes = [vp, vp, vp, vp]
     L.crt_hip_child_order.restype = C.c_int
+    L.crt_hip_refine_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.crt_hip_refine_state.restype = C.c_int
     L.crt_hip_prepared_scene_set_spp.argtypes = [vp, C.c_uint32]
     L.crt_hip_prepared_scene_set_spp.restype = C.c_int
     L.crt_hip_lds_stack_entries.restype = C.c_uint32

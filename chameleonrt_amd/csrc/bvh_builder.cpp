@@ -670,7 +670,7 @@ inline int32_t leaf_ref(uint32_t first, uint32_t count) { return (int32_t)~((fir
 } // namespace
 
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
-                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads)
+                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads, int reinsert_passes)
 {
     if (n == 0) {
         throw std::runtime_error("build_bvh: no items");
@@ -718,7 +718,7 @@ BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base,
     {
         // two passes by default (round 5; C4 -8 % line visits per ray, 54.6 -> 53.0 ms); CRT_BVH_REINSERT=0 switches it off
         const char *e = std::getenv("CRT_BVH_REINSERT");
-        const int passes = e != nullptr ? std::atoi(e) : 2;
+        const int passes = reinsert_passes >= 0 ? reinsert_passes : e != nullptr ? std::atoi(e) : 2;
         const int32_t n_nodes = b.next.load();
         if (passes > 0 && n_nodes > 7) {
             root = optimise_by_reinsertion(b, root, n_nodes, passes, dbg && n > 100000);

@@ -29,8 +29,11 @@ struct BuiltBvh {
 // node_base / item_base are added to the inner-node indices / leaf `first` values so several
 // BVHs can be concatenated into one array. If leaf_holds_item_id is set (TLAS), max_leaf must
 // be 1 and a leaf's `first` is the item id itself instead of its position in `order`.
+// reinsert_passes: passes of insertion-based re-optimisation after the top-down build (Bittner et al. 2013); < 0 = CRT_BVH_REINSERT
+// from the environment, default 2 (0 is what the quick tree of a background-refined scene asks for, crt_hip.h
+// CRT_HIP_FLAG_REFINE_IN_BACKGROUND).
 BuiltBvh build_bvh(const Aabb *boxes, size_t n, int max_leaf, int32_t node_base, uint32_t item_base,
-                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads);
+                   bool leaf_holds_item_id, uint32_t max_top_nodes, int n_threads, int reinsert_passes = -1);
 
 // Fixed-point frame of a BVH with bounds b, and the outward-rounded 64-byte form of a node in it
 // (crt_types.h QFrame / QNode): what the traversal kernels actually read.

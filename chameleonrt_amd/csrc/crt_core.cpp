@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <queue>
@@ -101,6 +102,66 @@ inline Vec3 normalize(Vec3 v) // glm::normalize = v * inversesqrt(dot(v, v))
 
 } // namespace
 
+// A deep copy of what the TREE of a scene is built from (crt_scene_desc borrows the caller's arrays for the duration of
+// crt_hip_set_scene only): geometry, meshes, parameterised meshes with their material ids, instances, materials (the textured flag
+// of a material id is read from them), lights. Texture images are not copied -- the refinement does not read them
+// (scene_prepare.h prepare_scene tree_only).
+struct SceneCopy {
+    std::vector<std::vector<float>> verts, uvs;
+    std::vector<std::vector<uint32_t>> indices, mat_ids;
+    std::vector<crt_geometry_desc> geoms;
+    std::vector<crt_mesh_desc> meshes;
+    std::vector<crt_parameterized_mesh_desc> pmeshes;
+    std::vector<crt_instance_desc> instances;
+    std::vector<float> materials, lights;
+    crt_scene_desc desc{};
+    explicit SceneCopy(const crt_scene_desc &s)
+    {
+        geoms.resize(s.n_geometries);
+        verts.resize(s.n_geometries);
+        uvs.resize(s.n_geometries);
+        indices.resize(s.n_geometries);
+        for (uint32_t g = 0; g < s.n_geometries; ++g) {
+            const crt_geometry_desc &in = s.geometries[g];
+            verts[g].assign(in.vertices, in.vertices + 3 * in.n_vertices);
+            indices[g].assign(in.indices, in.indices + 3 * in.n_triangles);
+            if (in.uvs) {
+                uvs[g].assign(in.uvs, in.uvs + 2 * in.n_vertices);
+            }
+            geoms[g] = crt_geometry_desc{verts[g].data(), in.n_vertices, indices[g].data(), in.n_triangles, in.uvs ? uvs[g].data() : nullptr};
+        }
+        meshes.assign(s.meshes, s.meshes + s.n_meshes);
+        pmeshes.assign(s.parameterized_meshes, s.parameterized_meshes + s.n_parameterized_meshes);
+        mat_ids.resize(s.n_parameterized_meshes);
+        for (uint32_t k = 0; k < s.n_parameterized_meshes; ++k) {
+            mat_ids[k].assign(pmeshes[k].material_ids, pmeshes[k].material_ids + pmeshes[k].n_material_ids);
+            pmeshes[k].material_ids = mat_ids[k].data();
+        }
+        instances.assign(s.instances, s.instances + s.n_instances);
+        materials.assign(s.materials, s.materials + (size_t)16 * s.n_materials);
+        lights.assign(s.lights, s.lights + (size_t)20 * s.n_lights);
+        desc = s;
+        desc.geometries = geoms.data();
+        desc.meshes = meshes.data();
+        desc.parameterized_meshes = pmeshes.data();
+        desc.instances = instances.data();
+        desc.materials = materials.data();
+        desc.lights = lights.data();
+        desc.textures = nullptr; // (never read by a tree-only preparation)
+    }
+};
+
+// The better tree of CRT_HIP_FLAG_REFINE_IN_BACKGROUND, built and uploaded by the context's refinement thread, waiting to be
+// swapped in between two frames (swap_in_refined_tree). Only what depends on the tree: everything else of the scene stays.
+struct RefinedTree {
+    DeviceBuffer nodes, slots, tri_uvs, instances;
+    uint64_t n_nodes = 0, n_slots = 0;
+    uint32_t stack_need = 0, two_level = 0, n_top = 0;
+    int32_t root = 0, world_inst = -1;
+    QFrame root_frame{};
+    double build_ms = 0.0;
+};
+
 struct crt_hip_ctx {
     int device = 0;
     uint32_t flags = 0;
@@ -176,6 +237,14 @@ struct crt_hip_ctx {
     DeviceBuffer d_nodes, d_slots, d_instances, d_material_ids, d_materials, d_textures, d_texels, d_lights;
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t stack_need = 0; // traversal-stack entries the deepest path of this scene's BVH can need
+    // CRT_HIP_FLAG_REFINE_IN_BACKGROUND: set_scene uploads a quickly built tree and this thread builds the full-quality one
+    // (host SAH + re-insertion), uploads it on a stream of its own and parks it in `refined`; the next render_begin swaps it in.
+    // refine_state: 0 none, 1 building, 2 ready to be swapped in, 3 swapped in, -1 failed (refine_error says why; the quick tree stays).
+    std::thread refine_thread;
+    std::atomic<int> refine_state{0};
+    std::unique_ptr<RefinedTree> refined;
+    std::string refine_error;
+    double refine_quick_ms = 0.0, refine_full_ms = 0.0;
 
     // wavefront state
     uint64_t capacity = 0; // paths per pass (every lane's queues hold that many)
@@ -205,6 +274,9 @@ struct crt_hip_ctx {
 
     ~crt_hip_ctx()
     {
+        if (refine_thread.joinable()) {
+            refine_thread.join();
+        }
         for (hipEvent_t e : events) {
             (void)hipEventDestroy(e);
         }
@@ -475,6 +547,9 @@ crt_hip_ctx *crt_hip_create(int device_id, uint32_t flags)
 void crt_hip_destroy(crt_hip_ctx *ctx)
 {
     if (ctx) {
+        if (ctx->refine_thread.joinable()) {
+            ctx->refine_thread.join();
+        }
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         delete ctx;
@@ -622,6 +697,116 @@ void upload_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene &ps)
     ctx->has_scene = true;
 }
 
+// ---- CRT_HIP_FLAG_REFINE_IN_BACKGROUND ---------------------------------------------------------------------------------------
+// A frame's image does not depend on the tree (closest hit = lexicographic minimum, occlusion = boolean: any correct tree gives
+// the same bits), so a better tree may replace the one in use BETWEEN two frames of an accumulation without anybody noticing
+// anything but the frame time. set_scene returns as soon as a quickly built tree is resident -- the host SAH tree without
+// re-insertion passes, or the device builder's linear tree with CRT_HIP_BUILD=device -- and this thread builds the tree the
+// default path would have made the caller wait for (embree_utils.cpp:63-76,121-129: the reference's rtcCommitScene blocks).
+void wait_for_refinement(crt_hip_ctx *ctx)
+{
+    if (ctx->refine_thread.joinable()) {
+        ctx->refine_thread.join();
+    }
+}
+
+void refinement_thread(crt_hip_ctx *ctx, std::shared_ptr<SceneCopy> scene, int n_threads)
+{
+    try {
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        crt_hip_prepared_scene ps;
+        prepare_scene(&scene->desc, &ps, n_threads, -1, -1, true); // host SAH + the environment's / default re-insertion passes; tree only
+        scene.reset();
+        std::unique_ptr<RefinedTree> r(new RefinedTree);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t up = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        try {
+            upload(r->nodes, ps.nodes, up);
+            upload(r->slots, ps.slots, up);
+            upload(r->tri_uvs, ps.tri_uvs, up);
+            upload(r->instances, ps.insts, up);
+        } catch (...) {
+            (void)hipStreamDestroy(up);
+            throw;
+        }
+        (void)hipStreamDestroy(up);
+        r->n_nodes = ps.nodes.size();
+        r->n_slots = ps.slots.size();
+        r->stack_need = ps.stack_need;
+        r->two_level = ps.two_level;
+        r->n_top = ps.n_top;
+        r->root = ps.root;
+        r->world_inst = ps.world_inst;
+        r->root_frame = ps.root_frame;
+        r->build_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        ctx->refine_full_ms = r->build_ms;
+        ctx->refined = std::move(r);
+        ctx->refine_state.store(2, std::memory_order_release);
+    } catch (const HipError &e) {
+        ctx->refine_error = e.msg;
+        ctx->refine_state.store(-1, std::memory_order_release);
+    } catch (const std::exception &e) {
+        ctx->refine_error = e.what();
+        ctx->refine_state.store(-1, std::memory_order_release);
+    }
+}
+
+// render_begin: if the refined tree is ready, let the frames in flight finish and swap it in (pointers only: it is resident already)
+void swap_in_refined_tree(crt_hip_ctx *ctx)
+{
+    if (ctx->refine_state.load(std::memory_order_acquire) != 2) {
+        return;
+    }
+    wait_for_refinement(ctx);
+    for (crt_hip_ctx::FrameSlot &f : ctx->slots) {
+        if (f.pending) {
+            HIP_CHECK(hipEventSynchronize(f.done)); // (its statistics are still collected by render_end)
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RefinedTree &r = *ctx->refined;
+    SceneView &sv = ctx->sv;
+    if (r.two_level != sv.two_level || r.n_slots != ctx->n_tris) {
+        ctx->refine_error = "the refined tree is of another kind than the quick one";
+        ctx->refined.reset();
+        ctx->refine_state.store(-1, std::memory_order_release);
+        return;
+    }
+    std::swap(ctx->d_nodes.ptr, r.nodes.ptr);
+    std::swap(ctx->d_nodes.bytes, r.nodes.bytes);
+    std::swap(ctx->d_slots.ptr, r.slots.ptr);
+    std::swap(ctx->d_slots.bytes, r.slots.bytes);
+    std::swap(ctx->d_tri_uvs.ptr, r.tri_uvs.ptr);
+    std::swap(ctx->d_tri_uvs.bytes, r.tri_uvs.bytes);
+    std::swap(ctx->d_instances.ptr, r.instances.ptr);
+    std::swap(ctx->d_instances.bytes, r.instances.bytes);
+    ctx->n_nodes = r.n_nodes;
+    sv.nodes = ctx->d_nodes.as<PNode>();
+    sv.slots = ctx->d_slots.as<LeafSlot>();
+    sv.tri_uvs = ctx->d_tri_uvs.as<float>();
+    sv.instances = ctx->d_instances.as<InstanceRec>();
+    sv.root = r.root;
+    sv.root_frame = r.root_frame;
+    sv.world_inst = r.world_inst;
+    sv.n_top_nodes = std::min<uint32_t>(r.n_top, r.two_level == 1u ? (uint32_t)CRT_MAX_TOP_NODES_TWO_LEVEL : (uint32_t)CRT_MAX_TOP_NODES);
+    if (r.stack_need > ctx->stack_need) { // a deeper tree: the HBM part of the traversal stack grows with it
+        const uint32_t lds_stack = traversal_lds_stack(r.two_level);
+        sv.spill_depth = std::max<uint32_t>(8u, r.stack_need > lds_stack ? r.stack_need - lds_stack : 0u);
+        const size_t spill_words = (size_t)sv.spill_stride * sv.spill_depth;
+        ctx->d_spill.alloc((size_t)(ctx->overlap ? 2 : 1) * (size_t)ctx->n_lanes * spill_words * sizeof(int32_t));
+        sv.stack_spill = ctx->d_spill.as<int32_t>();
+        ctx->capacity = 0; // (the pass lanes' spill slabs are carved from it: setup_queues again)
+    }
+    ctx->stack_need = std::max(ctx->stack_need, r.stack_need);
+    ctx->refined.reset(); // frees the quick tree's arrays
+    ctx->refine_state.store(3, std::memory_order_release);
+    if (std::getenv("CRT_HIP_DEBUG")) {
+        std::fprintf(stderr, "[crt_hip] refined tree swapped in: %llu nodes, built + uploaded in the background in %.1f ms (set_scene returned after %.1f ms)\n",
+                     (unsigned long long)ctx->n_nodes, ctx->refine_full_ms, ctx->refine_quick_ms);
+    }
+}
+
 } // namespace
 
 
@@ -764,6 +949,9 @@ int crt_hip_set_prepared_scene(crt_hip_ctx *ctx, const crt_hip_prepared_scene *p
         if (!ps) {
             return fail(ctx, CRT_HIP_EINVAL, "prepared scene is null");
         }
+        wait_for_refinement(ctx); // (of an earlier scene)
+        ctx->refined.reset();
+        ctx->refine_state.store(0);
         upload_scene(ctx, *ps);
         return CRT_HIP_OK;
     });
@@ -776,17 +964,46 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         if (frames_in_flight(ctx)) {
             return fail(ctx, CRT_HIP_ESTATE, "a frame enqueued with crt_hip_render_begin is still in flight: collect it with crt_hip_render_end first");
         }
+        wait_for_refinement(ctx); // (of an earlier scene)
+        ctx->refined.reset();
+        ctx->refine_state.store(0);
         crt_hip_prepared_scene ps;
         const char *where = std::getenv("CRT_HIP_BUILD"); // "device": BLAS of large meshes built on this context's GPU
-        prepare_scene(s, &ps, host_threads(), where && std::strcmp(where, "device") == 0 ? ctx->device : -1);
+        const bool refine = (ctx->flags & CRT_HIP_FLAG_REFINE_IN_BACKGROUND) != 0;
+        const auto t_prep = std::chrono::high_resolution_clock::now();
+        // (refine: the quick tree -- no re-insertion passes on the host; the full-quality tree follows in the background)
+        prepare_scene(s, &ps, host_threads(), where && std::strcmp(where, "device") == 0 ? ctx->device : -1, refine ? 0 : -1);
         const auto t0 = std::chrono::high_resolution_clock::now();
         upload_scene(ctx, ps);
+        if (refine && !ps.slots.empty() && ps.slots.size() >= 4096) { // (small scenes build in milliseconds either way)
+            ctx->refine_quick_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_prep).count();
+            ctx->refine_state.store(1);
+            ctx->refine_thread = std::thread(refinement_thread, ctx, std::make_shared<SceneCopy>(*s), host_threads());
+        }
         if (std::getenv("CRT_HIP_DEBUG")) {
             std::fprintf(stderr, "[crt_hip] set_scene %-22s %8.1f ms\n", "upload",
                          std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
         }
         return CRT_HIP_OK;
     });
+}
+
+int crt_hip_refine_state(crt_hip_ctx *ctx, double *quick_ms, double *full_ms)
+{
+    if (!ctx) {
+        return 0;
+    }
+    const int st = ctx->refine_state.load(std::memory_order_acquire);
+    if (quick_ms) {
+        *quick_ms = ctx->refine_quick_ms;
+    }
+    if (full_ms) {
+        *full_ms = st >= 2 ? ctx->refine_full_ms : 0.0;
+    }
+    if (st < 0) {
+        ctx->err = "background refinement failed: " + ctx->refine_error;
+    }
+    return st;
 }
 
 int32_t crt_hip_world_instance(crt_hip_ctx *ctx) { return ctx && ctx->has_scene ? ctx->sv.world_inst : -1; }
@@ -805,6 +1022,7 @@ int crt_hip_render_begin(crt_hip_ctx *ctx, const float pos[3], const float dir_[
         if (fs.pending) {
             return fail(ctx, CRT_HIP_ESTATE, "render_begin: two frames are in flight already; collect one with crt_hip_render_end");
         }
+        swap_in_refined_tree(ctx); // CRT_HIP_FLAG_REFINE_IN_BACKGROUND: the better tree, if it has arrived
         if (readback && frames_in_flight(ctx)) {
             // there is ONE host image (RenderBackend::img): a second frame's copy would overwrite the first one's before its
             // render_end hands it out. Pipelined callers read tiles / the device framebuffer; a host image wants one frame at a time

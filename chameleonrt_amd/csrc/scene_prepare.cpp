@@ -289,8 +289,10 @@ struct ScenePreparer {
     const bool dbg = std::getenv("CRT_HIP_DEBUG") != nullptr;
     std::chrono::high_resolution_clock::time_point t_phase = std::chrono::high_resolution_clock::now();
 
-    ScenePreparer(const crt_scene_desc *scene, crt_hip_prepared_scene *prepared, int threads, int device)
-        : s(scene), ps(prepared), n_threads(threads), build_device(device)
+    const int reinsert_passes; // build_bvh's: < 0 = the environment's / default
+    const bool tree_only;      // prepare_scene: skip validation and textures (done by an earlier call on the same scene)
+    ScenePreparer(const crt_scene_desc *scene, crt_hip_prepared_scene *prepared, int threads, int device, int reinsert, bool only_tree)
+        : s(scene), ps(prepared), n_threads(threads), build_device(device), reinsert_passes(reinsert), tree_only(only_tree)
     {
     }
 
@@ -306,8 +308,10 @@ struct ScenePreparer {
     void run()
     {
         const auto t_begin = t_phase;
-        check_scene(s);
-        phase("validate");
+        if (!tree_only) {
+            check_scene(s);
+            phase("validate");
+        }
         ps->spp = s->samples_per_pixel ? s->samples_per_pixel : 1;
         choose_structure();
         pair_all_geometries();
@@ -326,9 +330,11 @@ struct ScenePreparer {
         finish_references();
         pack_nodes();
         phase("TLAS + quantisation");
-        linearise_textures();
+        if (!tree_only) {
+            linearise_textures();
+            phase("textures");
+        }
         copy_tables();
-        phase("textures");
         ps->root_frame = root_frame;
         ps->root = root;
         ps->two_level = world_tree ? LEVELS_WORLD_TREE : two_level ? 1u : 0u;
@@ -552,7 +558,7 @@ struct ScenePreparer {
             built[m] = host_lbvh == 2 ? build_ploc_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                        : host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, two_level ? 0 : MAX_TOP_NODES_HOST)
                                  : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false,
-                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads);
+                                             two_level ? 0 : MAX_TOP_NODES_HOST, n_threads, reinsert_passes);
             blas_depth = std::max(blas_depth, built[m].max_depth);
             // slots in leaf order
             const size_t slot_base = slots.size();
@@ -824,7 +830,7 @@ struct ScenePreparer {
             }
             BuiltBvh tree = host_lbvh == 2 ? build_ploc_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
                             : host_lbvh ? build_lbvh_host(boxes.data(), boxes.size(), max_leaf, MAX_TOP_NODES_HOST)
-                                      : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads);
+                                      : build_bvh(boxes.data(), boxes.size(), max_leaf, 0, 0, false, MAX_TOP_NODES_HOST, n_threads, reinsert_passes);
             boxes = std::vector<Aabb>();
             blas_depth = tree.max_depth;
             slots.resize(recs.size());
@@ -1236,9 +1242,9 @@ int host_threads()
     return n;
 }
 
-void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads, int build_device)
+void prepare_scene(const crt_scene_desc *s, crt_hip_prepared_scene *ps, int n_threads, int build_device, int reinsert_passes, bool tree_only)
 {
-    ScenePreparer(s, ps, n_threads, build_device).run();
+    ScenePreparer(s, ps, n_threads, build_device, reinsert_passes, tree_only).run();
 }
 
 } // namespace crt

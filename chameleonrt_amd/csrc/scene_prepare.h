@@ -29,7 +29,11 @@ namespace crt {
 // Validates the scene (throws std::runtime_error on a malformed one: nothing may crash across the C ABI) and fills
 // `prepared`. build_device >= 0: meshes large enough to be worth it get their BLAS from the device builder
 // (bvh_device.hip) on that HIP device; -1: the host SAH builder for everything.
-void prepare_scene(const crt_scene_desc *scene, crt_hip_prepared_scene *prepared, int n_threads, int build_device = -1);
+// reinsert_passes: see build_bvh (< 0: the environment's / default). tree_only: the scene was validated and its textures prepared by
+// an earlier call -- only what depends on the TREE is filled (nodes, leaf slots, their uv records, instance records, root, frame,
+// stack need); `scene->textures` is not read (crt_core.cpp: the background refinement of CRT_HIP_FLAG_REFINE_IN_BACKGROUND).
+void prepare_scene(const crt_scene_desc *scene, crt_hip_prepared_scene *prepared, int n_threads, int build_device = -1, int reinsert_passes = -1,
+                   bool tree_only = false);
 
 // Host cores this process may use: affinity mask, capped by the cgroup CPU quota, overridable with CRT_HIP_BUILD_THREADS.
 int host_threads();

@@ -61,6 +61,14 @@ class RenderHIP:
         core.check(self._ctx, self._lib.crt_hip_set_prepared_scene(self._ctx, prepared.handle), "set_prepared_scene")
         self.samples_per_pixel = prepared.samples_per_pixel
 
+    def refine_state(self):
+        """(state, quick_ms, full_ms) of FLAG_REFINE_IN_BACKGROUND (crt_hip_refine_state): 0 none, 1 building, 2 ready, 3 in use."""
+        q, f = C.c_double(), C.c_double()
+        st = self._lib.crt_hip_refine_state(self._ctx, C.byref(q), C.byref(f))
+        if st < 0:
+            raise core.CoreError(self._lib.crt_hip_last_error(self._ctx).decode())
+        return st, q.value, f.value
+
     def render(self, pos, dir, up, fovy, camera_changed, readback_framebuffer=False) -> core.RenderStats:
         a = [np.ascontiguousarray(v, np.float32) for v in (pos, dir, up)]
         st = core.RenderStats()

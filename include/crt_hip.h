@@ -161,7 +161,16 @@ enum {
      * default path's (tests/test_gpu_elide.py), the any-hit kernel has less to do. Ray statistics keep the reference's
      * semantics (crt_render_stats::rays); the rays not traced are reported apart (shadow_rays_elided). The default traces
      * every ray the reference traces. */
-    CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS = 4
+    CRT_HIP_FLAG_ELIDE_UNUSED_SHADOW_RAYS = 4,
+    /* Opt-in (the C++ plugin sets it unless CRT_HIP_REFINE=0): crt_hip_set_scene returns as soon as a QUICKLY built tree is resident
+     * -- the host SAH tree without its re-insertion passes, or the device builder's linear tree with CRT_HIP_BUILD=device -- and a
+     * thread of the context builds the full-quality tree (what set_scene otherwise makes the caller wait for: rtcCommitScene in
+     * the reference, embree_utils.cpp:63-76,121-129), uploads it next to the quick one, and the first crt_hip_render_begin after
+     * that swaps it in between two frames. Images do not depend on the tree (closest hit = lexicographic minimum of (t, inst, geom,
+     * prim), occlusion = boolean), so the accumulation goes on undisturbed: frames with the flag are bit-identical to frames
+     * without it (tests/test_gpu_refine.py); only set_scene's latency and the first seconds' frame times differ.
+     * crt_hip_set_prepared_scene (multi-GPU: one preparation per node) is not affected. */
+    CRT_HIP_FLAG_REFINE_IN_BACKGROUND = 8
 };
 
 int crt_hip_abi_version(void);
@@ -184,6 +193,10 @@ int crt_hip_set_partition(crt_hip_ctx *ctx, int rank, int world);
 
 int crt_hip_initialize(crt_hip_ctx *ctx, int fb_width, int fb_height);
 int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *scene);
+/* CRT_HIP_FLAG_REFINE_IN_BACKGROUND: 0 = no refinement (flag off, or a scene too small to bother), 1 = the better tree is being
+ * built, 2 = built and resident, waiting for the next crt_hip_render_begin, 3 = in use, -1 = failed (crt_hip_last_error(ctx); the
+ * quick tree stays in use). quick_ms / full_ms (may be NULL): how long set_scene's own tree took, and the background one. */
+int crt_hip_refine_state(crt_hip_ctx *ctx, double *quick_ms, double *full_ms);
 
 /* set_scene in two halves, for the multi-GPU case (new functionality): the host half
  * (BLAS/TLAS build = the reference's rtcCommitScene, embree_utils.cpp:63-76,121-129; 8-bit texture

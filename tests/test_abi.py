@@ -27,6 +27,17 @@ def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(core.EXPORTS)
 
 
+def test_flag_values_of_the_header_and_the_binding_agree():
+    """Context flags are part of the boundary: the header's enum == chameleonrt_amd.core's constants."""
+    from chameleonrt_amd import core
+    src = open(os.path.join(ROOT, "include", "crt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    flags = {k: int(v) for k, v in re.findall(r"\bCRT_HIP_FLAG_([A-Z_]+)\s*=\s*(\d+)", src)}
+    assert flags == {"NONE": 0, "COUNTERS": core.FLAG_COUNTERS, "TIMING": core.FLAG_TIMING,
+                     "ELIDE_UNUSED_SHADOW_RAYS": core.FLAG_ELIDE_UNUSED_SHADOW_RAYS, "REFINE_IN_BACKGROUND": core.FLAG_REFINE_IN_BACKGROUND}
+    assert len(set(flags.values())) == len(flags) and all(v & (v - 1) == 0 for v in flags.values())  # distinct single bits
+
+
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_symbols():
         assert hasattr(lib, name), name

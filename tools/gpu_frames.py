@@ -27,10 +27,20 @@ rank, world = (int(x) for x in part.split("/")) if part else (0, 1)
 r = RenderHIP(flags=flags, rank=rank, world=world); r.initialize(w, h)
 t = time.time(); r.set_scene(sc); print("set_scene", time.time() - t, "s")
 cam = sc.cameras[0]; e, d, u = look_at(cam.position, cam.center, cam.up)
-for f in range(nframes):
+f, swapped_at = -1, None
+while f + 1 < nframes:
+    f += 1
     t = time.time()
     st = r.render(e, d, u, cam.fov_y, f == 0, False)
     wall = (time.time() - t) * 1e3
     print(f"frame {f}: wall {wall:.2f} ms render_time {st.render_time_ms:.2f} ms rays {st.rays} ({st.rays_per_second/1e6:.1f} MRay/s) closest {st.closest_ms:.3f} shadow {st.shadow_ms:.3f} shade {st.shade_ms:.3f}"
-          f" | nodes/ray c {st.closest_nodes/max(1,st.closest_rays):.1f} s {st.shadow_nodes/max(1,st.shadow_rays):.1f} tris/ray c {st.closest_tris/max(1,st.closest_rays):.1f} s {st.shadow_tris/max(1,st.shadow_rays):.1f}")
+          f" | nodes/ray c {st.closest_nodes/max(1,st.closest_rays):.1f} s {st.shadow_nodes/max(1,st.shadow_rays):.1f} tris/ray c {st.closest_tris/max(1,st.closest_rays):.1f} s {st.shadow_tris/max(1,st.shadow_rays):.1f}"
+          + (f" | refine state {r.refine_state()}" if flags & core.FLAG_REFINE_IN_BACKGROUND else ""))
+    if flags & core.FLAG_REFINE_IN_BACKGROUND:  # keep rendering until the refined tree is in use, then three frames more
+        state = r.refine_state()[0]
+        if state in (1, 2) and f == nframes - 1 and nframes < 4000:
+            nframes += 1
+        elif state == 3 and swapped_at is None:
+            swapped_at = f
+            nframes = max(nframes, f + 4)
 a = r.accum(); print("nan px", int(np.isnan(a).any(axis=2).sum()), "mean", np.nanmean(a))
