@@ -182,9 +182,17 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_raygen(ViewParams vp, const uin
 }
 
 // ---- LDS layout shared by the traversal kernels ----------------------------------------------
-template <bool TWO_LEVEL, bool INST_TRIS = false> struct TraceLds {
+// (CULL: the closest-hit kernels' stack rows carry a 16-bit entry distance per lane behind the references, traverse.h CRT_POP_CULL)
+template <bool CULL> struct StackRow {
+    int32_t ref[TRACE_BLOCK];
+};
+template <> struct StackRow<true> {
+    int32_t ref[TRACE_BLOCK];
+    uint16_t dist[TRACE_BLOCK];
+};
+template <bool TWO_LEVEL, bool INST_TRIS = false, bool CULL = false> struct TraceLds {
     PNodeHead top[(TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : MAX_TOP_NODES) + 1]; // 48 of a node's 64 bytes
-    int32_t stack[lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
+    StackRow<CULL> stack[lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS), CULL)];
     // two-level kernels: cold per-ray state of each lane (world-space ray, u / v / ids of the best hit; traverse.h)
     // world tree: the ray in the object space of the instance whose triangle the lane tested last
     float cold[lds_cold_of(levels_of(TWO_LEVEL, INST_TRIS))][TRACE_BLOCK];
@@ -202,6 +210,20 @@ template <typename Lds> CRT_DEV const PNodeHead *stage_top_nodes(const SceneView
     }
     __syncthreads();
     return lds.top; // always the LDS array (so loads through it stay ds_read); holds min(n_top_nodes, MAX_TOP_NODES) nodes
+}
+
+template <bool CULL, typename Stack, typename Lds> CRT_DEV void init_traversal_stack(Stack &st, Lds &lds, const SceneView &sc)
+{
+    st.lds = (TV_LDS int32_t *)&lds.stack[0].ref[threadIdx.x];
+    st.stride = TRACE_BLOCK;
+    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0].ref[0] + (uint32_t)(sizeof(lds.stack));
+    st.dist_off = 0u;
+    if constexpr (CULL) {
+        st.dist_off = (uint32_t)(uintptr_t)(TV_LDS uint16_t *)&lds.stack[0].dist[threadIdx.x] - (uint32_t)(uintptr_t)st.lds;
+    }
+    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
+    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
+                                  (threadIdx.x & 63));
 }
 
 // ---- K2 trace_closest ----------------------------------------------------------------------------
@@ -273,15 +295,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_clos
     if (pool_block_is_idle(pc->n_queue[bounce].v)) {
         return; // (the queue ends before this block's first chunk: traverse.h)
     }
-    __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
+    __shared__ TraceLds<TWO_LEVEL, INST_TRIS, stack_culls(false, TWO_LEVEL)> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
-    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
-    st.stride = TRACE_BLOCK;
-    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
-    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
-                                  (threadIdx.x & 63));
+    constexpr bool CULL = stack_culls(false, TWO_LEVEL);
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS), CULL), CULL> st;
+    init_traversal_stack<CULL>(st, lds, sc);
     // primary rays start at tnear = 0, later rays at EPSILON (ispc:231, 323)
     const float tnear = bounce == 0 ? 0.f : RAY_EPS;
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
@@ -366,13 +384,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, CRT_TRACE_MIN_WAVES) void k_trace_shad
     }
     __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
-    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
-    st.stride = TRACE_BLOCK;
-    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
-    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
-                                  (threadIdx.x & 63));
+    constexpr bool CULL = false;
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS), CULL), CULL> st;
+    init_traversal_stack<CULL>(st, lds, sc);
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
     const ShadowSource src{sa, sb, radiance};
     trace_wavefront<true, TWO_LEVEL, COUNTERS, ShadowSource, INST_TRIS>(sc, top, st, pc->n_shadow_a[bounce].v, &pc->cur_shadow_a[bounce].v,
@@ -942,15 +956,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_diag(SceneView sc, uint32
     if (pool_block_is_idle(n)) {
         return; // (the queue ends before this block's first chunk: traverse.h)
     }
-    __shared__ TraceLds<TWO_LEVEL, INST_TRIS> lds;
+    __shared__ TraceLds<TWO_LEVEL, INST_TRIS, stack_culls(ANY_HIT, TWO_LEVEL)> lds;
     const PNodeHead *top = stage_top_nodes(sc, lds);
-    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> st;
-    st.lds = (TV_LDS int32_t *)&lds.stack[0][threadIdx.x];
-    st.stride = TRACE_BLOCK;
-    st.limit = (uint32_t)(uintptr_t)(TV_LDS int32_t *)&lds.stack[0][0] + (uint32_t)(sizeof(lds.stack));
-    st.cold = (TV_LDS float *)&lds.cold[0][threadIdx.x];
-    st.spill = (TV_HBM int32_t *)(sc.stack_spill + (size_t)((blockIdx.x * TRACE_BLOCK + threadIdx.x) / 64) * (sc.spill_depth * 64u) +
-                                  (threadIdx.x & 63));
+    constexpr bool CULL = stack_culls(ANY_HIT, TWO_LEVEL);
+    TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS), CULL), CULL> st;
+    init_traversal_stack<CULL>(st, lds, sc);
     uint32_t n_nodes = 0, n_tris = 0, n_slots = 0;
     const DiagSource<ANY_HIT, levels_of(TWO_LEVEL, INST_TRIS)> src{sc, org, dir, tmax, out_t, out_u, out_v, out_inst, out_geom, out_prim};
     trace_wavefront<ANY_HIT, TWO_LEVEL, true, DiagSource<ANY_HIT, levels_of(TWO_LEVEL, INST_TRIS)>, INST_TRIS>(sc, top, st, n, reinterpret_cast<uint32_t *>(&counters[2]),
@@ -1116,7 +1126,9 @@ __global__ void k_kat(SceneView sc, int fn, uint32_t n, const float *in, int in_
 
 // ---- launchers ---------------------------------------------------------------------------------
 uint32_t traversal_grid_threads(int n_cus) { return (uint32_t)n_cus * CRT_TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
-uint32_t traversal_lds_stack(uint32_t levels) { return (uint32_t)lds_stack_of((int)levels); }
+// (the fewest LDS entries any kernel of that structure keeps: the closest-hit kernels' when their stack carries distances --
+// the HBM slab is sized for the deepest path beyond it)
+uint32_t traversal_lds_stack(uint32_t levels) { return (uint32_t)lds_stack_of((int)levels, stack_culls(false, levels == 1u)); }
 int traversal_child_order() { return CRT_CHILD_ORDER; }
 
 static inline int persistent_grid(const LaunchCfg &cfg, int blocks_per_cu)

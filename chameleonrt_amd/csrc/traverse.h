@@ -35,8 +35,32 @@ namespace crt {
 #ifndef CRT_LDS_STACK_WORLD_TREE
 #define CRT_LDS_STACK_WORLD_TREE 16
 #endif
-// levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE)
-constexpr int lds_stack_of(int levels) { return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? CRT_LDS_STACK_WORLD_TREE : CRT_LDS_STACK; }
+// Round 6 experiment, OFF (CRT_POP_CULL=1 builds it): the stack of the CLOSEST-HIT kernels of single trees and world trees carries each
+// entry's ENTRY DISTANCE, and an entry whose box the ray enters beyond what has meanwhile become the best hit is dropped at the pop
+// without its node being fetched. The product stacks references only and finds out by fetching the node and failing its four
+// children: 24 % of the line visits of C4's camera rays, 18 % of its bounce rays', 10 % on C3 and C2 (CPU pricing with the oracle's
+// walker, ORC_WALK_POP_CULL). The distance is kept as the upper 16 bits of the child's sort key (a bfloat16 rounded towards zero: a
+// lower bound, so nothing that could still matter is dropped) in a second LDS array, 2 bytes per entry next to the reference's 4;
+// the LDS budget of 7 blocks per CU then holds 14 / 11 entries instead of 21 / 16; entries in the HBM slab have no distance and are
+// never dropped. MEASURED (profiles/r06_pop_cull.txt): node visits per closest-hit ray of C4 29.9 -> 24.6, hits bit-identical, and
+// the kernel SLOWER -- 23.4 -> 26.7 ms with one pop per inner step, 28.7 with up to three, 30.3 with up to six: a dropped entry
+// either costs its lane the inner step the fetch would have cost (nothing gained but the request), or another LDS round trip in
+// front of the step's node fetch, which the whole wave waits for -- and each of those costs more than the L2-resident visit it saves.
+#ifndef CRT_POP_CULL
+#define CRT_POP_CULL 0
+#endif
+#ifndef CRT_LDS_STACK_CULL
+#define CRT_LDS_STACK_CULL 14
+#endif
+#ifndef CRT_LDS_STACK_WORLD_TREE_CULL
+#define CRT_LDS_STACK_WORLD_TREE_CULL 11
+#endif
+// levels: SceneView::two_level (0 one instance, 1 two-level, 2 = LEVELS_WORLD_TREE); cull: the stack carries entry distances
+constexpr bool stack_culls(bool any_hit, bool two_level) { return CRT_POP_CULL != 0 && !any_hit && !two_level; }
+constexpr int lds_stack_of(int levels, bool cull = false)
+{
+    return levels == 1 ? CRT_LDS_STACK_TWO_LEVEL : levels == 2 ? (cull ? CRT_LDS_STACK_WORLD_TREE_CULL : CRT_LDS_STACK_WORLD_TREE) : (cull ? CRT_LDS_STACK_CULL : CRT_LDS_STACK);
+}
 constexpr int lds_cold_of(int levels) { return levels == 1 ? 9 : levels == 2 ? 6 : 1; } // dwords of cold per-ray state per lane in LDS
 constexpr int levels_of(bool two_level, bool inst_tris) { return two_level ? 1 : inst_tris ? 2 : 0; }
 // Deeper entries go to an explicit HBM slab laid out [wave][depth][lane]: coalesced across a wave
@@ -63,15 +87,17 @@ struct RayHit {
 // vector instructions it issues. Entries of one lane are stride * 4 = 1024 bytes apart and a lane's column starts less
 // than that into the array, so "the entry lies in the LDS part" is one compare of `top` against `limit`, the same
 // constant for every lane (the address LDS_STACK rows into the block's stack array).
-template <int LDS_STACK> struct TraversalStack {
-    TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride]
+template <int LDS_STACK, bool DIST = false> struct TraversalStack {
+    static constexpr bool HAS_DIST = DIST;
+    TV_LDS int32_t *lds;   // this lane's column of the LDS part: entry k at lds[k * stride] (DIST: rows of [references][distances], 6 bytes per lane)
     int stride;
     TV_LDS float *cold;    // this lane's column of the cold per-ray state kept in LDS (two-level: world-space ray), same stride
     TV_HBM int32_t *spill; // this lane's column of its wave's HBM slab: entry k at spill[k * 64]
     uint32_t limit;        // LDS address of row LDS_STACK of the block's stack array
     uint32_t top;
+    uint32_t dist_off;     // DIST: LDS address of an entry's distance = the address of its reference + dist_off (a constant of the lane)
     CRT_DEV uint32_t base() const { return (uint32_t)(uintptr_t)lds; }
-    CRT_DEV uint32_t step() const { return (uint32_t)stride * 4u; }
+    CRT_DEV uint32_t step() const { return (uint32_t)stride * (DIST ? 6u : 4u); }
     CRT_DEV void clear() { top = base(); }
     CRT_DEV bool empty() const { return top == base(); }
     CRT_DEV int depth() const { return (int)((top - base()) / step()); }
@@ -80,6 +106,19 @@ template <int LDS_STACK> struct TraversalStack {
     {
         if (top < limit) {
             *(TV_LDS int32_t *)(uintptr_t)top = x;
+        } else {
+            *spilled(top) = x;
+        }
+        top += step();
+    }
+    // DIST: key = the child's sort key, whose upper 16 bits are its entry distance as a bfloat16 rounded towards zero
+    CRT_DEV void push(int32_t x, uint32_t key)
+    {
+        if (top < limit) {
+            *(TV_LDS int32_t *)(uintptr_t)top = x;
+            if (DIST) {
+                *(TV_LDS uint16_t *)(uintptr_t)(top + dist_off) = (uint16_t)(key >> 16);
+            }
         } else {
             *spilled(top) = x;
         }
@@ -94,6 +133,17 @@ template <int LDS_STACK> struct TraversalStack {
     {
         const uint32_t at = top - step();
         return at < limit ? *(TV_LDS int32_t *)(uintptr_t)at : *spilled(at);
+    }
+    // DIST: the top entry and a lower bound of the distance at which the ray enters its box (0 for an entry of the HBM slab, which has none)
+    CRT_DEV int32_t peek(float &entry_dist) const
+    {
+        const uint32_t at = top - step();
+        if (at < limit) {
+            entry_dist = __uint_as_float((uint32_t) * (TV_LDS uint16_t *)(uintptr_t)(at + dist_off) << 16);
+            return *(TV_LDS int32_t *)(uintptr_t)at;
+        }
+        entry_dist = 0.f;
+        return *spilled(at);
     }
     CRT_DEV void drop() { top -= step(); } // consume the entry peek() returned
 };
@@ -270,6 +320,7 @@ CRT_DEV V3 slot_pick(const SlotVerts &s, uint32_t sel)
 #endif
 constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not the sentinel
 constexpr int32_t CUR_EXIT = (int32_t)0x80000003; // two level: the lane popped the sentinel and has to leave its instance
+constexpr int32_t CUR_POP = (int32_t)0x80000005;  // CRT_POP_CULL: the entry the lane popped was dropped (its box lies beyond the best hit): pop again
 
 CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
@@ -306,7 +357,8 @@ CRT_DEV bool pool_block_is_idle(uint32_t n)
 // the ray transformed into that instance's object space (same expressions as the two-level entry, so the same bits),
 // which the lane keeps until a triangle of another instance comes along.
 template <bool ANY_HIT, bool TWO_LEVEL, bool COUNTERS, typename Source, bool INST_TRIS = false>
-CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS))> &st, uint32_t n,
+CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
+                             TraversalStack<lds_stack_of(levels_of(TWO_LEVEL, INST_TRIS), stack_culls(ANY_HIT, TWO_LEVEL)), stack_culls(ANY_HIT, TWO_LEVEL)> &st, uint32_t n,
                              uint32_t *cursor, float tnear, const Source &src, uint32_t &n_nodes, uint32_t &n_tris, uint32_t &n_slots,
                              uint32_t *max_ray_nodes = nullptr, float *worst_ray = nullptr,
                              unsigned long long *t_marks = nullptr /* [start, drained, end] strided by MAX_PATH_DEPTH */,
@@ -400,7 +452,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         const uint32_t bg = b.geom_sel & SLOT_GEOM_MASK, bp = (hit.tri & 1) != 0 ? b.prim1 : b.prim0;
         return geom != bg ? geom < bg : prim < bp;
     };
-    constexpr int SPEC = TWO_LEVEL ? 0 : ANY_HIT ? CRT_SPECULATE_ANYHIT : CRT_SPECULATE_CLOSEST;
+    constexpr bool CULL = stack_culls(ANY_HIT, TWO_LEVEL); // the stack carries entry distances: entries beyond the best hit are dropped at the pop
+    constexpr int SPEC = (TWO_LEVEL || CULL) ? 0 : ANY_HIT ? CRT_SPECULATE_ANYHIT : CRT_SPECULATE_CLOSEST;
     int32_t post = 0; // SPEC: the postponed leaf reference (negative), 0 = none
     int32_t cur_inst = TWO_LEVEL ? sc.world_inst : 0;
     bool in_blas = !TWO_LEVEL;
@@ -481,6 +534,15 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
     auto pop_next = [&]() {
         if (st.empty()) {
             cur = CUR_DONE;
+            return;
+        }
+        if (CULL) {
+            float entry_dist;
+            cur = st.peek(entry_dist);
+            st.drop();
+            if (entry_dist > hit.t) {
+                cur = CUR_POP; // dropped unfetched; the lane pops again at its next inner step
+            }
             return;
         }
         cur = st.pop();
@@ -567,9 +629,27 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 post = cur;
                 pop_next();
             }
+            if (CULL) {
+                // a dropped entry must not cost its lane an inner step of its own (the ray's walk would be no shorter than with the
+                // node fetched and its children failed): pop again, up to CRT_POP_CULL_ROUNDS times, while any lane of the wave has to
+#ifndef CRT_POP_CULL_ROUNDS
+#define CRT_POP_CULL_ROUNDS 3
+#endif
+#pragma unroll 1
+                for (int round = 0; round < CRT_POP_CULL_ROUNDS; ++round) {
+                    const bool again = ray >= 0 && cur == CUR_POP;
+                    if (__ballot(again) == 0ull) {
+                        break;
+                    }
+                    if (again) {
+                        pop_next();
+                    }
+                }
+            }
             const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur != CUR_DONE && !in_blas && is_instance_leaf(cur);
             const bool inner = (ray >= 0 && cur >= 0) || enter;
-            const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+            // (a lane that still has to pop again belongs to this phase: it is about to reach a node, a leaf or the end of its stack)
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner || (CULL && ray >= 0 && cur == CUR_POP)));
             if (n_inner == 0 || CRT_INNER_DEN * n_inner < CRT_INNER_NUM * n_active) {
                 break;
             }
@@ -657,33 +737,41 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                     // nearest child first, the other entered children stacked in slot order: no sort network
                     const uint32_t nearest = min(min(s0, s1), min(s2, s3));
                     if (nearest == 0xffffffffu) {
-                        pop_next();
+                        if (CULL) {
+                            cur = CUR_POP; // (ONE pop site per iteration: the top of the inner step, where dropped entries are retried too)
+                        } else {
+                            pop_next();
+                        }
                     } else {
                         if (s3 != 0xffffffffu && s3 != nearest) {
-                            st.push((int32_t)k2.w);
+                            st.push((int32_t)k2.w, s3);
                         }
                         if (s2 != 0xffffffffu && s2 != nearest) {
-                            st.push((int32_t)k2.z);
+                            st.push((int32_t)k2.z, s2);
                         }
                         if (s1 != 0xffffffffu && s1 != nearest) {
-                            st.push((int32_t)k2.y);
+                            st.push((int32_t)k2.y, s1);
                         }
                         if (s0 != 0xffffffffu && s0 != nearest) {
-                            st.push((int32_t)k2.x);
+                            st.push((int32_t)k2.x, s0);
                         }
                         cur = (int32_t)(s3 == nearest ? k2.w : s2 == nearest ? k2.z : s1 == nearest ? k2.y : k2.x); // (keys are distinct)
                     }
                 } else if (b0 == 0xffffffffu) {
-                    pop_next();
+                    if (CULL) {
+                        cur = CUR_POP;
+                    } else {
+                        pop_next();
+                    }
                 } else {
                     if (b3 != 0xffffffffu) {
-                        st.push(ref_of(b3));
+                        st.push(ref_of(b3), b3);
                     }
                     if (c2 != 0xffffffffu) {
-                        st.push(ref_of(c2));
+                        st.push(ref_of(c2), c2);
                     }
                     if (c1 != 0xffffffffu) {
-                        st.push(ref_of(c1));
+                        st.push(ref_of(c1), c1);
                     }
                     cur = ref_of(b0);
                 }
@@ -692,7 +780,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
         }
 
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
-        const bool leaf_lane = SPEC ? (ray >= 0 && post < 0 && (SPEC == 1 || cur < 0)) : (ray >= 0 && cur < 0 && cur != CUR_DONE);
+        const bool leaf_lane = SPEC ? (ray >= 0 && post < 0 && (SPEC == 1 || cur < 0)) : (ray >= 0 && cur < 0 && cur != CUR_DONE && !(CULL && cur == CUR_POP));
         const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(__ballot(leaf_lane)) : 0u;
         if (leaf_lane) {
             bool entered = false;
@@ -734,7 +822,9 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                 const float4 *p = reinterpret_cast<const float4 *>(sc.slots + first);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 // (SPEC: the lane's next reference was popped when the leaf was postponed; nothing to fetch from the stack)
-                const bool have_next = !SPEC && !st.empty();
+                // (CULL: the lane's next entry is taken at the top of the next inner step, where its entry distance is compared with
+                // the hit distance this very step may shrink: nothing of the stack is held in registers across the tests)
+                const bool have_next = !SPEC && !CULL && !st.empty();
                 const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
                 // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
                 const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
@@ -825,6 +915,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top, Traversa
                     cur = CUR_DONE;
                 } else if (SPEC) {
                     // cur is what the lane walked on to
+                } else if (CULL) {
+                    cur = CUR_POP;
                 } else if (!have_next) {
                     cur = CUR_DONE;
                 } else {

@@ -1956,6 +1956,11 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
     std::vector<int> bad_t(nthreads, 0);
     // diagnostic (tools/tree_cost.py): ORC_WALK_SPILL_DEPTH=K counts the pops of entries above the K-th, i.e. what a
     // K-entry on-chip stack sends through memory
+    // diagnostic (tools/tree_cost.py): ORC_WALK_POP_CULL=1 prices a stack that carries each entry's entry distance -- an entry whose
+    // box lies beyond the best hit found meanwhile is dropped at the pop, without its node being fetched (closest-hit rays only;
+    // =8: the distance kept as an 8-bit lower bound, 5-bit exponent + 3-bit mantissa). The product's stack holds references only.
+    const char *pc_env = std::getenv("ORC_WALK_POP_CULL");
+    const int pop_cull = pc_env ? std::atoi(pc_env) : 0;
     const char *sd_env = std::getenv("ORC_WALK_SPILL_DEPTH");
     const size_t spill_depth = sd_env ? (size_t)std::atol(sd_env) : 0;
     std::vector<uint64_t> sp_t(nthreads, 0), pop_t(nthreads, 0);
@@ -1963,6 +1968,18 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
         uint64_t nv = 0, tt = 0, ne = 0, nb = 0, ls = 0, spill_pops = 0, pops = 0;
         uint32_t ms = 0;
         std::vector<int32_t> stack(1024);
+        std::vector<float> stack_t(1024, 0.f);
+        auto lower_bound_8bit = [](float t) { // largest value <= t with a 3-bit mantissa (and 0 for t < 2^-16)
+            if (!(t > 1.52587890625e-05f)) {
+                return 0.f;
+            }
+            uint32_t b;
+            std::memcpy(&b, &t, 4);
+            b &= 0xfff00000u;
+            float r;
+            std::memcpy(&r, &b, 4);
+            return r;
+        };
         for (uint64_t i = (uint64_t)tid; i < n; i += (uint64_t)nthreads) {
             const f3 worg = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
             const f3 wdir = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
@@ -2021,6 +2038,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                         if (child_order == 0) {
                             std::sort(keys, keys + n_hit);
                             for (int k = n_hit - 1; k >= 1; --k) {
+                                const uint32_t kb = keys[k] & ~3u;
+                                std::memcpy(&stack_t[sp], &kb, 4);
                                 stack[sp++] = nd.ref[keys[k] & 3u];
                             }
                             cur = nd.ref[keys[0] & 3u];
@@ -2033,6 +2052,8 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                             }
                             for (int k = n_hit - 1; k >= 0; --k) {
                                 if (k != nearest) {
+                                    const uint32_t kb = keys[k] & ~3u;
+                                    std::memcpy(&stack_t[sp], &kb, 4);
                                     stack[sp++] = nd.ref[keys[k] & 3u];
                                 }
                             }
@@ -2135,6 +2156,18 @@ extern "C" int orc_walk_foreign_bvh(const void *nodes_, const void *tris_, const
                     }
                     cur = stack[--sp];
                     ++pops;
+                    if (pop_cull && closest && !(two_level && cur == F_SENTINEL)) {
+                        float te = pop_cull == 8 ? lower_bound_8bit(stack_t[sp]) : stack_t[sp];
+                        if (pop_cull == 16 || pop_cull == 2 || pop_cull == 3) { // bfloat16 towards zero / exponent only / exponent + one mantissa bit
+                            uint32_t tb;
+                            std::memcpy(&tb, &te, 4);
+                            tb &= pop_cull == 16 ? 0xffff0000u : pop_cull == 2 ? 0xff800000u : 0xffc00000u;
+                            std::memcpy(&te, &tb, 4);
+                        }
+                        if (te > best) {
+                            continue; // the box was entered beyond what is now the best hit
+                        }
+                    }
                     spill_pops += sp >= spill_depth;
                     if (two_level && cur == F_SENTINEL) {
                         o = worg;
