@@ -666,6 +666,20 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 st.push(STACK_SENTINEL);
                 cur = in.blas_root;
             } else if (inner) {
+                // (CRT_INNER_PEEK) the entry the lane will continue with if the ray misses all four children is read NOW, together with
+                // the node: a step that ends in a pop then pays no LDS round trip of its own in front of the next step's fetch
+#ifndef CRT_INNER_PEEK
+#define CRT_INNER_PEEK 0
+#endif
+                constexpr bool PEEK = CRT_INNER_PEEK != 0 && !CULL && !SPEC;
+                const bool peek_has = PEEK && !st.empty();
+                const int32_t peek_ref = peek_has ? st.peek() : CUR_DONE;
+                auto pop_peeked = [&]() {
+                    if (peek_has) {
+                        st.drop();
+                    }
+                    cur = TWO_LEVEL && peek_ref == STACK_SENTINEL ? CUR_EXIT : peek_ref;
+                };
                 // three of the record's four 16-byte quarters (crt_types.h PNode): frame + x planes, y and z planes, references
                 tv_u4 k0, k1, k2;
                 if ((TWO_LEVEL ? CRT_MAX_TOP_NODES_TWO_LEVEL : CRT_MAX_TOP_NODES) > 0 && cur >= top_lo && cur < top_hi) { // LDS-resident top levels: ds_read_b128
@@ -719,7 +733,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                     // occlusion rays: any order finds the same answer; lowest used slot first
                     const bool h0 = s0 != 0xffffffffu, h1 = s1 != 0xffffffffu, h2 = s2 != 0xffffffffu, h3 = s3 != 0xffffffffu;
                     if (!(h0 || h1 || h2 || h3)) {
-                        pop_next();
+                        if (PEEK) {
+                            pop_peeked();
+                        } else {
+                            pop_next();
+                        }
                     } else {
                         const int first = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
                         if (h3 && first < 3) {
@@ -739,6 +757,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                     if (nearest == 0xffffffffu) {
                         if (CULL) {
                             cur = CUR_POP; // (ONE pop site per iteration: the top of the inner step, where dropped entries are retried too)
+                        } else if (PEEK) {
+                            pop_peeked();
                         } else {
                             pop_next();
                         }
@@ -760,6 +780,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 } else if (b0 == 0xffffffffu) {
                     if (CULL) {
                         cur = CUR_POP;
+                    } else if (PEEK) {
+                        pop_peeked();
                     } else {
                         pop_next();
                     }
