@@ -7,12 +7,13 @@
 
 namespace crt {
 
-// BFS-ordered top BVH levels the traversal kernels stage in LDS (48 B each). 5 = the root and its children: at 7 blocks
-// per CU (22.8 KB of LDS each) the 4 KB that four full levels (85 nodes) took are worth more as four more entries of
-// every lane's stack -- C4 55.4 -> 54.6 ms; 0 nodes measures the same (profiles/r04_issue_bound_ab.txt). The builder is
-// asked for this many nodes in BFS order.
+// BFS-ordered top BVH levels the traversal kernels stage in LDS (48 B each). Round 4: 85 nodes (four full levels) -> 5 (the root
+// and its children): the 4 KB are worth more as four more entries of every lane's stack -- C4 55.4 -> 54.6 ms; 0 nodes measured the
+// same then (profiles/r04_issue_bound_ab.txt). Round 6: NONE -- every instruction of the inner step counts (profiles/
+// r06_fast_push_ab.txt), and the LDS-or-HBM test of a node's address is five of them for a fetch that hits L2 anyway: C3 7.89 -> 7.82
+// ms, C4 50.95 -> 50.85, C2 +-0 on top of the branch-free pushes. The builder is asked for this many nodes in BFS order.
 #ifndef CRT_MAX_TOP_NODES
-#define CRT_MAX_TOP_NODES 5
+#define CRT_MAX_TOP_NODES 0
 #endif
 // two-level scenes: top levels of the TLAS staged in LDS: none. The LDS of the two-level kernels also holds the cold
 // ray state and a traversal stack that runs much deeper than in a single tree (26 entries on the instanced C4), and

@@ -322,6 +322,10 @@ constexpr int32_t CUR_DONE = (int32_t)0x80000001; // not a node, not a leaf, not
 constexpr int32_t CUR_EXIT = (int32_t)0x80000003; // two level: the lane popped the sentinel and has to leave its instance
 constexpr int32_t CUR_POP = (int32_t)0x80000005;  // CRT_POP_CULL: the entry the lane popped was dropped (its box lies beyond the best hit): pop again
 
+// The wave's mask of a predicate, straight from the compare that formed it. HIP's __ballot(int) first MATERIALISES the predicate as
+// 0 / 1 in a vector register and compares that with zero again: two vector instructions per ballot, and the inner step -- priced by the
+// instructions it issues, ~0.2 ms of C4 each -- has two.
+CRT_DEV uint64_t tv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 CRT_DEV uint32_t tv_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 CRT_DEV uint32_t tv_lanes_below(uint64_t mask)
 {
@@ -551,21 +555,48 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
         }
     };
 
+    // BRANCH-FREE POP (round 6, CRT_FAST_POP; single trees and world trees). pop_next() above is a nest of branches -- empty? LDS part
+    // or HBM slab? -- executed whenever any lane of the wave pops. If no popping lane's top entry lies in the HBM slab (nearly always),
+    // every lane simply READS the word below its top -- for an empty stack that is the word below its column, whatever it holds --
+    // and selects: the entry and top - step, or CUR_DONE and top. One LDS read, two selects, no branch.
+#ifndef CRT_FAST_POP
+#define CRT_FAST_POP 0
+#endif
+    constexpr bool FAST_POP = CRT_FAST_POP != 0 && !TWO_LEVEL && !CULL;
+    auto pop_next_fast = [&]() {
+        if (FAST_POP && tv_ballot(!(st.top - st.step() < st.limit)) == 0ull) { // (an empty stack passes: its top is its base, below the limit)
+            const bool has = !st.empty();
+            const int32_t entry = *(TV_LDS int32_t *)(uintptr_t)(st.top - st.step());
+            cur = has ? entry : CUR_DONE;
+            st.top -= has ? st.step() : 0u;
+        } else {
+            pop_next();
+        }
+    };
+
     // up to `want` ray indices [pool_next, pool_next + take) of the wave's pool, which is topped up from the queue cursor
     // (one atomic per CRT_POOL_CHUNK rays) when it is empty; the caller advances pool_next by what it uses
     // (guided, shrinking chunks -- round 4, a measured loss: profiles/r04_guided_chunks_ab.txt -- are gone)
     const uint32_t pool_waves = gridDim.x * (blockDim.x >> 6); // waves of the grid
     bool pool_first = CRT_POOL_STATIC_FIRST != 0;               // the wave's own chunk is still to come
+    // (the wave's index in the grid, formed NOW into a scalar register: formed where it is used, it keeps threadIdx.x alive -- a vector
+    // register, or a scratch slot in the kernels at their 72-VGPR limit -- through the whole main loop)
+    const uint32_t wave_in_grid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     auto pool_take = [&](uint32_t want) -> uint32_t {
         if (pool_next == pool_end && !exhausted) {
             constexpr uint32_t chunk = (uint32_t)CRT_POOL_CHUNK;
             uint32_t c; // chunk index
             if (pool_first) {
                 pool_first = false;
-                c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+                c = wave_in_grid;
             } else {
                 uint32_t ticket = 0;
-                if (tv_lane_id() == 0) {
+                // (the lane id is formed HERE, by an asm the optimiser cannot hoist: computed once before the main loop it is a
+                // register held -- or, in the world-tree closest-hit kernel at its 72-VGPR limit, a scratch slot -- for a value
+                // needed once per 128 rays)
+                uint32_t lane_here;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
+                if (lane_here == 0) {
                     ticket = atomicAdd(cursor, 1u);
                 }
                 c = (CRT_POOL_STATIC_FIRST ? pool_waves : 0u) + __builtin_amdgcn_readfirstlane(ticket);
@@ -587,7 +618,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
         // ---- refill idle lanes --------------------------------------------------------------
         {
             const bool idle = ray < 0;
-            const uint64_t idle_mask = __ballot(idle);
+            const uint64_t idle_mask = tv_ballot(idle);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
             if (n_idle >= CRT_REFILL_MIN && !exhausted) {
                 const uint32_t take = pool_take(n_idle);
@@ -607,7 +638,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 pool_next += take;
             }
         }
-        const uint64_t active_mask = __ballot(ray >= 0);
+        const uint64_t active_mask = tv_ballot(ray >= 0);
         pf_mark(0, 0u);
         if (active_mask == 0) {
             if (exhausted) {
@@ -619,7 +650,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
             continue;
         }
         // lanes with a ray still being traversed (a finished ray may wait for its batch to retire)
-        const uint32_t n_active = (uint32_t)__popcll(__ballot(ray >= 0 && (cur != CUR_DONE || (SPEC && post < 0))));
+        const uint32_t n_active = (uint32_t)__popcll(tv_ballot(ray >= 0 && (cur != CUR_DONE || (SPEC && post < 0))));
 
         // ---- inner-node phase: step while at least 2/3 of the active lanes are on an inner node
         for (;;) {
@@ -638,7 +669,7 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
 #pragma unroll 1
                 for (int round = 0; round < CRT_POP_CULL_ROUNDS; ++round) {
                     const bool again = ray >= 0 && cur == CUR_POP;
-                    if (__ballot(again) == 0ull) {
+                    if (tv_ballot(again) == 0ull) {
                         break;
                     }
                     if (again) {
@@ -647,9 +678,11 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 }
             }
             const bool enter = CRT_ENTRY_IN_INNER && TWO_LEVEL && ray >= 0 && cur != CUR_DONE && !in_blas && is_instance_leaf(cur);
-            const bool inner = (ray >= 0 && cur >= 0) || enter;
+            // (an idle lane -- ray < 0 -- always has cur == CUR_DONE: it was retired in that state and begin_ray is the only place that
+            // changes it; so "on an inner node" is cur >= 0 alone: one compare whose result IS the wave mask the phase rule counts)
+            const bool inner = cur >= 0 || enter;
             // (a lane that still has to pop again belongs to this phase: it is about to reach a node, a leaf or the end of its stack)
-            const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner || (CULL && ray >= 0 && cur == CUR_POP)));
+            const uint32_t n_inner = (uint32_t)__popcll(tv_ballot(inner || (CULL && ray >= 0 && cur == CUR_POP)));
             if (n_inner == 0 || CRT_INNER_DEN * n_inner < CRT_INNER_NUM * n_active) {
                 break;
             }
@@ -760,20 +793,43 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                         } else if (PEEK) {
                             pop_peeked();
                         } else {
-                            pop_next();
+                            pop_next_fast();
                         }
                     } else {
-                        if (s3 != 0xffffffffu && s3 != nearest) {
+                        // BRANCH-FREE PUSHES (round 6, CRT_FAST_PUSH). Four conditional pushes are four nests of exec-mask branches --
+                        // compare, save / restore exec, "does the entry still fit the LDS part?", store, advance: ~16 instructions each
+                        // whenever ANY lane of the wave pushes at that site, about as many as the whole box test -- and a step is priced
+                        // by the instructions it issues. If every lane of the wave that pushes at all has room for four more entries
+                        // in its LDS part (nearly always: the HBM slab is for the deepest few paths), each candidate is simply WRITTEN
+                        // at the lane's current top and the top advanced only if the child is really stacked: a store, a select and an
+                        // add per site, no branch. (What is written above the top is free space: the next real push overwrites it.)
+#ifndef CRT_FAST_PUSH
+#define CRT_FAST_PUSH 1
+#endif
+                        const bool p3 = s3 != 0xffffffffu && s3 != nearest, p2 = s2 != 0xffffffffu && s2 != nearest;
+                        const bool p1 = s1 != 0xffffffffu && s1 != nearest, p0 = s0 != 0xffffffffu && s0 != nearest;
+                        if (CRT_FAST_PUSH && !CULL && tv_ballot(!(st.top + 3u * st.step() < st.limit)) == 0ull) {
+                            *(TV_LDS int32_t *)(uintptr_t)st.top = (int32_t)k2.w;
+                            st.top += p3 ? st.step() : 0u;
+                            *(TV_LDS int32_t *)(uintptr_t)st.top = (int32_t)k2.z;
+                            st.top += p2 ? st.step() : 0u;
+                            *(TV_LDS int32_t *)(uintptr_t)st.top = (int32_t)k2.y;
+                            st.top += p1 ? st.step() : 0u;
+                            *(TV_LDS int32_t *)(uintptr_t)st.top = (int32_t)k2.x;
+                            st.top += p0 ? st.step() : 0u;
+                        } else {
+                        if (p3) {
                             st.push((int32_t)k2.w, s3);
                         }
-                        if (s2 != 0xffffffffu && s2 != nearest) {
+                        if (p2) {
                             st.push((int32_t)k2.z, s2);
                         }
-                        if (s1 != 0xffffffffu && s1 != nearest) {
+                        if (p1) {
                             st.push((int32_t)k2.y, s1);
                         }
-                        if (s0 != 0xffffffffu && s0 != nearest) {
+                        if (p0) {
                             st.push((int32_t)k2.x, s0);
+                        }
                         }
                         cur = (int32_t)(s3 == nearest ? k2.w : s2 == nearest ? k2.z : s1 == nearest ? k2.y : k2.x); // (keys are distinct)
                     }
@@ -802,8 +858,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
         }
 
         // ---- leaf phase: triangles, or entering an instance -----------------------------------
-        const bool leaf_lane = SPEC ? (ray >= 0 && post < 0 && (SPEC == 1 || cur < 0)) : (ray >= 0 && cur < 0 && cur != CUR_DONE && !(CULL && cur == CUR_POP));
-        const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(__ballot(leaf_lane)) : 0u;
+        const bool leaf_lane = SPEC ? (ray >= 0 && post < 0 && (SPEC == 1 || cur < 0)) : (cur < 0 && cur != CUR_DONE && !(CULL && cur == CUR_POP)); // (idle lanes: cur == CUR_DONE, see the inner phase)
+        const uint32_t pf_leaf_lanes = PROF ? (uint32_t)__popcll(tv_ballot(leaf_lane)) : 0u;
         if (leaf_lane) {
             bool entered = false;
             if (TWO_LEVEL && cur == CUR_EXIT) {
@@ -847,7 +903,13 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 // (CULL: the lane's next entry is taken at the top of the next inner step, where its entry distance is compared with
                 // the hit distance this very step may shrink: nothing of the stack is held in registers across the tests)
                 const bool have_next = !SPEC && !CULL && !st.empty();
-                const int32_t next_ref = have_next ? st.peek() : CUR_DONE;
+                int32_t next_ref;
+                if (FAST_POP && !SPEC && tv_ballot(!(st.top - st.step() < st.limit)) == 0ull) { // (as pop_next_fast: one read, one select, no branch)
+                    const int32_t entry = *(TV_LDS int32_t *)(uintptr_t)(st.top - st.step());
+                    next_ref = have_next ? entry : CUR_DONE;
+                } else {
+                    next_ref = have_next ? st.peek() : CUR_DONE;
+                }
                 // closest-hit rays of a frame all end at RAY_TFAR (set_ray_hit, util.ih:118): a constant, not a register
                 const float tfar = Source::CONST_TFAR ? RAY_TFAR : tfar_var;
                 auto test_slot = [&](uint32_t slot) {
@@ -958,8 +1020,8 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
         // threshold (or nothing else is left to do in this wave), not one or two per iteration.
         bool do_retire = true;
         if (CRT_DEFER_RETIRE) {
-            const uint32_t n_done = (uint32_t)__popcll(__ballot(ray >= 0 && cur == CUR_DONE && !(SPEC && post < 0)));
-            const uint32_t n_idle = (uint32_t)__popcll(__ballot(ray < 0));
+            const uint32_t n_done = (uint32_t)__popcll(tv_ballot(ray >= 0 && cur == CUR_DONE && !(SPEC && post < 0)));
+            const uint32_t n_idle = (uint32_t)__popcll(tv_ballot(ray < 0));
             const uint32_t n_wait = exhausted ? n_done : n_done + n_idle;
             do_retire = n_wait >= CRT_REFILL_MIN || n_done + n_idle == 64u;
         }
