@@ -185,6 +185,9 @@ CRT_DEV bool tri_test_raw(const V3 a, const V3 b, const V3 c, V3 O, V3 D, float 
     const float U = __uint_as_float(__float_as_uint(dot3(R, e2)) ^ sgn);
     const float V = __uint_as_float(__float_as_uint(dot3(R, e1)) ^ sgn);
     const float T = __uint_as_float(__float_as_uint(dot3(Ng, C)) ^ sgn);
+    // ONE branch for the three rejections (they are compares of values all lanes have anyway; three exec-mask nests cost a dozen
+    // scalar instructions per triangle, and a step is priced by what it issues). `&` on purpose: no short-circuit control flow.
+    // (merging the three rejections into ONE branch was measured: +-0 on C4 / C3 / C2, session r6s19)
     if (den == 0.f) {
         return false;
     }
@@ -904,7 +907,10 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                 // the hit distance this very step may shrink: nothing of the stack is held in registers across the tests)
                 const bool have_next = !SPEC && !CULL && !st.empty();
                 int32_t next_ref;
-                if (FAST_POP && !SPEC && tv_ballot(!(st.top - st.step() < st.limit)) == 0ull) { // (as pop_next_fast: one read, one select, no branch)
+#ifndef CRT_FAST_PEEK
+#define CRT_FAST_PEEK CRT_FAST_POP
+#endif
+                if (CRT_FAST_PEEK && FAST_POP && !SPEC && tv_ballot(!(st.top - st.step() < st.limit)) == 0ull) { // (as pop_next_fast: one read, one select, no branch)
                     const int32_t entry = *(TV_LDS int32_t *)(uintptr_t)(st.top - st.step());
                     next_ref = have_next ? entry : CUR_DONE;
                 } else {
