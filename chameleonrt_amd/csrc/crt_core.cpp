@@ -969,13 +969,27 @@ int crt_hip_set_scene(crt_hip_ctx *ctx, const crt_scene_desc *s)
         ctx->refine_state.store(0);
         crt_hip_prepared_scene ps;
         const char *where = std::getenv("CRT_HIP_BUILD"); // "device": BLAS of large meshes built on this context's GPU
-        const bool refine = (ctx->flags & CRT_HIP_FLAG_REFINE_IN_BACKGROUND) != 0;
+        // (a scene of a few thousand triangles builds in milliseconds either way: it gets the full-quality tree at once, not a
+        // quick one that nothing would ever replace)
+        uint64_t instanced_tris = 0;
+        if (s && s->instances && s->parameterized_meshes && s->meshes && s->geometries) {
+            for (uint32_t i = 0; i < s->n_instances; ++i) {
+                const uint32_t pm = s->instances[i].parameterized_mesh_id;
+                if (pm < s->n_parameterized_meshes && s->parameterized_meshes[pm].mesh_id < s->n_meshes) {
+                    const crt_mesh_desc &m = s->meshes[s->parameterized_meshes[pm].mesh_id];
+                    for (uint32_t g = m.first_geometry; g < m.first_geometry + m.n_geometries && g < s->n_geometries; ++g) {
+                        instanced_tris += s->geometries[g].n_triangles;
+                    }
+                }
+            }
+        }
+        const bool refine = (ctx->flags & CRT_HIP_FLAG_REFINE_IN_BACKGROUND) != 0 && instanced_tris >= 16384;
         const auto t_prep = std::chrono::high_resolution_clock::now();
         // (refine: the quick tree -- no re-insertion passes on the host; the full-quality tree follows in the background)
         prepare_scene(s, &ps, host_threads(), where && std::strcmp(where, "device") == 0 ? ctx->device : -1, refine ? 0 : -1);
         const auto t0 = std::chrono::high_resolution_clock::now();
         upload_scene(ctx, ps);
-        if (refine && !ps.slots.empty() && ps.slots.size() >= 4096) { // (small scenes build in milliseconds either way)
+        if (refine && !ps.slots.empty()) {
             ctx->refine_quick_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_prep).count();
             ctx->refine_state.store(1);
             ctx->refine_thread = std::thread(refinement_thread, ctx, std::make_shared<SceneCopy>(*s), host_threads());
