@@ -834,7 +834,17 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
                             st.push((int32_t)k2.x, s0);
                         }
                         }
-                        cur = (int32_t)(s3 == nearest ? k2.w : s2 == nearest ? k2.z : s1 == nearest ? k2.y : k2.x); // (keys are distinct)
+                        // (keys are distinct. Three selects in a row, not a nested conditional: the compiler turned that one into two nests
+                        // of exec-mask branches, fifteen instructions for what three v_cndmask do)
+#if defined(CRT_CUR_SELECT_NESTED) // (the A/B switch of the remark above)
+                        cur = (int32_t)(s3 == nearest ? k2.w : s2 == nearest ? k2.z : s1 == nearest ? k2.y : k2.x);
+#else
+                        uint32_t next_cur = k2.x;
+                        next_cur = s1 == nearest ? k2.y : next_cur;
+                        next_cur = s2 == nearest ? k2.z : next_cur;
+                        next_cur = s3 == nearest ? k2.w : next_cur;
+                        cur = (int32_t)next_cur;
+#endif
                     }
                 } else if (b0 == 0xffffffffu) {
                     if (CULL) {
