@@ -569,9 +569,10 @@ CRT_DEV void trace_wavefront(const SceneView &sc, const PNodeHead *top,
     auto pop_next_fast = [&]() {
         if (FAST_POP && tv_ballot(!(st.top - st.step() < st.limit)) == 0ull) { // (an empty stack passes: its top is its base, below the limit)
             const bool has = !st.empty();
-            const int32_t entry = *(TV_LDS int32_t *)(uintptr_t)(st.top - st.step());
+            const uint32_t below = st.top - (has ? st.step() : 0u); // (an empty stack reads its own first word: never an address outside the LDS allocation)
+            const int32_t entry = *(TV_LDS int32_t *)(uintptr_t)below;
             cur = has ? entry : CUR_DONE;
-            st.top -= has ? st.step() : 0u;
+            st.top = below;
         } else {
             pop_next();
         }
